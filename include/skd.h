@@ -1,0 +1,179 @@
+/*
+ * skd.h -- C ABI of libskd_hip.so: the MI355X (gfx950) kernels behind the
+ * distillation-step hot path of irfanICMLL/structure_knowledge_distillation.
+ *
+ * Conventions (kept from the reference's native boundary, libs/src/bn.h:7-19 and
+ * libs/src/lib_cffi.cpp:1-2,36-168):
+ *   - every entry returns int: 1 = success, 0 = failure (libs/src/bn.cu:245-249;
+ *     the Python side turns 0 into RuntimeError like libs/functions.py:13-16);
+ *   - raw DEVICE pointers + sizes only, no framework types; a NULL pointer means
+ *     "optional tensor absent" (lib_cffi.cpp:62-63 / `weight != 0` in bn.cu:153);
+ *   - the caller owns all memory, outputs are pre-sized, kernels never allocate
+ *     (the legacy skd_bn_* entries keep one grow-only scratch per device, see below);
+ *   - dweight / dbias are ACCUMULATED into (+=), caller zero-fills (bn.cu:217-229);
+ *   - asynchronous on the caller's stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the default stream) -- replaces THCState_getCurrentStream, lib_cffi.cpp:37;
+ *   - stateless / re-entrant: one host thread per GPU with that GPU current.
+ * All tensors are contiguous fp32 NCHW unless stated; N = batch, C = channels,
+ * S = product of the spatial dims (lib_cffi.cpp:24-34).
+ */
+#ifndef SKD_H_
+#define SKD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *skd_stream_t; /* hipStream_t */
+
+/* activation codes for the fused entries (libs/functions.py:7-10) */
+#define SKD_ACT_NONE 0
+#define SKD_ACT_LEAKY_RELU 1
+#define SKD_ACT_ELU 2
+
+/* library / build identification: returns e.g. 950 for gfx950 */
+int skd_abi_version(void);
+int skd_target_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * 1. Drop-in replacements, one per reference export (same argument lists).
+ * ---------------------------------------------------------------------------------- */
+/* replaces _bn_mean_var_cuda, libs/src/bn.h:7 (kernel bn.cu:125-138) */
+int skd_bn_mean_var(int N, int C, int S, const float *x, float *mean, float *var, skd_stream_t stream);
+/* replaces _bn_forward_cuda, bn.h:8-9 (kernel bn.cu:140-165); y and z may alias x */
+int skd_bn_forward(int N, int C, int S, const float *x, const float *mean, const float *var,
+                   const float *weight, const float *bias, float *y, float *z, float eps,
+                   skd_stream_t stream);
+/* replaces _bn_edz_eydz_cuda, bn.h:10-11 (kernel bn.cu:167-184) */
+int skd_bn_edz_eydz(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                    const float *bias, float *edz, float *eydz, float eps, skd_stream_t stream);
+/* replaces _bn_backward_cuda, bn.h:12-14 (kernel bn.cu:186-232); dx/dweight/dbias may be NULL */
+int skd_bn_backward(int N, int C, int S, const float *dz, const float *z, const float *var,
+                    const float *weight, const float *bias, const float *edz, const float *eydz,
+                    float *dx, float *dweight, float *dbias, float eps, skd_stream_t stream);
+/* replace _leaky_relu_cuda / _leaky_relu_backward_cuda / _elu_* , bn.h:15-19 (bn.cu:302-377);
+ * here N is the flat element count */
+int skd_leaky_relu(int64_t N, float *x, float slope, skd_stream_t stream);
+int skd_leaky_relu_backward(int64_t N, const float *x, float *dx, float slope, skd_stream_t stream);
+int skd_elu(int64_t N, float *x, skd_stream_t stream);
+int skd_elu_backward(int64_t N, const float *x, float *dx, skd_stream_t stream);
+int skd_elu_inv(int64_t N, float *x, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 2. Fused InPlace-ABN path (what libs/functions.py:70-162 does in 3-6 launches + torch ops).
+ *    Workspace: skd_abn_workspace_floats(N,C,S) floats, owned by the caller.
+ * ---------------------------------------------------------------------------------- */
+int64_t skd_abn_workspace_floats(int N, int C, int S);
+
+/* training forward, single rank: one-pass shifted statistics -> mean/var (+ running-stat update,
+ * functions.py:90-91, n = N*S*replicas) -> in-place normalise + affine(|w|+eps) + activation.
+ * running_mean / running_var may be NULL (no update). mean/var [C] receive the batch statistics. */
+int skd_abn_forward_train(int N, int C, int S, float *x, const float *weight, const float *bias,
+                          float *running_mean, float *running_var, float *mean, float *var,
+                          float momentum, float eps, int activation, float slope,
+                          float *workspace, skd_stream_t stream);
+/* split form for cross-rank synchronised statistics (functions.py:183-209):
+ *   stats   : per-rank mean/var only (no running update, no normalisation)
+ *   apply   : normalise with externally supplied (combined) mean/var; also the eval-mode forward
+ *             (mean = running_mean, var = running_var, functions.py:92-93) */
+int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, float *workspace,
+                  skd_stream_t stream);
+int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float *var,
+                  const float *weight, const float *bias, float eps, int activation, float slope,
+                  skd_stream_t stream);
+/* running-stat update with an explicit sample count n (functions.py:209) */
+int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
+                           const float *var, float momentum, double n, skd_stream_t stream);
+
+/* backward: z = saved forward OUTPUT (post activation, read-only here -- the activation is undone
+ * in registers instead of rewriting z/dz like functions.py:54-62).
+ *   reduce : edz/eydz [C] (zero when training == 0, functions.py:146-147)
+ *   dx     : dx (may be NULL), dweight/dbias (+=, may be NULL) from given edz/eydz
+ *   skd_abn_backward = reduce + dx in one call (single rank). */
+int skd_abn_backward_reduce(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                            const float *bias, float *edz, float *eydz, float eps, int activation,
+                            float slope, float *workspace, skd_stream_t stream);
+int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, const float *var,
+                        const float *weight, const float *bias, const float *edz, const float *eydz,
+                        float *dx, float *dweight, float *dbias, float eps, int activation,
+                        float slope, skd_stream_t stream);
+int skd_abn_backward(int N, int C, int S, const float *z, const float *dz, const float *var,
+                     const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                     float *dweight, float *dbias, float eps, int activation, float slope,
+                     int training, float *workspace, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 3. Pixel-wise distillation loss, utils/criterion.py:219-226 (CriterionPixelWise.forward):
+ *    loss = -sum_{n,h,w,c} softmax(T)_c * log_softmax(S)_c / (W*H)   (not divided by N).
+ *    logits (N, C, H, W) fp32; one launch produces the loss AND dloss/dS
+ *    (= (softmax(S) - softmax(T)) / (W*H)); grad_s may be NULL.
+ *    workspace: skd_pixelwise_workspace_floats(N, HW) floats.
+ * ---------------------------------------------------------------------------------- */
+int64_t skd_pixelwise_workspace_floats(int N, int HW);
+int skd_pixelwise_loss(int N, int C, int HW, const float *logits_s, const float *logits_t,
+                       float *loss /* [1] */, float *grad_s /* (N,C,HW) or NULL */,
+                       float *workspace, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 4. Pair-wise similarity loss, utils/criterion.py:236-245 + utils/utils.py:170-183.
+ *    Stages (each its own entry so the autograd wrapper can keep what backward needs):
+ *      pool   : MaxPool2d(kernel=stride=(kh,kw), pad 0, ceil_mode=True) with argmax
+ *               (flat h*W+w index inside the plane, int32; first maximum in row-major scan
+ *               order wins, NaN propagates -- PyTorch semantics)
+ *      norm   : Fhat[b,c,m] = F[b,c,m] / (sqrt(sum_c F^2) + 1e-8)      (utils.py:170-176)
+ *      gram   : G[b] = Fhat_T[b]^T Fhat_T[b] - Fhat_S[b]^T Fhat_S[b]  (M x M, fp32 MFMA);
+ *               loss = sum G^2 / M^2 / B                               (utils.py:178-183)
+ *      bwd    : dFhat_S = -4 * gscale / (M^2 B) * Fhat_S G ; dP = dFhat_S / norm
+ *      unpool : scatter dP through the argmax into a dense (B,C,H,W) gradient
+ * ---------------------------------------------------------------------------------- */
+int skd_maxpool_argmax(int planes, int H, int W, int kh, int kw, const float *x,
+                       float *pooled /* (planes, OH*OW) */, int32_t *index /* same, or NULL */,
+                       skd_stream_t stream);
+/* leading dimension (floats) of the zero-padded node axis used by the GEMM stages: M rounded up
+ * to the 128-wide MFMA tile */
+int skd_pairwise_ldm(int M);
+/* pooled (B, C, M) -> fhat (B, C, ldm) zero padded; optional node-major copy fhat_t (B, ldm, ldc)
+ * (ldc >= C, multiple of 128, zero padded; NULL to skip); norm (B, M) (NULL to skip) */
+int skd_channel_l2_normalise(int B, int C, int M, const float *pooled, float *fhat, int ldm,
+                             float *fhat_t, int ldc, float *norm, skd_stream_t stream);
+int64_t skd_pairwise_workspace_floats(int B, int M);
+/* G (B, ldm, ldm) or NULL; loss [1] */
+int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *fhat_s,
+                           const float *fhat_t, float *G, float *loss, float *workspace,
+                           skd_stream_t stream);
+/* fhat_s_t (B, ldm, ldc); grad_loss [1] on the device; dpooled (B, Cs, ldm) */
+int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t,
+                          const float *G, const float *norm_s, const float *grad_loss,
+                          float *dpooled, skd_stream_t stream);
+/* dpooled rows have stride ldp floats (ldp = ldm from above, or M for a dense tensor) */
+int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float *dpooled,
+                          int64_t ldp, const int32_t *index, float *dx /* (planes, H, W) */,
+                          skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 5. Spectral normalisation, networks/spectral.py:23-35 (one power iteration on .data):
+ *      v <- l2normalize(W^T u); u <- l2normalize(W v); sigma = u . (W v); w = W / sigma
+ *    W is (h, w) row-major (conv weight viewed as (out, in*kh*kw)); u, v updated in place.
+ *    workspace: skd_spectral_workspace_floats(h, w) floats.
+ *    backward (u, v constants): gW_bar = gW / sigma - (sum(gW * W_bar) / sigma^2) * u v^T
+ * ---------------------------------------------------------------------------------- */
+int64_t skd_spectral_workspace_floats(int h, int w);
+int skd_spectral_norm_forward(int h, int w, const float *w_bar, float *u, float *v,
+                              float *sigma /* [1] */, float *w_out /* (h,w) or NULL */,
+                              float *workspace, skd_stream_t stream);
+int skd_spectral_norm_backward(int h, int w, const float *w_bar, const float *u, const float *v,
+                               const float *sigma, const float *grad_w, float *grad_w_bar,
+                               float *workspace, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 6. Deterministic two-stage sum (used by the loss kernels; exposed for tests).
+ * ---------------------------------------------------------------------------------- */
+int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, float *workspace,
+                skd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKD_H_ */

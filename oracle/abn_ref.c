@@ -1,0 +1,272 @@
+/*
+ * oracle/abn_ref.c -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * Plain-C, host-memory restatement of the reference's native InPlace-ABN kernels and of the
+ * op sequence its autograd functions run around them.  Same C ABI as the InPlace-ABN part of
+ * include/skd.h, but the pointers are HOST pointers and `stream` is ignored, so the very same
+ * ctypes call sites can be checked against it (and tests can swap it in as a CPU double).
+ *
+ * Follows:
+ *   K1 mean_var_kernel      libs/src/bn.cu:125-138  (two passes: mean, then biased variance)
+ *   K2 forward_kernel       libs/src/bn.cu:140-165
+ *   K3 edz_eydz_kernel      libs/src/bn.cu:167-184
+ *   K4 backward_kernel      libs/src/bn.cu:186-232
+ *   K5-K9 activations       libs/src/bn.cu:302-377
+ *   op order / running stats  libs/functions.py:70-162
+ * Reductions accumulate in double (the reference's float tree order is not reproducible and
+ * not part of its contract); element-wise arithmetic is float, in the reference's order.
+ * Built by oracle/Makefile into oracle/libabn_ref.so.  Parity status: unpinned by any
+ * reference-run output (bn.cu cannot be built here); pinned against closed-form autograd.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ACT_NONE 0
+#define ACT_LEAKY 1
+#define ACT_ELU 2
+
+typedef void *stream_t;
+
+static float gamma_of(const float *w, int c, float eps) { return w ? fabsf(w[c]) + eps : 1.f; }
+static float beta_of(const float *b, int c) { return b ? b[c] : 0.f; }
+static float inv_std_of(float var, float eps) {
+  float r = 0.f;
+  if (var != 0.f || eps != 0.f) r = 1.f / sqrtf(var + eps);
+  return r;
+}
+
+int skd_abi_version(void) { return 1; }
+int skd_target_arch(void) { return 0; /* host */ }
+
+/* ---- K1 ---- */
+int skd_bn_mean_var(int N, int C, int S, const float *x, float *mean, float *var, stream_t st) {
+  (void)st;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  const double norm = 1.0 / ((double)N * (double)S);
+  for (int c = 0; c < C; ++c) {
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const float *row = x + ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) s += row[i];
+    }
+    const float m = (float)(s * norm);
+    double v = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const float *row = x + ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) {
+        const double d = (double)row[i] - (double)m;
+        v += d * d;
+      }
+    }
+    mean[c] = m;
+    var[c] = (float)(v * norm);
+  }
+  return 1;
+}
+
+/* ---- K2 ---- */
+int skd_bn_forward(int N, int C, int S, const float *x, const float *mean, const float *var,
+                   const float *weight, const float *bias, float *y, float *z, float eps, stream_t st) {
+  (void)st;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      const float m = mean[c], is = inv_std_of(var[c], eps);
+      const float g = gamma_of(weight, c, eps), b = beta_of(bias, c);
+      const int64_t off = ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) {
+        const float yy = (x[off + i] - m) * is;
+        const float zz = yy * g + b;
+        y[off + i] = yy;
+        z[off + i] = zz; /* y and z may alias: z wins, as in the reference */
+      }
+    }
+  return 1;
+}
+
+/* ---- K3 ---- */
+int skd_bn_edz_eydz(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                    const float *bias, float *edz, float *eydz, float eps, stream_t st) {
+  (void)st;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  const double norm = 1.0 / ((double)N * (double)S);
+  for (int c = 0; c < C; ++c) {
+    const float g = gamma_of(weight, c, eps), b = beta_of(bias, c);
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const int64_t off = ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) {
+        const float yy = (z[off + i] - b) / g;
+        s1 += dz[off + i];
+        s2 += (double)(yy * dz[off + i]);
+      }
+    }
+    edz[c] = (float)(s1 * norm);
+    eydz[c] = (float)(s2 * norm);
+  }
+  return 1;
+}
+
+/* ---- K4 ---- */
+int skd_bn_backward(int N, int C, int S, const float *dz, const float *z, const float *var,
+                    const float *weight, const float *bias, const float *edz, const float *eydz,
+                    float *dx, float *dweight, float *dbias, float eps, stream_t st) {
+  (void)st;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  for (int c = 0; c < C; ++c) {
+    const float g = gamma_of(weight, c, eps), b = beta_of(bias, c);
+    if (dx) {
+      const float mul = g * inv_std_of(var[c], eps);
+      for (int n = 0; n < N; ++n) {
+        const int64_t off = ((int64_t)n * C + c) * S;
+        for (int i = 0; i < S; ++i) {
+          const float yy = (z[off + i] - b) / g;
+          dx[off + i] = (dz[off + i] - edz[c] - yy * eydz[c]) * mul;
+        }
+      }
+    }
+    const float norm = (float)N * (float)S;
+    if (dweight) {
+      if (weight[c] > 0.f)
+        dweight[c] += eydz[c] * norm;
+      else if (weight[c] < 0.f)
+        dweight[c] -= eydz[c] * norm;
+    }
+    if (dbias) dbias[c] += edz[c] * norm;
+  }
+  return 1;
+}
+
+/* ---- K5-K9 ---- */
+int skd_leaky_relu(int64_t n, float *x, float slope, stream_t st) {
+  (void)st;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] < 0.f) x[i] = x[i] * slope;
+  return 1;
+}
+int skd_leaky_relu_backward(int64_t n, const float *x, float *dx, float slope, stream_t st) {
+  (void)st;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] < 0.f) dx[i] = dx[i] * slope;
+  return 1;
+}
+int skd_elu(int64_t n, float *x, stream_t st) {
+  (void)st;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] < 0.f) x[i] = expf(x[i]) - 1.f;
+  return 1;
+}
+int skd_elu_backward(int64_t n, const float *x, float *dx, stream_t st) {
+  (void)st;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] < 0.f) dx[i] = dx[i] * (x[i] + 1.f);
+  return 1;
+}
+int skd_elu_inv(int64_t n, float *x, stream_t st) {
+  (void)st;
+  for (int64_t i = 0; i < n; ++i)
+    if (x[i] < 0.f) x[i] = log1pf(x[i]);
+  return 1;
+}
+
+/* ---- the fused entries, composed exactly like libs/functions.py does ---- */
+int64_t skd_abn_workspace_floats(int N, int C, int S) {
+  (void)N; (void)S;
+  return C > 0 ? 2 * (int64_t)C : 0;
+}
+
+int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, float *ws, stream_t st) {
+  (void)ws;
+  return skd_bn_mean_var(N, C, S, x, mean, var, st);
+}
+
+int skd_abn_update_running(int C, float *rm, float *rv, const float *mean, const float *var,
+                           float momentum, double n, stream_t st) {
+  (void)st;
+  const float nf = (float)n;
+  for (int c = 0; c < C; ++c) { /* functions.py:90-91 */
+    rm[c] = rm[c] * (1.f - momentum) + momentum * mean[c];
+    rv[c] = rv[c] * (1.f - momentum) + momentum * var[c] * nf / (nf - 1.f);
+  }
+  return 1;
+}
+
+static void act_forward(int act, int64_t n, float *x, float slope) { /* functions.py:45-51 */
+  if (act == ACT_LEAKY) skd_leaky_relu(n, x, slope, 0);
+  else if (act == ACT_ELU) skd_elu(n, x, 0);
+}
+
+int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float *var,
+                  const float *weight, const float *bias, float eps, int act, float slope, stream_t st) {
+  if (!skd_bn_forward(N, C, S, x, mean, var, weight, bias, x, x, eps, st)) return 0;
+  act_forward(act, (int64_t)N * C * S, x, slope);
+  return 1;
+}
+
+int skd_abn_forward_train(int N, int C, int S, float *x, const float *weight, const float *bias,
+                          float *rm, float *rv, float *mean, float *var, float momentum, float eps,
+                          int act, float slope, float *ws, stream_t st) {
+  (void)ws;
+  if (!skd_bn_mean_var(N, C, S, x, mean, var, st)) return 0;
+  if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, (double)N * (double)S, st);
+  return skd_abn_apply(N, C, S, x, mean, var, weight, bias, eps, act, slope, st);
+}
+
+/* undo the activation on private copies (functions.py:54-62 does it in place on z and dz) */
+static int undo_act(int act, int64_t n, const float *z, const float *dz, float slope, float **zc,
+                    float **dzc) {
+  *zc = (float *)malloc(sizeof(float) * (size_t)n);
+  *dzc = (float *)malloc(sizeof(float) * (size_t)n);
+  if (!*zc || !*dzc) return 0;
+  memcpy(*zc, z, sizeof(float) * (size_t)n);
+  memcpy(*dzc, dz, sizeof(float) * (size_t)n);
+  if (act == ACT_LEAKY) {
+    skd_leaky_relu_backward(n, *zc, *dzc, slope, 0);
+    skd_leaky_relu(n, *zc, 1.f / slope, 0);
+  } else if (act == ACT_ELU) {
+    skd_elu_backward(n, *zc, *dzc, 0);
+    skd_elu_inv(n, *zc, 0);
+  }
+  return 1;
+}
+
+int skd_abn_backward_reduce(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                            const float *bias, float *edz, float *eydz, float eps, int act,
+                            float slope, float *ws, stream_t st) {
+  (void)ws;
+  float *zc, *dzc;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  if (!undo_act(act, (int64_t)N * C * S, z, dz, slope, &zc, &dzc)) return 0;
+  const int r = skd_bn_edz_eydz(N, C, S, zc, dzc, weight, bias, edz, eydz, eps, st);
+  free(zc);
+  free(dzc);
+  return r;
+}
+
+int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, const float *var,
+                        const float *weight, const float *bias, const float *edz, const float *eydz,
+                        float *dx, float *dweight, float *dbias, float eps, int act, float slope,
+                        stream_t st) {
+  float *zc, *dzc;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  if (!undo_act(act, (int64_t)N * C * S, z, dz, slope, &zc, &dzc)) return 0;
+  const int r = skd_bn_backward(N, C, S, dzc, zc, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, st);
+  free(zc);
+  free(dzc);
+  return r;
+}
+
+int skd_abn_backward(int N, int C, int S, const float *z, const float *dz, const float *var,
+                     const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                     float *dweight, float *dbias, float eps, int act, float slope, int training,
+                     float *ws, stream_t st) {
+  if (training) {
+    if (!skd_abn_backward_reduce(N, C, S, z, dz, weight, bias, edz, eydz, eps, act, slope, ws, st)) return 0;
+  } else { /* functions.py:146-147 */
+    memset(edz, 0, sizeof(float) * (size_t)C);
+    memset(eydz, 0, sizeof(float) * (size_t)C);
+  }
+  return skd_abn_backward_dx(N, C, S, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, st);
+}

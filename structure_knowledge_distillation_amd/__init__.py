@@ -1,0 +1,13 @@
+"""MI355X-native distillation hot path of irfanICMLL/structure_knowledge_distillation.
+
+Sub-packages mirror the reference's import surface for this path so that its
+``train_and_eval.py`` loop runs unchanged after the aliasing shown in INTEGRATION.md:
+
+    libs      -> InPlaceABN / InPlaceABNSync            (reference: libs/)
+    networks  -> kd_model.NetModel, pspnet_combine, sagan_models, spectral
+    utils     -> criterion (the six loss classes), utils (sim_dis_compute ...), parallel shims
+
+All device work goes through ``libskd_hip.so`` (hand-written gfx950 kernels behind the C ABI of
+include/skd.h) or MIOpen/rocBLAS via PyTorch-ROCm for the convolutions.  There is no CPU path.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,148 @@
+"""ctypes binding of libskd_hip.so (the C ABI declared in include/skd.h).
+
+Replaces the reference's cffi shim (libs/_ext/__init__.py + libs/src/lib_cffi.cpp, which unwrap
+THCudaTensor*): here the Python side passes raw device pointers (``tensor.data_ptr()``) and the
+current HIP stream.  There is NO fallback: if the shared library is missing or a symbol cannot
+be resolved, every op raises -- a GPU box must never silently run an eager substitute.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskd_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "skd.h"))
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+_D = _c.c_double
+
+# name -> (restype, argtypes); mirrors include/skd.h one to one (tests/test_abi.py checks that
+# every prototype in the header is listed here and exported by the .so).
+SIGNATURES = {
+    "skd_abi_version": (_I, []),
+    "skd_target_arch": (_I, []),
+    "skd_bn_mean_var": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "skd_bn_forward": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "skd_bn_edz_eydz": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "skd_bn_backward": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P]),
+    "skd_leaky_relu": (_I, [_L, _P, _F, _P]),
+    "skd_leaky_relu_backward": (_I, [_L, _P, _P, _F, _P]),
+    "skd_elu": (_I, [_L, _P, _P]),
+    "skd_elu_backward": (_I, [_L, _P, _P, _P]),
+    "skd_elu_inv": (_I, [_L, _P, _P]),
+    "skd_abn_workspace_floats": (_L, [_I, _I, _I]),
+    "skd_abn_forward_train": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _P, _P]),
+    "skd_abn_stats": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "skd_abn_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _F, _I, _F, _P]),
+    "skd_abn_update_running": (_I, [_I, _P, _P, _P, _P, _F, _D, _P]),
+    "skd_abn_backward_reduce": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
+    "skd_abn_backward_dx": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P]),
+    "skd_abn_backward": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _P, _P]),
+    "skd_pixelwise_workspace_floats": (_L, [_I, _I]),
+    "skd_pixelwise_loss": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "skd_maxpool_argmax": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_pairwise_ldm": (_I, [_I]),
+    "skd_channel_l2_normalise": (_I, [_I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
+    "skd_pairwise_workspace_floats": (_L, [_I, _I]),
+    "skd_pairwise_gram_loss": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "skd_pairwise_backward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "skd_maxunpool_scatter": (_I, [_I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "skd_spectral_workspace_floats": (_L, [_I, _I]),
+    "skd_spectral_norm_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "skd_spectral_norm_backward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "skd_sum_f32": (_I, [_L, _P, _P, _F, _P, _P]),
+}
+
+_lib = None
+_test_backend = None  # see install_test_backend()
+
+
+class SkdLibraryError(RuntimeError):
+    pass
+
+
+def header_prototypes(path=HEADER_PATH):
+    """Names of all functions declared in include/skd.h (used by tests/test_abi.py)."""
+    with open(path) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(skd_[a-z0-9_]+)\s*\(", text)))
+
+
+def load(path=None):
+    """dlopen libskd_hip.so and type every entry point.  Raises SkdLibraryError when absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise SkdLibraryError(
+            "libskd_hip.so not found at %s -- build it with "
+            "`python -m structure_knowledge_distillation_amd.build` (there is no CPU/eager fallback)" % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise SkdLibraryError("cannot load %s: %s" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise SkdLibraryError("libskd_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def get():
+    """The library object the ops call into (the HIP library, or a test double)."""
+    if _test_backend is not None:
+        return _test_backend
+    return load()
+
+
+def install_test_backend(backend):
+    """TEST HOOK ONLY: route the C-ABI calls to ``backend`` (an object exposing the same
+    functions on HOST pointers).  tests/ uses it to exercise the host-side logic (autograd
+    wiring, in-place contract, cross-rank statistics exchange over gloo) on a box without a GPU.
+    Product code never calls this; with no backend installed every op requires CUDA tensors."""
+    global _test_backend
+    _test_backend = backend
+
+
+def test_backend_active():
+    return _test_backend is not None
+
+
+def check(ok, what):
+    """1 = success / 0 = failure, like libs/functions.py:13-16 (_check)."""
+    if not ok:
+        raise RuntimeError("HIP error encountered in %s" % what)
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None (lib_cffi.cpp:62-63 convention)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """hipStream_t of torch's current stream on t's device (replaces THCState_getCurrentStream)."""
+    if _test_backend is not None or not t.is_cuda:
+        return None
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device(*tensors):
+    """Fail loudly instead of falling back when handed CPU tensors (unless a test double is in)."""
+    if _test_backend is not None:
+        return
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SkdLibraryError(
+                "structure_knowledge_distillation_amd ops run on MI355X only: got a %s tensor "
+                "(no CPU fallback exists)" % t.device)

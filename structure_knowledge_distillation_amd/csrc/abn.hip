@@ -1,0 +1,673 @@
+// abn.hip -- InPlace-ABN (fused batch-norm + activation) for gfx950.
+//
+// Replaces the reference's only native component, libs/src/bn.cu (K1 mean_var 125-138,
+// K2 forward 140-165, K3 edz_eydz 167-184, K4 backward 186-232, K5-K9 activations 302-377)
+// and the op ordering of libs/functions.py:70-162.  Not a translation: the reference launches
+// C workgroups (one per channel, each looping over all N*S elements, two passes for the
+// variance, separate thrust passes for the activation).  Here:
+//   * work is cut into contiguous runs of <= kChunk floats of ONE (n, c) row, so a launch has
+//     N*C*pieces workgroups (4096 for an (8,512,65,65) tensor) that each stream 16-32 KiB with
+//     16-byte loads -- the kernels are HBM-bound and sized to cover all 256 CUs several times;
+//   * statistics are ONE pass: sums of (x-K) and (x-K)^2 around a per-channel pivot K = x[0,c,0]
+//     (shifted-data variance; no catastrophic cancellation, no second read of x);
+//   * per-workgroup partials are combined by a tiny finalize kernel in double precision in a
+//     fixed order (deterministic, no atomics), which also performs the running-stat update;
+//   * normalise + affine(|w|+eps) + activation is one in-place pass; backward undoes the
+//     activation in registers (z is never rewritten) and fuses it into both backward passes.
+// Algorithmic bytes/element (fp32): train fwd 12 (R,R,W), train bwd 20 (R z,dz; R z,dz, W dx),
+// eval fwd 8 -- versus 16-24 / 20-40 for the reference launch sequence.
+#include "skd_common.hpp"
+
+namespace skd {
+namespace {
+
+constexpr int kChunk = 8192;  // max floats per workgroup run (32 KiB)
+
+// How the (N, C, S) tensor is cut into workgroup items.
+//   S large : every (n, c) row is split into `pieces` runs of `chunk` floats, rows_per_item = 1
+//   S small : one item covers `rows_per_item` consecutive n of the same channel
+// P = items per channel = number of partial slots per channel.
+struct Plan {
+  int pieces, chunk, rows_per_item, groups, P;
+  int64_t items;
+};
+
+static Plan make_plan(int N, int C, int S) {
+  Plan p;
+  if (2 * S >= kChunk) {
+    p.pieces = (int)cdiv(S, kChunk);
+    p.chunk = (int)((cdiv(S, p.pieces) + 3) & ~(int64_t)3);
+    p.pieces = (int)cdiv(S, p.chunk);
+    p.rows_per_item = 1;
+    p.groups = N;
+  } else {
+    p.pieces = 1;
+    p.chunk = S;
+    int r = kChunk / (S > 0 ? S : 1);
+    if (r < 1) r = 1;
+    if (r > N) r = N;
+    p.rows_per_item = r;
+    p.groups = (int)cdiv(N, r);
+  }
+  p.P = p.groups * p.pieces;
+  p.items = (int64_t)p.P * C;
+  return p;
+}
+
+struct Item {
+  int c, p, n0, n1, start, len;
+};
+
+// item index -> (channel, partial slot, row range, run inside the row).  Items are numbered in
+// memory order for rows_per_item == 1 so that neighbouring workgroups touch neighbouring DRAM.
+__device__ __forceinline__ Item decode(int64_t w, int N, int C, int S, const Plan &pl) {
+  Item it;
+  if (pl.rows_per_item == 1) {
+    const int piece = (int)(w % pl.pieces);
+    const int64_t row = w / pl.pieces;
+    const int n = (int)(row / C);
+    it.c = (int)(row % C);
+    it.n0 = n;
+    it.n1 = n + 1;
+    it.start = piece * pl.chunk;
+    it.len = min(pl.chunk, S - it.start);
+    it.p = n * pl.pieces + piece;
+  } else {
+    it.c = (int)(w % C);
+    const int g = (int)(w / C);
+    it.n0 = g * pl.rows_per_item;
+    it.n1 = min(N, it.n0 + pl.rows_per_item);
+    it.start = 0;
+    it.len = S;
+    it.p = g;
+  }
+  return it;
+}
+
+__device__ __forceinline__ float gamma_of(const float *weight, int c, float eps) {
+  return weight != nullptr ? fabsf(weight[c]) + eps : 1.f;  // bn.cu:153
+}
+__device__ __forceinline__ float beta_of(const float *bias, int c) {
+  return bias != nullptr ? bias[c] : 0.f;  // bn.cu:154
+}
+__device__ __forceinline__ float inv_std_of(float var, float eps) {
+  return (var != 0.f || eps != 0.f) ? 1.f / sqrtf(var + eps) : 0.f;  // bn.cu:148-151
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z, float slope) {
+  if (ACT == SKD_ACT_LEAKY_RELU) return z < 0.f ? z * slope : z;        // bn.cu:302-315
+  if (ACT == SKD_ACT_ELU) return z < 0.f ? expf(z) - 1.f : z;           // bn.cu:333-346
+  return z;
+}
+// undo the activation on (z, dz) in registers: functions.py:54-62 / bn.cu:317-331,348-377
+template <int ACT>
+__device__ __forceinline__ void act_undo(float &z, float &dz, float slope, float inv_slope) {
+  if (ACT == SKD_ACT_LEAKY_RELU) {
+    if (z < 0.f) {
+      dz *= slope;
+      z *= inv_slope;
+    }
+  } else if (ACT == SKD_ACT_ELU) {
+    if (z < 0.f) {
+      dz *= (z + 1.f);
+      z = log1pf(z);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1': shifted one-pass statistics.  part[(c*P + p)*2 + {0,1}] = sum(x-K), sum((x-K)^2)
+// ---------------------------------------------------------------------------------------------
+struct StatsOp {
+  const float *row;
+  float K, s1, s2;
+  __device__ __forceinline__ float ld1(int i) const { return row[i]; }
+  __device__ __forceinline__ void use1(int, float v) {
+    const float d = v - K;
+    s1 += d;
+    s2 += d * d;
+  }
+  __device__ __forceinline__ float4 ld4(int i) const {
+    return *reinterpret_cast<const float4 *>(row + i);
+  }
+  __device__ __forceinline__ void use4(int, float4 v) {
+    const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+    s1 += (d0 + d1) + (d2 + d3);
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void abn_stats_partial_kernel(const float *__restrict__ x,
+                                                                    float *__restrict__ part, int N,
+                                                                    int C, int S, Plan pl) {
+  __shared__ float red[2 * kWavesPerWG];
+  const Item it = decode(blockIdx.x, N, C, S, pl);
+  StatsOp op;
+  op.K = x[(int64_t)it.c * S];  // pivot: first element of channel c in sample 0 (uniform load)
+  op.s1 = 0.f;
+  op.s2 = 0.f;
+  for (int n = it.n0; n < it.n1; ++n) {
+    op.row = x + ((int64_t)n * C + it.c) * S + it.start;
+    stream_run(reinterpret_cast<uintptr_t>(op.row), it.len, op);
+  }
+  float a = op.s1, b = op.s2;
+  block_sum2(a, b, red);
+  if (threadIdx.x == 0) {
+    float *dst = part + ((int64_t)it.c * pl.P + it.p) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+// One wave per channel: combine P partials in double, emit mean / biased var, optionally update
+// the running statistics (functions.py:90-91: running_var uses var*n/(n-1), n = count*replicas).
+__global__ __launch_bounds__(kThreads) void abn_stats_finalize_kernel(
+    const float *__restrict__ x, const float *__restrict__ part, float *__restrict__ mean,
+    float *__restrict__ var, float *running_mean, float *running_var, int N, int C, int S, int P,
+    float momentum, double n_total) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int c = blockIdx.x * kWavesPerWG + threadIdx.x / kWave;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = lane; p < P; p += kWave) {
+    s1 += (double)part[((int64_t)c * P + p) * 2];
+    s2 += (double)part[((int64_t)c * P + p) * 2 + 1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    const double cnt = (double)N * (double)S;
+    const double K = (double)x[(int64_t)c * S];
+    const double d = s1 / cnt;
+    double v = s2 / cnt - d * d;
+    if (v < 0.0) v = 0.0;
+    const float m_f = (float)(K + d), v_f = (float)v;
+    mean[c] = m_f;
+    var[c] = v_f;
+    if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
+    if (running_var != nullptr) {
+      const float nf = (float)n_total;
+      running_var[c] = running_var[c] * (1.f - momentum) + momentum * v_f * nf / (nf - 1.f);
+    }
+  }
+}
+
+__global__ void abn_update_running_kernel(int C, float *running_mean, float *running_var,
+                                          const float *mean, const float *var, float momentum,
+                                          float nf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mean[c];
+  running_var[c] = running_var[c] * (1.f - momentum) + momentum * var[c] * nf / (nf - 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2': normalise + affine + activation.  Writes z (and y when y != z, the legacy two-output form).
+// ---------------------------------------------------------------------------------------------
+template <int ACT, bool WRITE_Y>
+struct ApplyOp {
+  const float *xin;
+  float *yout, *zout;
+  float mean, inv_std, gamma, beta, slope;
+  __device__ __forceinline__ float one(float v, float &y) const {
+    y = (v - mean) * inv_std;  // bn.cu:158
+    return act_fwd<ACT>(y * gamma + beta, slope);  // bn.cu:159 (+ fused K5/K7)
+  }
+  __device__ __forceinline__ float ld1(int i) const { return xin[i]; }
+  __device__ __forceinline__ void use1(int i, float v) const {
+    float y;
+    const float z = one(v, y);
+    if (WRITE_Y) yout[i] = y;
+    zout[i] = z;
+  }
+  __device__ __forceinline__ float4 ld4(int i) const {
+    return *reinterpret_cast<const float4 *>(xin + i);
+  }
+  __device__ __forceinline__ void use4(int i, float4 v) const {
+    float4 y, z;
+    z.x = one(v.x, y.x);
+    z.y = one(v.y, y.y);
+    z.z = one(v.z, y.z);
+    z.w = one(v.w, y.w);
+    if (WRITE_Y) *reinterpret_cast<float4 *>(yout + i) = y;
+    *reinterpret_cast<float4 *>(zout + i) = z;
+  }
+};
+
+template <int ACT, bool WRITE_Y>
+__global__ __launch_bounds__(kThreads) void abn_apply_kernel(
+    const float *x, const float *__restrict__ mean, const float *__restrict__ var,
+    const float *__restrict__ weight, const float *__restrict__ bias, float *y, float *z, float eps,
+    float slope, int N, int C, int S, Plan pl, int reverse) {
+  // `reverse`: walk the items backwards so that a pass that follows the statistics pass starts
+  // on the lines that pass touched last (still resident in L2 / Infinity Cache).
+  const int64_t w = reverse ? (pl.items - 1 - (int64_t)blockIdx.x) : (int64_t)blockIdx.x;
+  const Item it = decode(w, N, C, S, pl);
+  ApplyOp<ACT, WRITE_Y> op;
+  op.mean = mean[it.c];
+  op.inv_std = inv_std_of(var[it.c], eps);
+  op.gamma = gamma_of(weight, it.c, eps);
+  op.beta = beta_of(bias, it.c);
+  op.slope = slope;
+  for (int n = it.n0; n < it.n1; ++n) {
+    const int64_t off = ((int64_t)n * C + it.c) * S + it.start;
+    op.xin = x + off;
+    op.yout = y + off;
+    op.zout = z + off;
+    stream_run(reinterpret_cast<uintptr_t>(op.xin), it.len, op);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3': edz / eydz partial sums with the activation undone in registers.
+// ---------------------------------------------------------------------------------------------
+struct F4x2 {
+  float4 a, b;
+};
+struct F1x2 {
+  float a, b;
+};
+
+template <int ACT>
+struct GradReduceOp {
+  const float *z, *dz;
+  float beta, inv_gamma_unused, gamma, slope, inv_slope, s1, s2;
+  __device__ __forceinline__ void acc(float zv, float dzv) {
+    act_undo<ACT>(zv, dzv, slope, inv_slope);
+    const float y = (zv - beta) / gamma;  // bn.cu:52
+    s1 += dzv;
+    s2 += y * dzv;
+  }
+  __device__ __forceinline__ F1x2 ld1(int i) const { return F1x2{z[i], dz[i]}; }
+  __device__ __forceinline__ void use1(int, F1x2 v) { acc(v.a, v.b); }
+  __device__ __forceinline__ F4x2 ld4(int i) const {
+    return F4x2{*reinterpret_cast<const float4 *>(z + i), *reinterpret_cast<const float4 *>(dz + i)};
+  }
+  __device__ __forceinline__ void use4(int, F4x2 v) {
+    acc(v.a.x, v.b.x);
+    acc(v.a.y, v.b.y);
+    acc(v.a.z, v.b.z);
+    acc(v.a.w, v.b.w);
+  }
+};
+
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void abn_grad_partial_kernel(
+    const float *__restrict__ z, const float *__restrict__ dz, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ part, float eps, float slope, int N, int C,
+    int S, Plan pl) {
+  __shared__ float red[2 * kWavesPerWG];
+  const Item it = decode(blockIdx.x, N, C, S, pl);
+  GradReduceOp<ACT> op;
+  op.gamma = gamma_of(weight, it.c, eps);
+  op.beta = beta_of(bias, it.c);
+  op.slope = slope;
+  op.inv_slope = 1.f / slope;
+  op.s1 = 0.f;
+  op.s2 = 0.f;
+  for (int n = it.n0; n < it.n1; ++n) {
+    const int64_t off = ((int64_t)n * C + it.c) * S + it.start;
+    op.z = z + off;
+    op.dz = dz + off;
+    stream_run(reinterpret_cast<uintptr_t>(op.z), it.len, op);
+  }
+  float a = op.s1, b = op.s2;
+  block_sum2(a, b, red);
+  if (threadIdx.x == 0) {
+    float *dst = part + ((int64_t)it.c * pl.P + it.p) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void abn_grad_finalize_kernel(const float *__restrict__ part,
+                                                                    float *__restrict__ edz,
+                                                                    float *__restrict__ eydz, int N,
+                                                                    int C, int S, int P) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int c = blockIdx.x * kWavesPerWG + threadIdx.x / kWave;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = lane; p < P; p += kWave) {
+    s1 += (double)part[((int64_t)c * P + p) * 2];
+    s2 += (double)part[((int64_t)c * P + p) * 2 + 1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    const double cnt = (double)N * (double)S;
+    edz[c] = (float)(s1 / cnt);   // bn.cu:176
+    eydz[c] = (float)(s2 / cnt);  // bn.cu:177
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4': dx = (dz - edz - y*eydz) * gamma * invStd, with the activation undone in registers.
+//      dweight += sign(w)*eydz*N*S, dbias += edz*N*S by the first item of each channel.
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+struct GradDxOp {
+  const float *z, *dz;
+  float *dx;
+  float beta, gamma, slope, inv_slope, edz, eydz, mul;
+  __device__ __forceinline__ float one(float zv, float dzv) const {
+    act_undo<ACT>(zv, dzv, slope, inv_slope);
+    const float y = (zv - beta) / gamma;   // bn.cu:208
+    return (dzv - edz - y * eydz) * mul;   // bn.cu:209
+  }
+  __device__ __forceinline__ F1x2 ld1(int i) const { return F1x2{z[i], dz[i]}; }
+  __device__ __forceinline__ void use1(int i, F1x2 v) const { dx[i] = one(v.a, v.b); }
+  __device__ __forceinline__ F4x2 ld4(int i) const {
+    return F4x2{*reinterpret_cast<const float4 *>(z + i), *reinterpret_cast<const float4 *>(dz + i)};
+  }
+  __device__ __forceinline__ void use4(int i, F4x2 v) const {
+    float4 r;
+    r.x = one(v.a.x, v.b.x);
+    r.y = one(v.a.y, v.b.y);
+    r.z = one(v.a.z, v.b.z);
+    r.w = one(v.a.w, v.b.w);
+    *reinterpret_cast<float4 *>(dx + i) = r;
+  }
+};
+
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void abn_grad_dx_kernel(
+    const float *z, const float *dz, const float *__restrict__ var,
+    const float *__restrict__ weight, const float *__restrict__ bias,
+    const float *__restrict__ edz, const float *__restrict__ eydz, float *dx, float *dweight,
+    float *dbias, float eps, float slope, int N, int C, int S, Plan pl, int reverse) {
+  const int64_t w = reverse ? (pl.items - 1 - (int64_t)blockIdx.x) : (int64_t)blockIdx.x;
+  const Item it = decode(w, N, C, S, pl);
+  GradDxOp<ACT> op;
+  op.gamma = gamma_of(weight, it.c, eps);
+  op.beta = beta_of(bias, it.c);
+  op.slope = slope;
+  op.inv_slope = 1.f / slope;
+  op.edz = edz[it.c];
+  op.eydz = eydz[it.c];
+  op.mul = op.gamma * inv_std_of(var[it.c], eps);  // bn.cu:203
+  if (dx != nullptr) {
+    for (int n = it.n0; n < it.n1; ++n) {
+      const int64_t off = ((int64_t)n * C + it.c) * S + it.start;
+      op.z = z + off;
+      op.dz = dz + off;
+      op.dx = dx + off;
+      stream_run(reinterpret_cast<uintptr_t>(op.z), it.len, op);
+    }
+  }
+  if (it.p == 0 && threadIdx.x == 0) {
+    const float norm = (float)N * (float)S;  // bn.cu:215
+    if (dweight != nullptr) {
+      const float wv = weight[it.c];
+      if (wv > 0.f)
+        dweight[it.c] += op.eydz * norm;  // bn.cu:219-222
+      else if (wv < 0.f)
+        dweight[it.c] -= op.eydz * norm;
+    }
+    if (dbias != nullptr) dbias[it.c] += op.edz * norm;  // bn.cu:228
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5-K9: stand-alone activations (legacy ABI only; the fused path never launches them).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>  // 0 leaky fwd, 1 leaky bwd, 2 elu fwd, 3 elu bwd, 4 elu inv
+__global__ __launch_bounds__(kThreads) void act_kernel(int64_t n, const float *x, float *out,
+                                                       float slope) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i];
+    if (xv < 0.f) {
+      if (KIND == 0) out[i] = xv * slope;
+      if (KIND == 1) out[i] = out[i] * slope;
+      if (KIND == 2) out[i] = expf(xv) - 1.f;
+      if (KIND == 3) out[i] = out[i] * (xv + 1.f);
+      if (KIND == 4) out[i] = log1pf(xv);
+    }
+  }
+}
+
+static int act_grid(int64_t n) {
+  int64_t g = cdiv(n, kThreads);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// One grow-only scratch buffer per device for the legacy entries, whose reference signatures have
+// no workspace argument.  (The fused entries take the workspace from the caller.)
+struct Scratch {
+  float *ptr = nullptr;
+  int64_t floats = 0;
+};
+static Scratch g_scratch[64];
+
+static float *legacy_scratch(int64_t floats) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  Scratch &s = g_scratch[dev];
+  if (s.floats < floats) {
+    if (s.ptr != nullptr) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(s.ptr);
+    }
+    s.ptr = nullptr;
+    s.floats = 0;
+    int64_t want = floats < (1 << 16) ? (1 << 16) : floats;
+    if (hipMalloc(reinterpret_cast<void **>(&s.ptr), want * sizeof(float)) != hipSuccess) return nullptr;
+    s.floats = want;
+  }
+  return s.ptr;
+}
+
+static bool same_phase(const void *a, const void *b) {
+  return ((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
+template <bool WRITE_Y>
+static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x, const float *mean,
+                         const float *var, const float *weight, const float *bias, float *y, float *z,
+                         float eps, float slope, int N, int C, int S, int reverse) {
+  const dim3 grid((unsigned)pl.items), block(kThreads);
+  switch (act) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_apply_kernel<SKD_ACT_LEAKY_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      break;
+    case SKD_ACT_ELU:
+      abn_apply_kernel<SKD_ACT_ELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      break;
+    default:
+      abn_apply_kernel<SKD_ACT_NONE, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+  }
+}
+
+static int valid_dims(int N, int C, int S) { return N > 0 && C > 0 && S > 0; }
+
+}  // namespace
+}  // namespace skd
+
+using namespace skd;
+
+extern "C" {
+
+int64_t skd_abn_workspace_floats(int N, int C, int S) {
+  if (!valid_dims(N, C, S)) return 0;
+  const Plan pl = make_plan(N, C, S);
+  return (int64_t)pl.P * C * 2;
+}
+
+int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, float *workspace,
+                  skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !x || !mean || !var || !workspace) return 0;
+  const Plan pl = make_plan(N, C, S);
+  hipStream_t st = as_stream(stream);
+  abn_stats_partial_kernel<<<dim3((unsigned)pl.items), dim3(kThreads), 0, st>>>(x, workspace, N, C, S, pl);
+  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
+      x, workspace, mean, var, nullptr, nullptr, N, C, S, pl.P, 0.f, 0.0);
+  return ok();
+}
+
+int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
+                           const float *var, float momentum, double n, skd_stream_t stream) {
+  if (C <= 0 || !running_mean || !running_var || !mean || !var) return 0;
+  abn_update_running_kernel<<<dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream)>>>(
+      C, running_mean, running_var, mean, var, momentum, (float)n);
+  return ok();
+}
+
+int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float *var,
+                  const float *weight, const float *bias, float eps, int activation, float slope,
+                  skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !x || !mean || !var) return 0;
+  const Plan pl = make_plan(N, C, S);
+  launch_apply<false>(activation, pl, as_stream(stream), x, mean, var, weight, bias, x, x, eps, slope, N, C, S, 0);
+  return ok();
+}
+
+int skd_abn_forward_train(int N, int C, int S, float *x, const float *weight, const float *bias,
+                          float *running_mean, float *running_var, float *mean, float *var,
+                          float momentum, float eps, int activation, float slope, float *workspace,
+                          skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !x || !mean || !var || !workspace) return 0;
+  const Plan pl = make_plan(N, C, S);
+  hipStream_t st = as_stream(stream);
+  abn_stats_partial_kernel<<<dim3((unsigned)pl.items), dim3(kThreads), 0, st>>>(x, workspace, N, C, S, pl);
+  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
+      x, workspace, mean, var, running_mean, running_var, N, C, S, pl.P, momentum,
+      (double)N * (double)S);
+  launch_apply<false>(activation, pl, st, x, mean, var, weight, bias, x, x, eps, slope, N, C, S, 1);
+  return ok();
+}
+
+int skd_abn_backward_reduce(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                            const float *bias, float *edz, float *eydz, float eps, int activation,
+                            float slope, float *workspace, skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !z || !dz || !edz || !eydz || !workspace) return 0;
+  if (!same_phase(z, dz)) return 0;
+  const Plan pl = make_plan(N, C, S);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)pl.items), block(kThreads);
+  switch (activation) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_grad_partial_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(z, dz, weight, bias, workspace, eps, slope, N, C, S, pl);
+      break;
+    case SKD_ACT_ELU:
+      abn_grad_partial_kernel<SKD_ACT_ELU><<<grid, block, 0, st>>>(z, dz, weight, bias, workspace, eps, slope, N, C, S, pl);
+      break;
+    default:
+      abn_grad_partial_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(z, dz, weight, bias, workspace, eps, slope, N, C, S, pl);
+  }
+  abn_grad_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
+      workspace, edz, eydz, N, C, S, pl.P);
+  return ok();
+}
+
+int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, const float *var,
+                        const float *weight, const float *bias, const float *edz, const float *eydz,
+                        float *dx, float *dweight, float *dbias, float eps, int activation,
+                        float slope, skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !z || !dz || !var || !edz || !eydz) return 0;
+  if (dweight && !weight) return 0;
+  if (!same_phase(z, dz) || (dx && !same_phase(z, dx))) return 0;
+  const Plan pl = make_plan(N, C, S);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)pl.items), block(kThreads);
+  switch (activation) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_grad_dx_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+      break;
+    case SKD_ACT_ELU:
+      abn_grad_dx_kernel<SKD_ACT_ELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+      break;
+    default:
+      abn_grad_dx_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+  }
+  return ok();
+}
+
+int skd_abn_backward(int N, int C, int S, const float *z, const float *dz, const float *var,
+                     const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                     float *dweight, float *dbias, float eps, int activation, float slope,
+                     int training, float *workspace, skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !edz || !eydz) return 0;
+  if (training) {
+    if (!skd_abn_backward_reduce(N, C, S, z, dz, weight, bias, edz, eydz, eps, activation, slope,
+                                 workspace, stream))
+      return 0;
+  } else {
+    // functions.py:146-147: inference-mode backward uses edz = eydz = 0
+    if (hipMemsetAsync(edz, 0, sizeof(float) * C, as_stream(stream)) != hipSuccess) return 0;
+    if (hipMemsetAsync(eydz, 0, sizeof(float) * C, as_stream(stream)) != hipSuccess) return 0;
+  }
+  return skd_abn_backward_dx(N, C, S, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps,
+                             activation, slope, stream);
+}
+
+// ---- legacy drop-in entries ---------------------------------------------------------------------
+
+int skd_bn_mean_var(int N, int C, int S, const float *x, float *mean, float *var, skd_stream_t stream) {
+  if (!valid_dims(N, C, S)) return 0;
+  float *ws = legacy_scratch(skd_abn_workspace_floats(N, C, S));
+  if (ws == nullptr) return 0;
+  return skd_abn_stats(N, C, S, x, mean, var, ws, stream);
+}
+
+int skd_bn_forward(int N, int C, int S, const float *x, const float *mean, const float *var,
+                   const float *weight, const float *bias, float *y, float *z, float eps,
+                   skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !x || !mean || !var || !y || !z) return 0;
+  if (!same_phase(x, y) || !same_phase(x, z)) return 0;
+  const Plan pl = make_plan(N, C, S);
+  if (y == z)
+    launch_apply<false>(SKD_ACT_NONE, pl, as_stream(stream), x, mean, var, weight, bias, y, z, eps, 0.f, N, C, S, 0);
+  else
+    launch_apply<true>(SKD_ACT_NONE, pl, as_stream(stream), x, mean, var, weight, bias, y, z, eps, 0.f, N, C, S, 0);
+  return ok();
+}
+
+int skd_bn_edz_eydz(int N, int C, int S, const float *z, const float *dz, const float *weight,
+                    const float *bias, float *edz, float *eydz, float eps, skd_stream_t stream) {
+  if (!valid_dims(N, C, S)) return 0;
+  float *ws = legacy_scratch(skd_abn_workspace_floats(N, C, S));
+  if (ws == nullptr) return 0;
+  return skd_abn_backward_reduce(N, C, S, z, dz, weight, bias, edz, eydz, eps, SKD_ACT_NONE, 0.f, ws, stream);
+}
+
+int skd_bn_backward(int N, int C, int S, const float *dz, const float *z, const float *var,
+                    const float *weight, const float *bias, const float *edz, const float *eydz,
+                    float *dx, float *dweight, float *dbias, float eps, skd_stream_t stream) {
+  return skd_abn_backward_dx(N, C, S, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps,
+                             SKD_ACT_NONE, 0.f, stream);
+}
+
+int skd_leaky_relu(int64_t N, float *x, float slope, skd_stream_t stream) {
+  if (N < 0 || (N > 0 && !x)) return 0;
+  if (N == 0) return 1;
+  act_kernel<0><<<dim3(act_grid(N)), dim3(kThreads), 0, as_stream(stream)>>>(N, x, x, slope);
+  return ok();
+}
+int skd_leaky_relu_backward(int64_t N, const float *x, float *dx, float slope, skd_stream_t stream) {
+  if (N < 0 || (N > 0 && (!x || !dx))) return 0;
+  if (N == 0) return 1;
+  act_kernel<1><<<dim3(act_grid(N)), dim3(kThreads), 0, as_stream(stream)>>>(N, x, dx, slope);
+  return ok();
+}
+int skd_elu(int64_t N, float *x, skd_stream_t stream) {
+  if (N < 0 || (N > 0 && !x)) return 0;
+  if (N == 0) return 1;
+  act_kernel<2><<<dim3(act_grid(N)), dim3(kThreads), 0, as_stream(stream)>>>(N, x, x, 0.f);
+  return ok();
+}
+int skd_elu_backward(int64_t N, const float *x, float *dx, skd_stream_t stream) {
+  if (N < 0 || (N > 0 && (!x || !dx))) return 0;
+  if (N == 0) return 1;
+  act_kernel<3><<<dim3(act_grid(N)), dim3(kThreads), 0, as_stream(stream)>>>(N, x, dx, 0.f);
+  return ok();
+}
+int skd_elu_inv(int64_t N, float *x, skd_stream_t stream) {
+  if (N < 0 || (N > 0 && !x)) return 0;
+  if (N == 0) return 1;
+  act_kernel<4><<<dim3(act_grid(N)), dim3(kThreads), 0, as_stream(stream)>>>(N, x, x, 0.f);
+  return ok();
+}
+
+}  // extern "C"

@@ -1,0 +1,516 @@
+// pairwise.hip -- pair-wise feature-similarity distillation loss for gfx950.
+//
+// Reference: CriterionPairWiseforWholeFeatAfterPool.forward, utils/criterion.py:236-245, and
+// L2 / similarity / sim_dis_compute, utils/utils.py:170-183:
+//     P   = MaxPool2d(k=s=(kh,kw), pad 0, ceil_mode=True)(F)            (B, C, OH, OW), M = OH*OW
+//     Fh  = P / (sqrt(sum_c P^2) + 1e-8)      (norm detached)
+//     A   = einsum('icm,icn->imn', Fh, Fh)                               (B, M, M)
+//     L   = sum((A_T - A_S)^2) / M^2 / B
+// The reference runs ~15 stock launches and materialises A_S and A_T.  Here:
+//   pool      one wave per (plane, output-row band); lanes own columns (coalesced row reads),
+//             running (max, argmax) per column, then a short segmented reduce in LDS.
+//   normalise one workgroup per (image, 64 nodes): channel L2 norm + scaled copy into a
+//             zero-padded (B, C, ldm) buffer, ldm = M rounded up to 128 -> the GEMM tiles below
+//             need no edge masks and all their loads are 16-byte aligned.  A node-major copy
+//             FhS^T (B, ldm, ldc) is written for the backward GEMM.
+//   gram      G = Fh_T^T Fh_T - Fh_S^T Fh_S accumulated in ONE set of fp32 MFMA accumulators
+//             (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- there is no
+//             TF32/xf32 on gfx950 and bf16 would break the 1e-4 loss tolerance).  128x128 output
+//             tile per 256-thread workgroup, 4 waves x (2x2) 32x32 MFMA tiles, K streamed through
+//             a double-buffered LDS ring of k-major panels; both operands are rows of the same
+//             channel-major matrix, so LDS reads are conflict-free ds_read_b32 with no transposes.
+//             The epilogue squares and reduces the tile (A_S/A_T never exist) and stores G.
+//   backward  dFh_S = -4 g/(M^2 B) * Fh_S G with the same tile routine (operands FhS^T and G),
+//             epilogue divides by the detached norm; unpool scatters through the argmax while
+//             writing the dense gradient once (no zero-fill pass, no atomics).
+// Bounds: pool/unpool/normalise are HBM-bound; gram is fp32-MFMA-bound for M >~ 100
+// (2*B*M^2*(C_S+C_T) flop), launch/latency-bound at the reference default M = 9.
+#include "skd_common.hpp"
+
+namespace skd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =============================================================================================
+// max-pool with argmax
+// =============================================================================================
+struct Cand {
+  float v;
+  int idx;
+};
+// PyTorch scan semantics: `if (val > maxval || isnan(val)) take` in row-major order
+//  -> first maximum wins among ordinary values, the LAST NaN wins when any NaN is present.
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b) {
+  const bool an = a.v != a.v, bn = b.v != b.v;
+  if (an) return bn ? a.idx > b.idx : true;
+  if (bn) return false;
+  return a.v > b.v || (a.v == b.v && a.idx < b.idx);
+}
+
+constexpr int kPoolMaxW = 1024;  // columns per plane row handled by the wave-per-band kernel
+
+template <int NJ>  // NJ = ceil(W / 64) column slots per lane
+__global__ __launch_bounds__(kThreads) void maxpool_band_kernel(const float *__restrict__ x,
+                                                               float *__restrict__ pooled,
+                                                               int32_t *__restrict__ index,
+                                                               int64_t planes, int H, int W, int kh,
+                                                               int kw, int OH, int OW,
+                                                               int bands_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  float *colv = reinterpret_cast<float *>(smem_raw) + (size_t)wid * W;
+  int *coli = reinterpret_cast<int *>(smem_raw + sizeof(float) * (size_t)kWavesPerWG * W) + (size_t)wid * W;
+
+  const int groups = (OH + bands_per_wave - 1) / bands_per_wave;  // band groups per plane
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerWG + wid;
+  const bool live = unit < planes * groups;
+  const int64_t plane = live ? unit / groups : 0;
+  const int g = live ? (int)(unit % groups) : 0;
+  const float *px = x + plane * (int64_t)H * W;
+
+  for (int bi = 0; bi < bands_per_wave; ++bi) {
+    const int oh = g * bands_per_wave + bi;
+    const bool on = live && oh < OH;
+    if (on) {
+      const int r0 = oh * kh;
+      const int r1 = min(H, r0 + kh);
+      Cand best[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        best[j].v = -INFINITY;
+        best[j].idx = r0 * W + j * kWave + lane;
+      }
+#pragma unroll 4
+      for (int r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int col = j * kWave + lane;
+          if (col < W) {
+            const float v = px[(int64_t)r * W + col];
+            if (v > best[j].v || v != v) {
+              best[j].v = v;
+              best[j].idx = r * W + col;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = j * kWave + lane;
+        if (col < W) {
+          colv[col] = best[j].v;
+          coli[col] = best[j].idx;
+        }
+      }
+    }
+    __syncthreads();
+    if (on) {
+      for (int ow = lane; ow < OW; ow += kWave) {
+        const int c0 = ow * kw, c1 = min(W, c0 + kw);
+        Cand acc{colv[c0], coli[c0]};
+        for (int c = c0 + 1; c < c1; ++c) {
+          const Cand cand{colv[c], coli[c]};
+          if (better(cand, acc)) acc = cand;
+        }
+        const int64_t o = plane * (int64_t)OH * OW + (int64_t)oh * OW + ow;
+        pooled[o] = acc.v;
+        if (index != nullptr) index[o] = acc.idx;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fallback for very wide planes: one thread per output cell
+__global__ __launch_bounds__(kThreads) void maxpool_cell_kernel(const float *__restrict__ x,
+                                                               float *__restrict__ pooled,
+                                                               int32_t *__restrict__ index,
+                                                               int64_t planes, int H, int W, int kh,
+                                                               int kw, int OH, int OW) {
+  const int64_t total = planes * OH * OW;
+  const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (o >= total) return;
+  const int ow = (int)(o % OW);
+  const int oh = (int)((o / OW) % OH);
+  const int64_t plane = o / ((int64_t)OW * OH);
+  const float *px = x + plane * (int64_t)H * W;
+  const int r0 = oh * kh, r1 = min(H, r0 + kh), c0 = ow * kw, c1 = min(W, c0 + kw);
+  float bv = -INFINITY;
+  int bi = r0 * W + c0;
+  for (int r = r0; r < r1; ++r)
+    for (int c = c0; c < c1; ++c) {
+      const float v = px[(int64_t)r * W + c];
+      if (v > bv || v != v) {
+        bv = v;
+        bi = r * W + c;
+      }
+    }
+  pooled[o] = bv;
+  if (index != nullptr) index[o] = bi;
+}
+
+// dense un-pool: every input position is written exactly once
+__global__ __launch_bounds__(kThreads) void maxunpool_kernel(const float *__restrict__ dpooled,
+                                                            const int32_t *__restrict__ index,
+                                                            float *__restrict__ dx, int H, int W,
+                                                            int kh, int kw, int OH, int OW,
+                                                            int64_t ldp) {
+  const int64_t plane = blockIdx.y;
+  const int HW = H * W;
+  const float *dp = dpooled + plane * ldp;
+  const int32_t *ix = index + plane * (int64_t)OH * OW;
+  float *out = dx + plane * (int64_t)HW;
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < HW; e += gridDim.x * kThreads) {
+    const int h = e / W, w = e - h * W;
+    const int m = (h / kh) * OW + (w / kw);
+    out[e] = (ix[m] == e) ? dp[m] : 0.f;
+  }
+}
+
+// =============================================================================================
+// channel L2 norm + normalise into padded buffers
+// =============================================================================================
+// grid (ceil(ldm/64), B); block 256 = 64 nodes x 4 channel slices
+__global__ __launch_bounds__(kThreads) void l2_normalise_kernel(const float *__restrict__ pooled,
+                                                               float *__restrict__ fhat,
+                                                               float *__restrict__ fhat_t,
+                                                               float *__restrict__ norm, int C, int M,
+                                                               int ldm, int ldc) {
+  __shared__ float ssq[kWavesPerWG][kWave];
+  const int lane = threadIdx.x & (kWave - 1), slice = threadIdx.x / kWave;
+  const int b = blockIdx.y;
+  const int m = blockIdx.x * kWave + lane;
+  const bool valid = m < M;
+  const float *src = pooled + (int64_t)b * C * M;
+  float acc = 0.f;
+  if (valid)
+    for (int c = slice; c < C; c += kWavesPerWG) {
+      const float v = src[(int64_t)c * M + m];
+      acc += v * v;
+    }
+  ssq[slice][lane] = acc;
+  __syncthreads();
+  const float tot = (ssq[0][lane] + ssq[1][lane]) + (ssq[2][lane] + ssq[3][lane]);
+  const float nrm = sqrtf(tot) + 1e-8f;  // utils.py:170-171
+  if (valid && slice == 0 && norm != nullptr) norm[(int64_t)b * M + m] = nrm;
+  if (m < ldm) {
+    float *dst = fhat + (int64_t)b * C * ldm;
+    for (int c = slice; c < C; c += kWavesPerWG)
+      dst[(int64_t)c * ldm + m] = valid ? src[(int64_t)c * M + m] / nrm : 0.f;  // utils.py:176
+  }
+  if (fhat_t != nullptr && m < ldm) {
+    // node-major copy (B, ldm, ldc), zero padded in both directions
+    float *dst = fhat_t + ((int64_t)b * ldm + m) * ldc;
+    for (int c = slice; c < ldc; c += kWavesPerWG)
+      dst[c] = (valid && c < C) ? src[(int64_t)c * M + m] / nrm : 0.f;
+  }
+}
+
+// =============================================================================================
+// 128x128 fp32 MFMA tile over k-major panels:  acc[i][j] += sign * sum_k A[k][i] * B[k][j]
+// =============================================================================================
+constexpr int kTile = 128;
+constexpr int kBK = 16;
+constexpr int kPanel = kBK * kTile;  // floats per panel per stage
+
+struct Segment {
+  const float *A;  // element [k][i] at A[k*lda + i], i in [0,128)
+  const float *B;
+  int64_t lda, ldb;
+  int K;        // valid k rows (rows beyond read as zero)
+  int negate;   // accumulate with a minus sign
+};
+
+struct TileRegs {
+  float4 a[2], b[2];
+};
+
+__device__ __forceinline__ void panel_load(const Segment &s, int k0, TileRegs &r) {
+  const int t = threadIdx.x;
+  const int row = t >> 5;       // 0..7
+  const int c4 = (t & 31) * 4;  // 0..124
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = k0 + row + 8 * h;
+    if (k < s.K) {
+      r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)k * s.lda + c4);
+      r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)k * s.ldb + c4);
+    } else {
+      r.a[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      r.b[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+__device__ __forceinline__ void panel_store(float *lds_stage, const TileRegs &r) {
+  const int t = threadIdx.x;
+  const int row = t >> 5;
+  const int c4 = (t & 31) * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    *reinterpret_cast<float4 *>(lds_stage + (row + 8 * h) * kTile + c4) = r.a[h];
+    *reinterpret_cast<float4 *>(lds_stage + kPanel + (row + 8 * h) * kTile + c4) = r.b[h];
+  }
+}
+
+__device__ __forceinline__ void tile_compute(const float *lds_stage, bool negate, f32x16 (&acc)[2][2]) {
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int kk = lane >> 5, l31 = lane & 31;
+  const float *pa = lds_stage + kk * kTile + wi + l31;
+  const float *pb = lds_stage + kPanel + kk * kTile + wj + l31;
+#pragma unroll
+  for (int ks = 0; ks < kBK / 2; ++ks) {
+    float a0 = pa[ks * 2 * kTile], a1 = pa[ks * 2 * kTile + 32];
+    const float b0 = pb[ks * 2 * kTile], b1 = pb[ks * 2 * kTile + 32];
+    if (negate) {
+      a0 = -a0;
+      a1 = -a1;
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// Runs all segments back to back through the double-buffered LDS ring.
+template <int NSEG>
+__device__ __forceinline__ void tile_gemm(const Segment (&seg)[NSEG], float *lds, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int nk[NSEG], total = 0;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    nk[s] = (seg[s].K + kBK - 1) / kBK;
+    total += nk[s];
+  }
+  if (total == 0) return;
+
+  TileRegs regs;
+  int s_ld = 0, k_ld = 0;  // next K-tile to load
+  while (s_ld < NSEG && nk[s_ld] == 0) ++s_ld;
+  panel_load(seg[s_ld], 0, regs);
+  panel_store(lds, regs);
+  __syncthreads();
+  int stage = 0, s_cp = s_ld, k_cp = 0;
+  for (int it = 0; it < total; ++it) {
+    // advance the load cursor
+    ++k_ld;
+    if (k_ld >= nk[s_ld]) {
+      k_ld = 0;
+      ++s_ld;
+      while (s_ld < NSEG && nk[s_ld] == 0) ++s_ld;
+    }
+    const bool more = it + 1 < total;
+    if (more) panel_load(seg[s_ld], k_ld * kBK, regs);
+    tile_compute(lds + stage * 2 * kPanel, seg[s_cp].negate != 0, acc);
+    if (more) panel_store(lds + (stage ^ 1) * 2 * kPanel, regs);
+    __syncthreads();
+    stage ^= 1;
+    ++k_cp;
+    if (k_cp >= nk[s_cp]) {
+      k_cp = 0;
+      ++s_cp;
+      while (s_cp < NSEG && nk[s_cp] == 0) ++s_cp;
+    }
+  }
+}
+
+// C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// gram + loss.  grid = (nt*nt, B): blockIdx.x -> (ti, tj)
+__global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__restrict__ fs,
+                                                                const float *__restrict__ ft,
+                                                                float *__restrict__ G,
+                                                                float *__restrict__ part, int Cs,
+                                                                int Ct, int ldm, int nt) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kPanel];
+  __shared__ float red[2 * kWavesPerWG];
+  const int b = blockIdx.y;
+  const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+  const int i0 = ti * kTile, j0 = tj * kTile;
+  Segment seg[2];
+  seg[0].A = ft + (int64_t)b * Ct * ldm + i0;
+  seg[0].B = ft + (int64_t)b * Ct * ldm + j0;
+  seg[0].lda = seg[0].ldb = ldm;
+  seg[0].K = Ct;
+  seg[0].negate = 0;
+  seg[1].A = fs + (int64_t)b * Cs * ldm + i0;
+  seg[1].B = fs + (int64_t)b * Cs * ldm + j0;
+  seg[1].lda = seg[1].ldb = ldm;
+  seg[1].K = Cs;
+  seg[1].negate = 1;
+  f32x16 acc[2][2];
+  tile_gemm<2>(seg, lds, acc);
+
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  float sq = 0.f, unused = 0.f;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float g = acc[bi][bj][r];
+        sq += g * g;  // padded rows/cols are exactly zero
+        if (G != nullptr) {
+          const int row = i0 + wi + bi * 32 + frag_row(r, lane);
+          const int col = j0 + wj + bj * 32 + (lane & 31);
+          G[((int64_t)b * ldm + row) * ldm + col] = g;
+        }
+      }
+  block_sum2(sq, unused, red);
+  if (threadIdx.x == 0) part[(int64_t)b * gridDim.x + blockIdx.x] = sq;
+}
+
+// backward: D[c][m] = sum_n FhS^T[n][c] * G[n][m];  dP[c][m] = coef * D[c][m] / norm[m]
+// grid = (ntm * ntc, B)
+__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ fst,
+                                                                   const float *__restrict__ G,
+                                                                   const float *__restrict__ norm,
+                                                                   const float *__restrict__ gscale,
+                                                                   float *__restrict__ dpooled, int Cs,
+                                                                   int M, int ldm, int ldc, int ntm,
+                                                                   float coef) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kPanel];
+  const int b = blockIdx.y;
+  const int tc = blockIdx.x / ntm, tm = blockIdx.x % ntm;
+  const int c0 = tc * kTile, m0 = tm * kTile;
+  Segment seg[1];
+  seg[0].A = fst + (int64_t)b * ldm * ldc + c0;  // [k = n][i = c]
+  seg[0].lda = ldc;
+  seg[0].B = G + (int64_t)b * ldm * ldm + m0;    // [k = n][j = m]
+  seg[0].ldb = ldm;
+  seg[0].K = ldm;
+  seg[0].negate = 0;
+  f32x16 acc[2][2];
+  tile_gemm<1>(seg, lds, acc);
+
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const float scale = coef * gscale[0];
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) {
+    const int m = m0 + wj + bj * 32 + (lane & 31);
+    const float inv = m < M ? scale / norm[(int64_t)b * M + m] : 0.f;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wi + bi * 32 + frag_row(r, lane);
+        if (c < Cs) dpooled[((int64_t)b * Cs + c) * ldm + m] = acc[bi][bj][r] * inv;
+      }
+  }
+}
+
+}  // namespace
+}  // namespace skd
+
+using namespace skd;
+
+extern "C" {
+
+int skd_maxpool_argmax(int planes, int H, int W, int kh, int kw, const float *x, float *pooled,
+                       int32_t *index, skd_stream_t stream) {
+  if (planes <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !x || !pooled) return 0;
+  if ((int64_t)H * W >= (int64_t)1 << 31) return 0;
+  hipStream_t st = as_stream(stream);
+  const int OH = (int)cdiv(H, kh), OW = (int)cdiv(W, kw);
+  if (W <= kPoolMaxW) {
+    int bpw = kh >= 16 ? 1 : (int)cdiv(16, kh);
+    if (bpw > OH) bpw = OH;
+    const int groups = (int)cdiv(OH, bpw);
+    const int64_t units = (int64_t)planes * groups;
+    const dim3 grid((unsigned)cdiv(units, kWavesPerWG)), block(kThreads);
+    const size_t smem = (size_t)kWavesPerWG * W * (sizeof(float) + sizeof(int));
+    const int nj = (int)cdiv(W, kWave);
+#define SKD_POOL(NJ) \
+  maxpool_band_kernel<NJ><<<grid, block, smem, st>>>(x, pooled, index, planes, H, W, kh, kw, OH, OW, bpw)
+    if (nj <= 1) SKD_POOL(1);
+    else if (nj <= 2) SKD_POOL(2);
+    else if (nj <= 4) SKD_POOL(4);
+    else if (nj <= 8) SKD_POOL(8);
+    else SKD_POOL(16);
+#undef SKD_POOL
+  } else {
+    const int64_t total = (int64_t)planes * OH * OW;
+    maxpool_cell_kernel<<<dim3((unsigned)cdiv(total, kThreads)), dim3(kThreads), 0, st>>>(
+        x, pooled, index, planes, H, W, kh, kw, OH, OW);
+  }
+  return ok();
+}
+
+int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float *dpooled, int64_t ldp,
+                          const int32_t *index, float *dx, skd_stream_t stream) {
+  if (planes <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !dpooled || !index || !dx) return 0;
+  if (planes > 65535 * 1024) return 0;
+  const int OH = (int)cdiv(H, kh), OW = (int)cdiv(W, kw);
+  int gx = (int)cdiv((int64_t)H * W, kThreads);
+  if (gx > 64) gx = 64;
+  // gridDim.y is limited to 65535: fold planes in chunks
+  hipStream_t st = as_stream(stream);
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)((planes - p0) < 65535 ? (planes - p0) : 65535);
+    maxunpool_kernel<<<dim3(gx, np), dim3(kThreads), 0, st>>>(
+        dpooled + p0 * ldp, index + p0 * (int64_t)OH * OW, dx + p0 * (int64_t)H * W, H, W, kh, kw, OH, OW, ldp);
+  }
+  return ok();
+}
+
+int skd_pairwise_ldm(int M) { return M <= 0 ? 0 : (int)(cdiv(M, kTile) * kTile); }
+
+int skd_channel_l2_normalise(int B, int C, int M, const float *pooled, float *fhat, int ldm,
+                             float *fhat_t, int ldc, float *norm, skd_stream_t stream) {
+  if (B <= 0 || C <= 0 || M <= 0 || !pooled || !fhat || ldm < M) return 0;
+  if (fhat_t != nullptr && ldc < C) return 0;
+  if (B > 65535) return 0;
+  l2_normalise_kernel<<<dim3((unsigned)cdiv(ldm, kWave), B), dim3(kThreads), 0, as_stream(stream)>>>(
+      pooled, fhat, fhat_t, norm, C, M, ldm, ldc);
+  return ok();
+}
+
+int64_t skd_pairwise_workspace_floats(int B, int M) {
+  if (B <= 0 || M <= 0) return 1;
+  const int64_t nt = cdiv(M, kTile);
+  return nt * nt * B;
+}
+
+int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *fhat_s,
+                           const float *fhat_t, float *G, float *loss, float *workspace,
+                           skd_stream_t stream) {
+  if (B <= 0 || Cs <= 0 || Ct <= 0 || M <= 0 || !fhat_s || !fhat_t || !loss || !workspace) return 0;
+  if (ldm != skd_pairwise_ldm(M) || B > 65535) return 0;
+  if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(fhat_t)) & 15) return 0;
+  hipStream_t st = as_stream(stream);
+  const int nt = ldm / kTile;
+  gram_loss_kernel<<<dim3((unsigned)(nt * nt), B), dim3(kThreads), 0, st>>>(fhat_s, fhat_t, G, workspace,
+                                                                          Cs, Ct, ldm, nt);
+  if (!ok()) return 0;
+  // utils.py:181: / (M*M) / B
+  return launch_final_sum(workspace, (int64_t)nt * nt * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
+}
+
+int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t, const float *G,
+                          const float *norm_s, const float *grad_loss, float *dpooled,
+                          skd_stream_t stream) {
+  if (B <= 0 || Cs <= 0 || M <= 0 || !fhat_s_t || !G || !norm_s || !grad_loss || !dpooled) return 0;
+  if (ldm != skd_pairwise_ldm(M) || ldc % kTile != 0 || ldc < Cs || B > 65535) return 0;
+  if ((reinterpret_cast<uintptr_t>(fhat_s_t) | reinterpret_cast<uintptr_t>(G)) & 15) return 0;
+  const int ntm = ldm / kTile, ntc = ldc / kTile;
+  // dL/dA_S = -2 G /(M^2 B); dFhat = Fhat (dA + dA^T) = -4/(M^2 B) Fhat G   (G symmetric)
+  const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
+  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B), dim3(kThreads), 0, as_stream(stream)>>>(
+      fhat_s_t, G, norm_s, grad_loss, dpooled, Cs, M, ldm, ldc, ntm, coef);
+  return ok();
+}
+
+}  // extern "C"

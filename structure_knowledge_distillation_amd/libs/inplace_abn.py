@@ -1,0 +1,209 @@
+"""Autograd functions for InPlace-ABN on MI355X.
+
+Mirrors the *contract* of the reference's libs/functions.py:70-309 (in-place on the conv output,
+forward output saved for backward, not double-differentiable, ValueError on non-contiguous input,
+RuntimeError when a native call reports failure) on top of the fused kernels of csrc/abn.hip:
+
+    reference (per layer, training)                  here
+    ---------------------------------------------    -------------------------------------------
+    K1 mean_var (2 passes over x)                    stats partials (1 pass) + finalize
+    2 torch ops for the running stats                  (fused into finalize)
+    K2 forward  + K5 leaky-relu pass                 one normalise+affine+activation pass
+    K6 + K5(1/slope) rewrite dz, z ; K3 ; K4         reduce pass + dx pass, activation undone in
+                                                     registers (z and dz are never rewritten)
+
+Cross-replica synchronisation (libs/functions.py:185-205, 263-280: master/worker Queues +
+comm.gather / broadcast_coalesced inside one process) is replaced by one-process-per-GPU
+collectives on a torch.distributed group (RCCL over xGMI): all_gather of [mean, var] followed by
+the reference's combine rule, and an averaged all_reduce of [edz, eydz].
+"""
+import torch
+import torch.autograd as autograd
+import torch.distributed as dist
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+ACT_LEAKY_RELU = "leaky_relu"
+ACT_ELU = "elu"
+ACT_NONE = "none"
+_ACT_CODE = {ACT_NONE: 0, ACT_LEAKY_RELU: 1, ACT_ELU: 2}
+
+
+def _act_code(name):
+    try:
+        return _ACT_CODE[name]
+    except KeyError:
+        raise ValueError("unknown activation %r (expected leaky_relu, elu or none)" % (name,))
+
+
+def _check_contiguous(*tensors):
+    # libs/functions.py:65-67
+    if not all(t is None or t.is_contiguous() for t in tensors):
+        raise ValueError("Non-contiguous input")
+
+
+def _dims(x):
+    n, c = x.shape[0], x.shape[1]
+    s = 1
+    for d in x.shape[2:]:
+        s *= d
+    return n, c, s
+
+
+def _same_phase(a, b):
+    return ((a.data_ptr() ^ b.data_ptr()) & 15) == 0
+
+
+def _group_size(group):
+    if group is None:
+        return 1
+    return dist.get_world_size(group)
+
+
+def combine_replica_stats(gathered):
+    """gathered: (G, 2, C) per-rank [mean, var] -> combined (mean, var).
+
+    The reference rule, libs/functions.py:196-197 (equal per-rank sample counts assumed):
+        mean = means.mean(0);  var = (vars + (mean - means)**2).mean(0)
+    """
+    means, vars_ = gathered[:, 0], gathered[:, 1]
+    mean = means.mean(0)
+    var = (vars_ + (mean - means) ** 2).mean(0)
+    return mean, var
+
+
+class _InPlaceABN(autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps,
+                activation, slope, group):
+        _lib.require_device(x, weight, bias, running_mean, running_var)
+        if x.dtype != torch.float32:
+            raise TypeError("InPlaceABN kernels are fp32 only (got %s)" % x.dtype)
+        ctx.training = bool(training)
+        ctx.eps = float(eps)
+        ctx.act = _act_code(activation)
+        ctx.slope = float(slope)
+        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        if x.dim() < 2:
+            raise ValueError("InPlaceABN expects (N, C, ...) input")
+        _check_contiguous(x, weight, bias, running_mean, running_var)
+        n, c, s = _dims(x)
+        lib = _lib.get()
+        st = _lib.stream_of(x)
+
+        if x.numel() == 0:
+            ctx.var = running_var
+            ctx.save_for_backward(x, weight, bias)
+            ctx.mark_dirty(x)
+            return x
+
+        if ctx.training:
+            stat = x.new_empty((2, c))
+            mean, var = stat[0], stat[1]
+            ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+            if ctx.group is None:
+                _lib.check(lib.skd_abn_forward_train(
+                    n, c, s, x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                    _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(),
+                    float(momentum), ctx.eps, ctx.act, ctx.slope, ws.data_ptr(), st),
+                    "skd_abn_forward_train")
+            else:
+                g = _group_size(ctx.group)
+                _lib.check(lib.skd_abn_stats(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                             ws.data_ptr(), st), "skd_abn_stats")
+                gathered = x.new_empty((g, 2, c))
+                dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=ctx.group)
+                mean, var = combine_replica_stats(gathered)
+                mean, var = mean.contiguous(), var.contiguous()
+                if running_mean is not None:
+                    # libs/functions.py:177,208-209: n counts the samples of ALL replicas
+                    _lib.check(lib.skd_abn_update_running(
+                        c, running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
+                        var.data_ptr(), float(momentum), float(n * s * g), st),
+                        "skd_abn_update_running")
+                _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                             _lib.ptr(weight), _lib.ptr(bias), ctx.eps, ctx.act,
+                                             ctx.slope, st), "skd_abn_apply")
+        else:
+            var = running_var
+            _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), running_mean.data_ptr(),
+                                         running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                                         ctx.eps, ctx.act, ctx.slope, st), "skd_abn_apply")
+
+        ctx.var = var
+        ctx.save_for_backward(x, weight, bias)
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        z, weight, bias = ctx.saved_tensors
+        var = ctx.var
+        del ctx.var
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
+        n, c, s = _dims(z)
+        if z.numel() == 0:
+            return (torch.zeros_like(z) if need_dx else None,
+                    torch.zeros_like(weight) if need_dw and weight is not None else None,
+                    torch.zeros_like(bias) if need_db and bias is not None else None,
+                    None, None, None, None, None, None, None, None)
+        dz = dz.contiguous()
+        if not _same_phase(z, dz):
+            dz = dz.clone(memory_format=torch.contiguous_format)
+        lib = _lib.get()
+        st = _lib.stream_of(z)
+
+        dx = torch.empty_like(z) if need_dx else None
+        dweight = torch.zeros_like(weight) if (need_dw and weight is not None) else None
+        dbias = torch.zeros_like(bias) if (need_db and bias is not None) else None
+        stat = z.new_empty((2, c))
+        edz, eydz = stat[0], stat[1]
+        ws = z.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+
+        if ctx.group is None or not ctx.training:
+            _lib.check(lib.skd_abn_backward(
+                n, c, s, z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+                _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight),
+                _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, 1 if ctx.training else 0,
+                ws.data_ptr(), st), "skd_abn_backward")
+        else:
+            _lib.check(lib.skd_abn_backward_reduce(
+                n, c, s, z.data_ptr(), dz.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                edz.data_ptr(), eydz.data_ptr(), ctx.eps, ctx.act, ctx.slope, ws.data_ptr(), st),
+                "skd_abn_backward_reduce")
+            # libs/functions.py:271-272: reduce_add(...) / number of replicas
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)
+            stat.div_(_group_size(ctx.group))
+            _lib.check(lib.skd_abn_backward_dx(
+                n, c, s, z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+                _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight),
+                _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, st), "skd_abn_backward_dx")
+        return dx, dweight, dbias, None, None, None, None, None, None, None, None
+
+
+def inplace_abn(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-05,
+                activation=ACT_LEAKY_RELU, slope=0.01):
+    """Signature of libs/functions.py:70-73 (InPlaceABN.apply)."""
+    return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
+                             activation, slope, None)
+
+
+def inplace_abn_sync(x, weight, bias, running_mean, running_var, extra=None, training=True,
+                     momentum=0.1, eps=1e-05, activation=ACT_LEAKY_RELU, slope=0.01):
+    """Signature of libs/functions.py:165-168 (InPlaceABNSync.apply).
+
+    ``extra`` carried the master/worker queues in the reference; here it is either None
+    (default process group when torch.distributed is initialised with world_size > 1, otherwise
+    no synchronisation) or a dict {"group": ProcessGroup}.
+    """
+    group = None
+    if isinstance(extra, dict):
+        group = extra.get("group")
+    elif extra is not None:
+        group = extra
+    if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = dist.group.WORLD
+    return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
+                             activation, slope, group)

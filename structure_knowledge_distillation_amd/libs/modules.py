@@ -1,0 +1,114 @@
+"""nn.Module front-ends of InPlace-ABN -- same constructor signatures, parameter / buffer names
+and state-dict keys (weight, bias, running_mean, running_var; no num_batches_tracked) as the
+reference's libs/bn.py:24-215, so networks/pspnet_combine.py builds unchanged on top of them."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .inplace_abn import inplace_abn, inplace_abn_sync
+
+_sync_group = {"group": None, "explicit": False}
+
+
+def set_sync_group(group):
+    """Process group used by every InPlaceABNSync (None = default group when initialised)."""
+    _sync_group["group"] = group
+    _sync_group["explicit"] = True
+
+
+def get_sync_group():
+    return _sync_group["group"]
+
+
+class ABN(nn.Sequential):
+    """BatchNorm2d + activation as two stock modules (libs/bn.py:24-45)."""
+
+    def __init__(self, num_features, activation=None, **kwargs):
+        act = activation if activation is not None else nn.ReLU(inplace=True)
+        super().__init__(OrderedDict([("bn", nn.BatchNorm2d(num_features, **kwargs)), ("act", act)]))
+
+
+class _ABNBase(nn.Module):
+    def __init__(self, num_features, eps, momentum, affine, activation, slope):
+        super().__init__()
+        self.num_features = num_features
+        self.affine = affine
+        self.eps = eps
+        self.momentum = momentum
+        self.activation = activation
+        self.slope = slope
+        if affine:
+            self.weight = nn.Parameter(torch.empty(num_features))
+            self.bias = nn.Parameter(torch.empty(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # libs/bn.py:86-91
+        with torch.no_grad():
+            self.running_mean.zero_()
+            self.running_var.fill_(1)
+            if self.affine:
+                self.weight.fill_(1)
+                self.bias.zero_()
+
+    def extra_repr(self):
+        rep = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"
+        if self.activation == "leaky_relu":
+            rep += ", slope={slope}"
+        return rep.format(**self.__dict__)
+
+
+class InPlaceABN(_ABNBase):
+    """libs/bn.py:48-105."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu",
+                 slope=0.01):
+        super().__init__(num_features, eps, momentum, affine, activation, slope)
+
+    def forward(self, x):
+        return inplace_abn(x, self.weight, self.bias, self.running_mean, self.running_var,
+                           self.training, self.momentum, self.eps, self.activation, self.slope)
+
+
+class InPlaceABNSync(_ABNBase):
+    """libs/bn.py:108-193.  ``devices`` is accepted for signature compatibility; replicas are
+    separate processes here (one per GPU), synchronised through torch.distributed (RCCL)."""
+
+    def __init__(self, num_features, devices=None, eps=1e-5, momentum=0.1, affine=True,
+                 activation="leaky_relu", slope=0.01):
+        super().__init__(num_features, eps, momentum, affine, activation, slope)
+        self.devices = list(devices) if devices else []
+
+    def forward(self, x):
+        extra = {"group": _sync_group["group"]} if _sync_group["explicit"] else None
+        return inplace_abn_sync(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                extra, self.training, self.momentum, self.eps, self.activation,
+                                self.slope)
+
+
+class InPlaceABNWrapper(nn.Module):
+    """libs/bn.py:196-204."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.bn = InPlaceABN(*args, **kwargs)
+
+    def forward(self, input):
+        return self.bn(input)
+
+
+class InPlaceABNSyncWrapper(nn.Module):
+    """libs/bn.py:207-215."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.bn = InPlaceABNSync(*args, **kwargs)
+
+    def forward(self, input):
+        return self.bn(input)
