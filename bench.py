@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- distillation-step images/sec @512x512 (Pi+Pa+Ho) on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one NetModel.optimize_parameters() (kd_model.py:167-173): frozen ResNet101-PSPNet teacher
+forward + ResNet18-PSPNet student forward/backward (InPlace-ABN at every BN) + CE/Pi/Pa/Ho losses +
+SGD + discriminator step (adv + WGAN-GP) + SGD, fp32, batch 8 per GPU, synthetic 512x512 19-class
+tensors already resident in HBM, Dropout on, logged scalars read back every step like
+train_and_eval.py:26.  N > 1: one process per GPU, weak scaling (8 images per rank), RCCL gradient
+all-reduce + cross-GPU InPlaceABNSync.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant hand-written kernel (abn_apply_kernel: normalise + affine + activation,
+                in place, 8 algorithmic bytes per element), timed live with HIP events on the launch
+                stream over the timed steps
+  kernels       the same measurement for the other hand-written kernels / kernel chains
+  cpu_baseline  the CPU oracle (oracle/step_torch.py, a port of the reference step pinned to the
+                reference's own Python) timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, exact fp32
+STEP_TFLOP_PER_IMAGE = 0.959   # teacher fwd 579.3 GF + student fwd 126.7 + bwd 253.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--pairwise-sweep", action="store_true", help="also time the Pa kernels at large M")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds, size):
+    """Reference step on the host cores: the oracle port at B=2, same losses and optimizers."""
+    import torch
+    from oracle import step_torch as O
+    B = 2
+    cores = torch.get_num_threads()
+    PS, PT, PD = O.pspnet_init(O.STUDENT, 19, 1), O.pspnet_init(O.TEACHER, 19, 2), O.discriminator_init(seed=3)
+    cfg = O.StepConfig(weight_decay=5e-4, lambda_pa=0.5)
+    state = {"G": {}, "D": {}}
+    x, y = O.synthetic_batch(B, size, size)
+    O.distillation_step(PS, PT, PD, x, y, cfg, state)            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.distillation_step(PS, PT, PD, x, y, cfg, state)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 5:
+            break
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = [l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(B * n / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed steps (+1 warm-up) of the full Pi+Pa+Ho step at batch %d, %dx%d, fp32, torch CPU "
+                      "(oracle/step_torch.py); host CPU: %s" % (n, B, size, size, model)}
+
+
+def summarise(recs, bytes_per_elem):
+    """[(ms, (N,C,S))] -> achieved GB/s over all launches (sum bytes / sum time) + launch stats."""
+    if not recs:
+        return None
+    tot_ms = sum(ms for ms, _ in recs)
+    tot_b = sum(bytes_per_elem * d[0] * d[1] * d[2] for _, d in recs)
+    big = [(ms, d) for ms, d in recs if d[0] * d[1] * d[2] >= (1 << 22)]
+    out = {"launches": len(recs), "avg_us": round(1e3 * tot_ms / len(recs), 2),
+           "achieved_GBs": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
+    if big:
+        bms = sum(ms for ms, _ in big)
+        bb = sum(bytes_per_elem * d[0] * d[1] * d[2] for _, d in big)
+        out["achieved_GBs_large"] = round(bb / (bms * 1e-3) / 1e9, 1)   # launches >= 4M elements
+    return out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+
+    rank, world, local = P.init_distributed()
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % a.gpus)
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(1234)
+    args = default_args(batch_size=a.batch, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000)
+    model = NetModel(args)
+    gen = torch.Generator().manual_seed(100 + rank)
+    images = (torch.randn(a.batch, 3, a.size, a.size, generator=gen) * 57.0).to(dev)
+    labels = torch.randint(0, 19, (a.batch, a.size, a.size), generator=gen)
+    labels[0, : a.size // 16] = 255
+    labels = labels.to(dev)
+    data = (images, labels, None, None)
+
+    def step(i):
+        model.adjust_learning_rate(args.lr_g, model.G_solver, i)
+        model.adjust_learning_rate(args.lr_d, model.D_solver, i)
+        model.set_input(data)
+        model.optimize_parameters()
+        return (model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss)  # print_info's reads
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    timed = ["skd_abn_apply", "skd_abn_forward_train", "skd_abn_backward", "skd_pixelwise_loss"]
+    if not a.no_kernel_timing and rank == 0:
+        _lib.enable_kernel_timing(timed)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = step(a.warmup + i)
+    fence()
+    el = time.perf_counter() - t0
+    recs = _lib.disable_kernel_timing() if (not a.no_kernel_timing and rank == 0) else {}
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = 1e3 * el / a.steps
+    value = a.batch * world * a.steps / el
+    line = {
+        "metric": "distillation-step images/sec @512x512 (Pi+Pa+Ho)", "value": round(value, 3), "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]%s: ResNet18-PSPNet student + frozen ResNet101-PSPNet teacher, "
+                               "Pi+Pa+Ho (SAGAN D, spectral norm, WGAN-GP), batch %d per GPU, %dx%d, 19 classes"
+                               % (" x %d ranks (configs[3])" % world if world > 1 else "", a.batch, a.size, a.size),
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                   "losses_last_step": {k: round(float(v), 6) for k, v in
+                                        zip(("G", "mc", "pi", "pa", "D"), losses)}},
+        "step_fp32_mfma_frac": round(value / world * STEP_TFLOP_PER_IMAGE / MFMA_F32_PEAK_TFLOPS, 4),
+    }
+    ap = summarise(recs.get("skd_abn_apply", []), 8)
+    if ap:
+        ach = ap.get("achieved_GBs_large", ap["achieved_GBs"])
+        line["roofline"] = {"kernel": "abn_apply_kernel (skd_abn_apply: teacher eval-mode InPlace-ABN, in place)",
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_element": 8, "detail": ap}
+        line["kernels"] = {
+            "skd_abn_forward_train (stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
+            "skd_abn_backward (reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),
+        }
+    if not a.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.size)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,56 @@ def get():
     """The library object the ops call into (the HIP library, or a test double)."""
     if _test_backend is not None:
         return _test_backend
+    if _timing is not None:
+        return _TimedLib(load())
     return load()
+
+
+# ---- optional per-entry HIP-event timing (bench.py's roofline leg) ---------------------------------
+_timing = None
+
+
+class _TimedLib:
+    """Brackets the selected C-ABI calls with HIP events recorded on the stream the kernels are
+    launched on (torch's current stream, the `stream` argument every op passes)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        rec = _timing.get(name) if _timing is not None else None
+        if rec is None:
+            return fn
+        import torch
+
+        def timed(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args)
+            e1.record()
+            rec.append((e0, e1, args[:3]))
+            return r
+        return timed
+
+
+def enable_kernel_timing(names):
+    """Start collecting (start event, end event, first three int args) for every call of ``names``."""
+    global _timing
+    _timing = {n: [] for n in names}
+
+
+def disable_kernel_timing():
+    """Stop collecting; returns {name: [(ms, (N, C, S)), ...]} (synchronises the device)."""
+    global _timing
+    import torch
+    out = {}
+    if _timing is not None:
+        torch.cuda.synchronize()
+        for n, recs in _timing.items():
+            out[n] = [(e0.elapsed_time(e1), dims) for e0, e1, dims in recs]
+    _timing = None
+    return out
 
 
 def install_test_backend(backend):

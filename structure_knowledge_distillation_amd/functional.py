@@ -1,0 +1,301 @@
+"""Autograd front-ends of the loss / spectral-norm kernels in libskd_hip.so.
+
+Each function here is the differentiable form of one reference computation, executed by the
+hand-written gfx950 kernels behind the C ABI of include/skd.h (no eager fallback: CPU tensors
+raise, see _lib.require_device):
+
+    pixel_wise_loss(S, T)        utils/criterion.py:219-226   csrc/pixelwise.hip
+    max_pool_argmax(x, kh, kw)   nn.MaxPool2d(k=s, ceil_mode=True) of criterion.py:243   csrc/pairwise.hip
+    sim_dis(f_S, f_T)            utils/utils.py:170-183 (L2, similarity, sim_dis_compute)  csrc/pairwise.hip
+    spectral_normalize(W, u, v)  networks/spectral.py:23-35    csrc/spectral.hip
+
+All are first-order only (``once_differentiable``), like the reference's native op
+(libs/functions.py:112,230).  WGAN-GP's double backward (criterion.py:110-115) only needs second
+derivatives of the discriminator's stock convolutions; the spectral-norm node is traversed once,
+by the final ``d_loss.backward()``.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32:
+        raise TypeError("%s: fp32 tensors only (got %s)" % (what, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _PixelWise(Function):
+    @staticmethod
+    def forward(ctx, logits_s, logits_t):
+        _lib.require_device(logits_s, logits_t)
+        assert logits_s.shape == logits_t.shape, "the output dim of teacher and student differ"  # criterion.py:221
+        s, t = _f32c(logits_s, "pixel_wise_loss"), _f32c(logits_t, "pixel_wise_loss")
+        n, c = s.shape[0], s.shape[1]
+        hw = s.numel() // max(1, n * c)
+        lib, st = _lib.get(), _lib.stream_of(s)
+        loss = s.new_empty(())
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(s) if need_grad else None
+        ws = s.new_empty((max(1, lib.skd_pixelwise_workspace_floats(n, hw)),))
+        _lib.check(lib.skd_pixelwise_loss(n, c, hw, s.data_ptr(), t.data_ptr(), loss.data_ptr(),
+                                          _lib.ptr(grad), ws.data_ptr(), st), "skd_pixelwise_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g if grad is not None else None), None
+
+
+def pixel_wise_loss(logits_s, logits_t):
+    """sum(-softmax(T) * log_softmax(S)) / W / H over the class dim of (N,C,W,H) logits; no grad to T."""
+    return _PixelWise.apply(logits_s, logits_t.detach())
+
+
+def pool_out_size(n, k):
+    """ceil_mode=True, stride = kernel, no padding."""
+    return -(-n // k)
+
+
+class _MaxPoolArgmax(Function):
+    @staticmethod
+    def forward(ctx, x, kh, kw):
+        _lib.require_device(x)
+        x = _f32c(x, "max_pool_argmax")
+        b, c, h, w = x.shape
+        oh, ow = pool_out_size(h, kh), pool_out_size(w, kw)
+        lib, st = _lib.get(), _lib.stream_of(x)
+        pooled = x.new_empty((b, c, oh, ow))
+        need = ctx.needs_input_grad[0]
+        index = torch.empty((b, c, oh, ow), dtype=torch.int32, device=x.device) if need else None
+        _lib.check(lib.skd_maxpool_argmax(b * c, h, w, kh, kw, x.data_ptr(), pooled.data_ptr(),
+                                          _lib.ptr(index), st), "skd_maxpool_argmax")
+        ctx.geom = (b, c, h, w, kh, kw)
+        ctx.save_for_backward(index)
+        return pooled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        if index is None:
+            return None, None, None
+        b, c, h, w, kh, kw = ctx.geom
+        g = _f32c(g, "max_pool_argmax backward")
+        m = g.shape[2] * g.shape[3]
+        dx = g.new_empty((b, c, h, w))
+        lib, st = _lib.get(), _lib.stream_of(g)
+        _lib.check(lib.skd_maxunpool_scatter(b * c, h, w, kh, kw, g.data_ptr(), m, index.data_ptr(),
+                                             dx.data_ptr(), st), "skd_maxunpool_scatter")
+        return dx, None, None
+
+
+def max_pool_argmax(x, kh, kw, return_indices=False):
+    """MaxPool2d(kernel=stride=(kh,kw), padding=0, ceil_mode=True).  Indices (bit-exact with
+    PyTorch's: flat h*W+w of the first maximum, int32) are available through max_pool_indices()."""
+    return _MaxPoolArgmax.apply(x, int(kh), int(kw))
+
+
+def max_pool_indices(x, kh, kw):
+    """(pooled, int32 argmax) without autograd -- used by the parity tests."""
+    _lib.require_device(x)
+    x = _f32c(x, "max_pool_indices")
+    b, c, h, w = x.shape
+    oh, ow = pool_out_size(h, kh), pool_out_size(w, kw)
+    pooled = x.new_empty((b, c, oh, ow))
+    index = torch.empty((b, c, oh, ow), dtype=torch.int32, device=x.device)
+    _lib.check(_lib.get().skd_maxpool_argmax(b * c, h, w, int(kh), int(kw), x.data_ptr(), pooled.data_ptr(),
+                                             index.data_ptr(), _lib.stream_of(x)), "skd_maxpool_argmax")
+    return pooled, index
+
+
+class _SimDis(Function):
+    """sim_dis_compute(f_S, f_T) on pooled features (B, C, oh, ow)."""
+
+    @staticmethod
+    def forward(ctx, f_s, f_t):
+        _lib.require_device(f_s, f_t)
+        f_s, f_t = _f32c(f_s, "sim_dis"), _f32c(f_t, "sim_dis")
+        b, cs = f_s.shape[0], f_s.shape[1]
+        ct = f_t.shape[1]
+        m = f_t.shape[-1] * f_t.shape[-2]                      # utils.py:181
+        assert f_s.shape[0] == f_t.shape[0] and f_s.shape[2:] == f_t.shape[2:]
+        lib, st = _lib.get(), _lib.stream_of(f_s)
+        ldm = lib.skd_pairwise_ldm(m)
+        ldc = -(-cs // 128) * 128
+        need = ctx.needs_input_grad[0]
+        fh_s = f_s.new_empty((b, cs, ldm))
+        fh_t = f_s.new_empty((b, ct, ldm))
+        fh_s_t = f_s.new_empty((b, ldm, ldc)) if need else None
+        norm_s = f_s.new_empty((b, m)) if need else None
+        _lib.check(lib.skd_channel_l2_normalise(b, cs, m, f_s.data_ptr(), fh_s.data_ptr(), ldm,
+                                                _lib.ptr(fh_s_t), ldc, _lib.ptr(norm_s), st),
+                   "skd_channel_l2_normalise")
+        _lib.check(lib.skd_channel_l2_normalise(b, ct, m, f_t.data_ptr(), fh_t.data_ptr(), ldm,
+                                                None, 0, None, st), "skd_channel_l2_normalise")
+        g = f_s.new_empty((b, ldm, ldm)) if need else None
+        loss = f_s.new_empty(())
+        ws = f_s.new_empty((max(1, lib.skd_pairwise_workspace_floats(b, m)),))
+        _lib.check(lib.skd_pairwise_gram_loss(b, cs, ct, m, ldm, fh_s.data_ptr(), fh_t.data_ptr(),
+                                              _lib.ptr(g), loss.data_ptr(), ws.data_ptr(), st),
+                   "skd_pairwise_gram_loss")
+        ctx.geom = (tuple(f_s.shape), m, ldm, ldc)
+        ctx.save_for_backward(fh_s_t, g, norm_s)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        fh_s_t, g, norm_s = ctx.saved_tensors
+        if g is None:
+            return None, None
+        shape, m, ldm, ldc = ctx.geom
+        b, cs = shape[0], shape[1]
+        lib, st = _lib.get(), _lib.stream_of(g)
+        gl = gl.to(torch.float32).contiguous()
+        dp = g.new_empty((b, cs, ldm))
+        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, ldc, fh_s_t.data_ptr(), g.data_ptr(),
+                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), st),
+                   "skd_pairwise_backward")
+        return dp[:, :, :m].reshape(shape), None
+
+
+def sim_dis(f_s, f_t):
+    """sum((A_T - A_S)^2) / M^2 / B with A = normalised Gram over channels (utils.py:173-183);
+    the channel L2 norm is a constant for autograd (utils.py:175) and f_T gets no gradient."""
+    return _SimDis.apply(f_s, f_t.detach())
+
+
+class _PairWise(Function):
+    """Whole Pa loss in one node: pool(+argmax) -> normalise -> Gram/loss; backward scatters the
+    pooled gradient straight from the padded GEMM output (no slice/copy in between)."""
+
+    @staticmethod
+    def forward(ctx, feat_s, feat_t, kh, kw):
+        _lib.require_device(feat_s, feat_t)
+        feat_s, feat_t = _f32c(feat_s, "pair_wise_loss"), _f32c(feat_t, "pair_wise_loss")
+        b, cs, h, w = feat_s.shape
+        ct = feat_t.shape[1]
+        assert feat_t.shape[0] == b and tuple(feat_t.shape[2:]) == (h, w)
+        oh, ow = pool_out_size(h, kh), pool_out_size(w, kw)
+        m = oh * ow
+        lib, st = _lib.get(), _lib.stream_of(feat_s)
+        need = ctx.needs_input_grad[0]
+        ldm = lib.skd_pairwise_ldm(m)
+        ldc = -(-cs // 128) * 128
+        p_s = feat_s.new_empty((b, cs, m))
+        p_t = feat_s.new_empty((b, ct, m))
+        index = torch.empty((b, cs, m), dtype=torch.int32, device=feat_s.device) if need else None
+        _lib.check(lib.skd_maxpool_argmax(b * cs, h, w, kh, kw, feat_s.data_ptr(), p_s.data_ptr(),
+                                          _lib.ptr(index), st), "skd_maxpool_argmax")
+        _lib.check(lib.skd_maxpool_argmax(b * ct, h, w, kh, kw, feat_t.data_ptr(), p_t.data_ptr(),
+                                          None, st), "skd_maxpool_argmax")
+        fh_s = feat_s.new_empty((b, cs, ldm))
+        fh_t = feat_s.new_empty((b, ct, ldm))
+        fh_s_t = feat_s.new_empty((b, ldm, ldc)) if need else None
+        norm_s = feat_s.new_empty((b, m)) if need else None
+        _lib.check(lib.skd_channel_l2_normalise(b, cs, m, p_s.data_ptr(), fh_s.data_ptr(), ldm,
+                                                _lib.ptr(fh_s_t), ldc, _lib.ptr(norm_s), st),
+                   "skd_channel_l2_normalise")
+        _lib.check(lib.skd_channel_l2_normalise(b, ct, m, p_t.data_ptr(), fh_t.data_ptr(), ldm,
+                                                None, 0, None, st), "skd_channel_l2_normalise")
+        g = feat_s.new_empty((b, ldm, ldm)) if need else None
+        loss = feat_s.new_empty(())
+        ws = feat_s.new_empty((max(1, lib.skd_pairwise_workspace_floats(b, m)),))
+        _lib.check(lib.skd_pairwise_gram_loss(b, cs, ct, m, ldm, fh_s.data_ptr(), fh_t.data_ptr(),
+                                              _lib.ptr(g), loss.data_ptr(), ws.data_ptr(), st),
+                   "skd_pairwise_gram_loss")
+        ctx.geom = (b, cs, h, w, kh, kw, m, ldm, ldc)
+        ctx.save_for_backward(fh_s_t, g, norm_s, index)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        fh_s_t, g, norm_s, index = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        b, cs, h, w, kh, kw, m, ldm, ldc = ctx.geom
+        lib, st = _lib.get(), _lib.stream_of(g)
+        gl = gl.to(torch.float32).contiguous()
+        dp = g.new_empty((b, cs, ldm))
+        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, ldc, fh_s_t.data_ptr(), g.data_ptr(),
+                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), st),
+                   "skd_pairwise_backward")
+        dx = g.new_empty((b, cs, h, w))
+        _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dp.data_ptr(), ldm, index.data_ptr(),
+                                             dx.data_ptr(), st), "skd_maxunpool_scatter")
+        return dx, None, None, None
+
+
+def pair_wise_loss(feat_s, feat_t, kh, kw):
+    """CriterionPairWiseforWholeFeatAfterPool.forward on raw (B,C,H,W) features, criterion.py:236-245."""
+    return _PairWise.apply(feat_s, feat_t.detach(), int(kh), int(kw))
+
+
+class _SpectralNormalize(Function):
+    """w = w_bar / sigma after ONE power iteration that updates u and v in place (spectral.py:23-35).
+
+    u and v are held by reference, not snapshotted: the reference rebinds ``u.data`` / ``v.data``
+    without an autograd version bump, so a graph recorded by an earlier forward is back-propagated
+    with whatever u, v hold at backward time (the D step runs three forwards before its single
+    backward, kd_model.py:156-164).  Reading them at backward time reproduces that exactly.
+    """
+
+    @staticmethod
+    def forward(ctx, w_bar, u, v):
+        _lib.require_device(w_bar, u, v)
+        wb = _f32c(w_bar, "spectral_normalize")
+        h = wb.shape[0]
+        wd = wb.numel() // h
+        if not (u.is_contiguous() and v.is_contiguous()) or u.numel() != h or v.numel() != wd:
+            raise ValueError("spectral_normalize: u/v must be contiguous vectors of length (out, in*kh*kw)")
+        lib, st = _lib.get(), _lib.stream_of(wb)
+        sigma = wb.new_empty(())
+        w = torch.empty_like(wb)
+        ws = wb.new_empty((max(1, lib.skd_spectral_workspace_floats(h, wd)),))
+        _lib.check(lib.skd_spectral_norm_forward(h, wd, wb.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                                 sigma.data_ptr(), w.data_ptr(), ws.data_ptr(), st),
+                   "skd_spectral_norm_forward")
+        ctx.u, ctx.v = u, v
+        ctx.save_for_backward(wb, sigma)
+        return w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gw):
+        wb, sigma = ctx.saved_tensors
+        h = wb.shape[0]
+        wd = wb.numel() // h
+        gw = _f32c(gw, "spectral_normalize backward")
+        lib, st = _lib.get(), _lib.stream_of(wb)
+        gwb = torch.empty_like(wb)
+        ws = wb.new_empty((max(1, lib.skd_spectral_workspace_floats(h, wd)),))
+        _lib.check(lib.skd_spectral_norm_backward(h, wd, wb.data_ptr(), ctx.u.data_ptr(), ctx.v.data_ptr(),
+                                                  sigma.data_ptr(), gw.data_ptr(), gwb.data_ptr(),
+                                                  ws.data_ptr(), st), "skd_spectral_norm_backward")
+        return gwb, None, None
+
+
+def spectral_normalize(w_bar, u, v):
+    return _SpectralNormalize.apply(w_bar, u, v)
+
+
+def spectral_power_iteration(w_bar, u, v):
+    """u, v update only (extra iterations when power_iterations > 1); returns sigma (0-dim)."""
+    _lib.require_device(w_bar, u, v)
+    wb = _f32c(w_bar.detach(), "spectral_power_iteration")
+    h = wb.shape[0]
+    wd = wb.numel() // h
+    lib, st = _lib.get(), _lib.stream_of(wb)
+    sigma = wb.new_empty(())
+    ws = wb.new_empty((max(1, lib.skd_spectral_workspace_floats(h, wd)),))
+    _lib.check(lib.skd_spectral_norm_forward(h, wd, wb.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                             sigma.data_ptr(), None, ws.data_ptr(), st),
+               "skd_spectral_norm_forward")
+    return sigma

@@ -1,0 +1,266 @@
+"""NetModel -- the distillation-step orchestrator, same surface as the reference's
+networks/kd_model.py:27-193 so ``train_and_eval.py:19-29`` runs unchanged:
+
+    model = NetModel(args)
+    model.adjust_learning_rate(args.lr_g, model.G_solver, step)
+    model.set_input((images, labels, _, _)); model.optimize_parameters(); model.print_info(epoch, step)
+
+One step = frozen teacher forward (no grad, eval) -> student forward (train) -> G loss =
+CE(DSN) + lambda_pi*Pi + lambda_pa*Pa + lambda_d*Ho -> backward -> SGD -> (Ho) discriminator step
+(adv + WGAN-GP) -> SGD  (kd_model.py:167-173).
+
+What differs from the reference, none of it changing a number the step produces:
+  * one process per GPU (utils/parallel.py here); gradients averaged by bucketed RCCL all-reduce;
+  * the four logged scalars are kept as device tensors and read back lazily (one host sync when
+    ``print_info`` / the attributes are read, instead of four ``.item()`` stalls inside the step);
+  * the teacher's cross-entropy, which the reference computes and discards (kd_model.py:129), is skipped;
+  * while the student loss is back-propagated through D (kd_model.py:148-150) D's parameters do not
+    require grad: the reference computes those weight gradients and then zeroes them (kd_model.py:154).
+"""
+import logging
+import os
+import os.path as osp
+
+import torch
+import torch.nn as nn  # noqa: F401
+import torch.optim as optim
+
+from ..utils import parallel as parallel_old
+from ..utils.criterion import (CriterionAdditionalGP, CriterionAdv, CriterionAdvForG, CriterionDSN,
+                               CriterionPairWiseforWholeFeatAfterPool, CriterionPixelWise)
+from ..utils.utils import print_model_parm_nums, to_tuple_str  # noqa: F401
+from .pspnet_combine import BasicBlock, Bottleneck, Res_pspnet
+from .sagan_models import Discriminator
+
+
+def load_T_model(model, ckpt_path):
+    """utils/utils.py:73-91: teacher checkpoints store the PSP module under head.0 / the classifier under head.1."""
+    if not ckpt_path or not osp.isfile(ckpt_path):
+        logging.info("teacher checkpoint %r not found: random initialisation", ckpt_path)
+        return False
+    saved = torch.load(ckpt_path, map_location="cpu")
+    new = {}
+    for k, v in saved.items():
+        if k.startswith("head.0."):
+            k = "pspmodule." + k[len("head.0."):]
+        elif k.startswith("head.1."):
+            k = "head." + k[len("head.1."):]
+        new[k] = v
+    model.load_state_dict(new, strict=False)
+    return True
+
+
+def load_S_model(args, model, with_module=False):
+    """utils/utils.py:93-128: ImageNet ResNet18 weights by key intersection when available."""
+    path = getattr(args, "student_pretrain_model_imgnet", None)
+    if not getattr(args, "is_student_load_imgnet", False) or not path or not osp.isfile(str(path)):
+        logging.info("student: no ImageNet checkpoint, random initialisation")
+        return False
+    saved = torch.load(path, map_location="cpu")
+    own = model.state_dict()
+    own.update({k: v for k, v in saved.items() if k in own and own[k].shape == v.shape})
+    model.load_state_dict(own)
+    return True
+
+
+class NetModel():
+    def name(self):
+        return "kd_seg"
+
+    def DataParallelModelProcess(self, model, ParallelModelType=1, is_eval="train", device="cuda"):
+        if ParallelModelType not in (1, 2):
+            raise ValueError("ParallelModelType should be 1 or 2")
+        parallel_model = parallel_old.DataParallelModel(model)
+        if is_eval == "eval":
+            parallel_model.eval()
+        elif is_eval == "train":
+            parallel_model.train()
+        else:
+            raise ValueError("is_eval should be eval or train")
+        parallel_model.float()
+        parallel_model.to(device)
+        return parallel_model
+
+    def DataParallelCriterionProcess(self, criterion, device="cuda"):
+        criterion = parallel_old.my_DataParallelCriterion(criterion)
+        criterion.to(self.args.device)
+        return criterion
+
+    def __init__(self, args):
+        self.args = args
+        device = args.device
+        torch.backends.cudnn.enabled = True          # MIOpen
+        student = Res_pspnet(BasicBlock, [2, 2, 2, 2], num_classes=args.classes_num)
+        load_S_model(args, student, False)
+        print_model_parm_nums(student, "student_model")
+        self.parallel_student = self.DataParallelModelProcess(student, 2, "train", device)
+        self.student = student
+
+        teacher = Res_pspnet(Bottleneck, [3, 4, 23, 3], num_classes=args.classes_num)
+        load_T_model(teacher, getattr(args, "T_ckpt_path", None))
+        print_model_parm_nums(teacher, "teacher_model")
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        self.parallel_teacher = self.DataParallelModelProcess(teacher, 2, "eval", device)
+        self.teacher = teacher
+
+        D_model = Discriminator(args.preprocess_GAN_mode, args.classes_num, args.batch_size,
+                                args.imsize_for_adv, args.adv_conv_dim)
+        print_model_parm_nums(D_model, "D_model")
+        self.parallel_D = self.DataParallelModelProcess(D_model, 2, "train", device)
+        self.D_model = D_model
+
+        # every replica starts from rank 0's weights (the reference re-broadcasts them every forward)
+        for m in (student, teacher, D_model):
+            parallel_old.broadcast_module(m)
+
+        self._s_params = [p for p in self.student.parameters() if p.requires_grad]
+        self._d_params = [p for p in D_model.parameters() if p.requires_grad]
+        self.G_solver = optim.SGD([{"params": self._s_params, "initial_lr": args.lr_g}], args.lr_g,
+                                  momentum=args.momentum, weight_decay=args.weight_decay)
+        self.D_solver = optim.SGD([{"params": self._d_params, "initial_lr": args.lr_d}], args.lr_d,
+                                  momentum=args.momentum, weight_decay=args.weight_decay)
+        self._s_reducer = parallel_old.GradientAllReducer(self._s_params)
+        self._d_reducer = parallel_old.GradientAllReducer(self._d_params)
+
+        self.best_mean_IU = args.best_mean_IU
+
+        self.criterion = self.DataParallelCriterionProcess(CriterionDSN())
+        self.criterion_pixel_wise = self.DataParallelCriterionProcess(CriterionPixelWise())
+        self.criterion_pair_wise_for_interfeat = self.DataParallelCriterionProcess(
+            CriterionPairWiseforWholeFeatAfterPool(scale=args.pool_scale, feat_ind=-5))
+        self.criterion_adv = self.DataParallelCriterionProcess(CriterionAdv(args.adv_loss_type))
+        if args.adv_loss_type == "wgan-gp":
+            self.criterion_AdditionalGP = self.DataParallelCriterionProcess(
+                CriterionAdditionalGP(self.parallel_D, args.lambda_gp))
+        self.criterion_adv_for_G = self.DataParallelCriterionProcess(CriterionAdvForG(args.adv_loss_type))
+
+        self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0}
+        self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
+
+        torch.backends.cudnn.benchmark = True        # MIOpen find mode
+        snap = getattr(args, "snapshot_dir", None)
+        if snap and not os.path.exists(snap):
+            os.makedirs(snap)
+
+    # ---- logged scalars: device tensors until somebody reads them -------------------------------
+    def _get_scalar(self, key):
+        v = self._scalars[key]
+        if torch.is_tensor(v):
+            v = v.item()
+            self._scalars[key] = v
+        return v
+
+    mc_G_loss = property(lambda self: self._get_scalar("mc_G_loss"))
+    pi_G_loss = property(lambda self: self._get_scalar("pi_G_loss"))
+    pa_G_loss = property(lambda self: self._get_scalar("pa_G_loss"))
+    G_loss = property(lambda self: self._get_scalar("G_loss"))
+    D_loss = property(lambda self: self._get_scalar("D_loss"))
+
+    def set_input(self, data):
+        images, labels, _, _ = data
+        dev = self.args.device
+        self.images = images.to(dev, non_blocking=True)
+        self.labels = labels.long().to(dev, non_blocking=True)
+
+    def lr_poly(self, base_lr, iter, max_iter, power):
+        return base_lr * ((1 - float(iter) / max_iter) ** (power))
+
+    def adjust_learning_rate(self, base_lr, optimizer, i_iter):
+        args = self.args
+        lr = self.lr_poly(base_lr, i_iter, args.num_steps, args.power)
+        optimizer.param_groups[0]["lr"] = lr
+        return lr
+
+    def forward(self):
+        args = self.args
+        with torch.no_grad():
+            self.preds_T = self.parallel_teacher.eval()(self.images, parallel=args.parallel)
+        self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
+
+    def student_backward(self):
+        args = self.args
+        temp = self.criterion(self.preds_S, self.labels, is_target_scattered=False)
+        self._scalars["mc_G_loss"] = temp.detach()
+        G_loss = temp
+        if args.pi == True:  # noqa: E712  (flags may arrive as 0/1)
+            temp = args.lambda_pi * self.criterion_pixel_wise(self.preds_S, self.preds_T, is_target_scattered=True)
+            self._scalars["pi_G_loss"] = temp.detach()
+            G_loss = G_loss + temp
+        if args.pa == True:  # noqa: E712
+            temp1 = self.criterion_pair_wise_for_interfeat(self.preds_S, self.preds_T, is_target_scattered=True)
+            self._scalars["pa_G_loss"] = temp1.detach()
+            G_loss = G_loss + args.lambda_pa * temp1
+        if args.ho == True:  # noqa: E712
+            for p in self._d_params:
+                p.requires_grad_(False)
+            try:
+                d_out_S = self.parallel_D(self.preds_S[0], parallel=args.parallel)
+            finally:
+                for p in self._d_params:
+                    p.requires_grad_(True)
+            G_loss = G_loss + args.lambda_d * self.criterion_adv_for_G(d_out_S, d_out_S, is_target_scattered=True)
+        self._s_reducer.arm()
+        G_loss.backward()
+        self._s_reducer.finish()
+        self._scalars["G_loss"] = G_loss.detach()
+
+    def discriminator_backward(self):
+        self.D_solver.zero_grad()
+        args = self.args
+        d_out_T = self.parallel_D(self.preds_T[0].detach(), parallel=True)
+        d_out_S = self.parallel_D(self.preds_S[0].detach(), parallel=True)
+        d_loss = args.lambda_d * self.criterion_adv(d_out_S, d_out_T, is_target_scattered=True)
+        if args.adv_loss_type == "wgan-gp":
+            gp = self.criterion_AdditionalGP(self.preds_S, self.preds_T, alpha=self.gp_alpha, is_target_scattered=True)
+            d_loss = d_loss + args.lambda_d * gp
+        self._d_reducer.arm()
+        d_loss.backward()
+        self._d_reducer.finish()
+        self._scalars["D_loss"] = d_loss.detach()
+        self.D_solver.step()
+
+    def optimize_parameters(self):
+        self.forward()
+        self.G_solver.zero_grad()
+        self.student_backward()
+        self.G_solver.step()
+        if self.args.ho == True:  # noqa: E712
+            self.discriminator_backward()
+
+    def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
+        """Evaluation (networks/evaluate.py) is outside this hot path: use the
+        reference's evaluate_main when it is importable in the caller's environment."""
+        try:
+            from networks.evaluate import evaluate_main
+        except Exception as e:  # pragma: no cover
+            raise NotImplementedError("evaluation is not part of the MI355X distillation hot path; "
+                                      "networks.evaluate.evaluate_main is not importable: %s" % (e,))
+        return evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
+                             num_classes=num_classes, whole=whole)
+
+    def print_info(self, epoch, step):
+        logging.info("step:{:5d} G_lr:{:.6f} G_loss:{:.5f}(mc:{:.5f} pixelwise:{:.5f} pairwise:{:.5f}) "
+                     "D_lr:{:.6f} D_loss:{:.5f}".format(
+                         step, self.G_solver.param_groups[-1]["lr"], self.G_loss, self.mc_G_loss,
+                         self.pi_G_loss, self.pa_G_loss, self.D_solver.param_groups[-1]["lr"], self.D_loss))
+
+    def save_ckpt(self, epoch, step, mean_IU, IU_array):
+        torch.save(self.student.state_dict(),
+                   osp.join(self.args.snapshot_dir, "CS_scenes_" + str(step) + "_" + str(mean_IU) + ".pth"))
+
+
+def default_args(**overrides):
+    """The flag defaults of utils/train_options.py:18-63 that shape the step, as a namespace
+    (``run_train_val.sh`` overrides: weight_decay 5e-4, lambda_pa 0.5)."""
+    import argparse
+    a = argparse.Namespace(
+        classes_num=19, batch_size=8, input_size="512,512", momentum=0.9, num_steps=40000, power=0.9,
+        weight_decay=1e-4, lr_g=1e-2, lr_d=4e-4, pi=True, pa=True, ho=True, lambda_pi=10.0, lambda_pa=1.0,
+        lambda_d=0.1, lambda_gp=10.0, pool_scale=0.5, adv_loss_type="wgan-gp", imsize_for_adv=65,
+        adv_conv_dim=64, preprocess_GAN_mode=1, parallel="True", gpu="0", gpu_num=1, best_mean_IU=0.0,
+        T_ckpt_path=None, is_student_load_imgnet=False, student_pretrain_model_imgnet=None,
+        snapshot_dir=None, device=torch.device("cuda" if torch.cuda.is_available() else "cpu"))
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    return a

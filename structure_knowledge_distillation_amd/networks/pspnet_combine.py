@@ -1,0 +1,160 @@
+"""Dilated-ResNet PSPNet (student ResNet18 / teacher ResNet101) on MI355X.
+
+Same public surface, module names and state-dict keys as the reference's
+networks/pspnet_combine.py:114-197 (150 tensors student / 565 teacher), so its checkpoints load
+and ``forward`` returns the same 7-element list ``[logits, dsn, feat_after_psp, x4, x3, x2, x1]``
+(pspnet_combine.py:189).  Convolutions run on MIOpen through PyTorch-ROCm; every normalisation is
+the hand-written InPlace-ABN of csrc/abn.hip (``libs``), applied in place on the conv output.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..libs import InPlaceABN, InPlaceABNSync  # noqa: F401  (re-exported like pspnet_combine.py:11)
+
+affine_par = True
+BatchNorm2d = functools.partial(InPlaceABNSync, activation="none")   # pspnet_combine.py:12
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, multi_grid=1):
+        super().__init__()
+        d = dilation * multi_grid
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, d, d, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=False)       # ABN keeps its OUTPUT for backward: not in place
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, d, d, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.relu_inplace = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        residual = self.downsample(x) if self.downsample is not None else x
+        return self.relu_inplace(out + residual)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, fist_dilation=1, multi_grid=1):
+        super().__init__()
+        d = dilation * multi_grid
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, d, d, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=False)
+        self.relu_inplace = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.dilation = dilation
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        residual = self.downsample(x) if self.downsample is not None else x
+        return self.relu_inplace(out + residual)
+
+
+class PSPModule(nn.Module):
+    """Pyramid pooling (pspnet_combine.py:86-112): pooled priors at 1,2,3,6 -> 1x1 conv -> ABN(leaky)
+    -> bilinear (align_corners) back to the feature size -> concat -> 3x3 conv -> ABN(leaky) -> Dropout2d."""
+
+    def __init__(self, features, out_features=512, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([self._make_stage(features, out_features, s) for s in sizes])
+        self.bottleneck = nn.Sequential(
+            nn.Conv2d(features + len(sizes) * out_features, out_features, 3, padding=1, dilation=1, bias=False),
+            InPlaceABNSync(out_features),
+            nn.Dropout2d(0.1))
+
+    def _make_stage(self, features, out_features, size):
+        return nn.Sequential(nn.AdaptiveAvgPool2d(output_size=(size, size)),
+                             nn.Conv2d(features, out_features, 1, bias=False),
+                             InPlaceABNSync(out_features))
+
+    def forward(self, feats):
+        h, w = feats.size(2), feats.size(3)
+        priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=True)
+                  for stage in self.stages] + [feats]
+        return self.bottleneck(torch.cat(priors, 1))
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes):
+        self.inplanes = 128
+        super().__init__()
+        self.conv1 = conv3x3(3, 64, stride=2)
+        self.bn1 = BatchNorm2d(64)
+        self.relu1 = nn.ReLU(inplace=False)
+        self.conv2 = conv3x3(64, 64)
+        self.bn2 = BatchNorm2d(64)
+        self.relu2 = nn.ReLU(inplace=False)
+        self.conv3 = conv3x3(64, 128)
+        self.bn3 = BatchNorm2d(128)
+        self.relu3 = nn.ReLU(inplace=False)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=True)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=1, dilation=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=1, dilation=4, multi_grid=(1, 1, 1))
+        layers = list(layers)
+        if layers == [3, 4, 23, 3]:
+            feat, mid = 2048, 512
+        elif layers == [2, 2, 2, 2]:
+            feat, mid = 512, 128
+        else:
+            raise ValueError("layers should be [3, 4, 23, 3] or [2, 2, 2, 2]")
+        self.pspmodule = PSPModule(feat, mid)
+        self.head = nn.Conv2d(mid, num_classes, 1, 1, 0, bias=True)
+        self.dsn = nn.Sequential(
+            nn.Conv2d(feat // 2, mid, 3, 1, 1),
+            InPlaceABNSync(mid),
+            nn.Dropout2d(0.1),
+            nn.Conv2d(mid, num_classes, 1, 1, 0, bias=True))
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1, multi_grid=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                BatchNorm2d(planes * block.expansion, affine=affine_par))
+        grid = lambda i: multi_grid[i % len(multi_grid)] if isinstance(multi_grid, tuple) else 1
+        mods = [block(self.inplanes, planes, stride, dilation=dilation, downsample=downsample, multi_grid=grid(0))]
+        self.inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            mods.append(block(self.inplanes, planes, dilation=dilation, multi_grid=grid(i)))
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        x = self.relu1(self.bn1(self.conv1(x)))
+        x = self.relu2(self.bn2(self.conv2(x)))
+        x = self.relu3(self.bn3(self.conv3(x)))
+        x = self.maxpool(x)
+        x1 = self.layer1(x)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        x_dsn = self.dsn(x3)
+        x4 = self.layer4(x3)
+        x_feat_after_psp = self.pspmodule(x4)
+        x = self.head(x_feat_after_psp)
+        return [x, x_dsn, x_feat_after_psp, x4, x3, x2, x1]
+
+
+def Res_pspnet(block=Bottleneck, layers=[3, 4, 23, 3], num_classes=21):
+    """ResNet(Bottleneck, [3, 4, 23, 3], C) = teacher; ResNet(BasicBlock, [2, 2, 2, 2], C) = student."""
+    return ResNet(block, layers, num_classes)

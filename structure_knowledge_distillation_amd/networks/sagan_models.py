@@ -1,0 +1,71 @@
+"""Holistic (SAGAN) discriminator, networks/sagan_models.py:9-41 (Self_Attn) and :105-168
+(Discriminator) of the reference; same constructor, module names and state-dict keys (37 tensors).
+Spectral-normalised convolutions use the gfx950 kernel through networks/spectral.py; the
+convolutions and the two tiny attention bmm's run on MIOpen / rocBLAS (stock ops, so WGAN-GP's
+double backward through them keeps working).  The unused ``Generator`` is out of scope."""
+import torch
+import torch.nn as nn
+
+from .spectral import SpectralNorm
+
+
+class Self_Attn(nn.Module):
+    """out = gamma * (V softmax(Q^T K)^T) + x, attention returned as (B, N, N)."""
+
+    def __init__(self, in_dim, activation):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.activation = activation
+        self.query_conv = nn.Conv2d(in_dim, in_dim // 8, 1)
+        self.key_conv = nn.Conv2d(in_dim, in_dim // 8, 1)
+        self.value_conv = nn.Conv2d(in_dim, in_dim, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):
+        b, c, width, height = x.size()
+        n = width * height
+        q = self.query_conv(x).view(b, -1, n).permute(0, 2, 1)
+        k = self.key_conv(x).view(b, -1, n)
+        attention = self.softmax(torch.bmm(q, k))
+        v = self.value_conv(x).view(b, -1, n)
+        out = torch.bmm(v, attention.permute(0, 2, 1)).view(b, c, width, height)
+        return self.gamma * out + x, attention
+
+
+class Discriminator(nn.Module):
+    def __init__(self, preprocess_GAN_mode, input_channel, batch_size=64, image_size=64, conv_dim=64):
+        super().__init__()
+        self.imsize = image_size
+
+        def sn_block(cin, cout):
+            return nn.Sequential(SpectralNorm(nn.Conv2d(cin, cout, 4, 2, 1)), nn.LeakyReLU(0.1))
+
+        curr = conv_dim
+        self.l1 = sn_block(input_channel, curr)
+        self.l2 = sn_block(curr, curr * 2)
+        curr *= 2
+        self.l3 = sn_block(curr, curr * 2)
+        curr *= 2
+        if self.imsize == 65:                        # sagan_models.py:131-136
+            self.l4 = sn_block(curr, curr * 2)
+            curr *= 2
+        self.last = nn.Sequential(nn.Conv2d(curr, 1, 4))
+        self.attn1 = Self_Attn(256, "relu")
+        self.attn2 = Self_Attn(512, "relu")
+        if preprocess_GAN_mode == 1:
+            self.preprocess_additional = nn.BatchNorm2d(input_channel)
+        elif preprocess_GAN_mode == 2:
+            self.preprocess_additional = nn.Tanh()
+        elif preprocess_GAN_mode == 3:
+            self.preprocess_additional = lambda x: 2 * (x / 255 - 0.5)
+        else:
+            raise ValueError("preprocess_GAN_mode should be 1:bn or 2:tanh or 3:-1 - 1")
+
+    def forward(self, x):
+        x = self.preprocess_additional(x)
+        out = self.l3(self.l2(self.l1(x)))
+        out, p1 = self.attn1(out)
+        out = self.l4(out)
+        out, p2 = self.attn2(out)
+        return [self.last(out), p1, p2]

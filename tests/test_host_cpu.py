@@ -1,0 +1,163 @@
+"""Host-side logic on a box without a GPU: the product's autograd wiring, module surface and
+NetModel step are run with oracle/libskd_ref.so installed as the C-ABI double (same entry points,
+host pointers) and compared with the torch oracle.  No compute goes through libskd_hip.so here."""
+import argparse
+
+import pytest
+import torch
+
+from oracle import abn_torch, cref, step_torch as O
+from structure_knowledge_distillation_amd import _lib
+
+
+@pytest.fixture(autouse=True)
+def c_double():
+    _lib.install_test_backend(cref.load(_lib.SIGNATURES))
+    yield
+    _lib.install_test_backend(None)
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_abn_module_autograd_and_inplace_contract():
+    from structure_knowledge_distillation_amd import libs
+    torch.manual_seed(0)
+    for act in ("none", "leaky_relu", "elu"):
+        mod = libs.InPlaceABNSync(6, activation=act).train()
+        with torch.no_grad():
+            mod.weight.copy_(torch.randn(6)); mod.bias.copy_(torch.randn(6))
+        x = torch.randn(3, 6, 5, 4)
+        gz = torch.randn(3, 6, 5, 4)
+        xo = x.double().requires_grad_(True)
+        wo, bo = mod.weight.detach().double().requires_grad_(True), mod.bias.detach().double().requires_grad_(True)
+        rm, rv = torch.zeros(6, dtype=torch.float64), torch.ones(6, dtype=torch.float64)
+        zo = abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, act, 0.01)
+        zo.backward(gz.double())
+        xg = x.clone().requires_grad_(True)
+        inp = xg * 1.0
+        z = mod(inp)
+        assert z.data_ptr() == inp.data_ptr()
+        z.backward(gz)
+        assert rel(z, zo) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
+        assert rel(mod.weight.grad, wo.grad) < 1e-4 and rel(mod.bias.grad, bo.grad) < 1e-4
+        assert rel(mod.running_mean, rm) < 1e-6 and rel(mod.running_var, rv) < 1e-6
+        with pytest.raises(RuntimeError):   # once_differentiable: no double backward (functions.py:112)
+            xg2 = x.clone().requires_grad_(True)
+            out = mod(xg2 * 1.0)
+            (g1,) = torch.autograd.grad(out.sum(), xg2, create_graph=True)
+            g1.sum().backward()
+    with pytest.raises(ValueError):
+        libs.InPlaceABN(6)(torch.randn(2, 6, 4, 4).transpose(2, 3))
+    # wrappers and state-dict keys of libs/bn.py
+    wr = libs.InPlaceABNSyncWrapper(4)
+    assert sorted(wr.state_dict().keys()) == ["bn.bias", "bn.running_mean", "bn.running_var", "bn.weight"]
+    assert libs.InPlaceABNSync(4, devices=[0, 1]).devices == [0, 1]
+
+
+def test_criteria_host_wiring():
+    from structure_knowledge_distillation_amd.utils import criterion as C
+    g = torch.Generator().manual_seed(1)
+    S = [torch.randn(2, 19, 17, 17, generator=g).requires_grad_(True), torch.randn(2, 19, 17, 17, generator=g).requires_grad_(True),
+         torch.randn(2, 12, 17, 17, generator=g).requires_grad_(True)] + [None] * 4
+    T = [torch.randn(2, 19, 17, 17, generator=g), torch.randn(2, 19, 17, 17, generator=g), torch.randn(2, 20, 17, 17, generator=g)] + [None] * 4
+    So = [t.detach().double().requires_grad_(True) for t in S[:3]] + [None] * 4
+    To = [t.double() for t in T[:3]] + [None] * 4
+    y = torch.randint(0, 19, (2, 65, 65), generator=g)
+    y[1, 5:9] = 255
+    got = C.CriterionDSN()(S, y) + 10 * C.CriterionPixelWise()(S, T) + 0.5 * C.CriterionPairWiseforWholeFeatAfterPool(0.5, -5)(S, T)
+    want = O.criterion_dsn(So, y) + 10 * O.criterion_pixel_wise(So, To) + 0.5 * O.criterion_pair_wise(So, To, 0.5, -5)
+    assert abs(float(got) - float(want)) < 1e-5 * abs(float(want))
+    got.backward(); want.backward()
+    for a, b in zip(S[:3], So[:3]):
+        assert rel(a.grad, b.grad) < 1e-4
+    for scale in (0.25, 0.1):
+        a = C.CriterionPairWiseforWholeFeatAfterPool(scale, -5)(S, T)
+        b = O.criterion_pair_wise(So, To, scale, -5)
+        assert abs(float(a) - float(b)) < 1e-5 * abs(float(b))
+
+
+def test_spectral_norm_wrapper_state_and_quirk():
+    from structure_knowledge_distillation_amd.networks.spectral import SpectralNorm
+    torch.manual_seed(2)
+    conv = torch.nn.Conv2d(5, 7, 4, 2, 1)
+    sn = SpectralNorm(conv)
+    assert sorted(sn.state_dict().keys()) == ["module.bias", "module.weight_bar", "module.weight_u", "module.weight_v"]
+    assert not conv.weight_u.requires_grad and not conv.weight_v.requires_grad and conv.weight_bar.requires_grad
+    Pd = {"weight_bar": conv.weight_bar.detach().double().requires_grad_(True), "weight_u": conv.weight_u.detach().double().clone(),
+          "weight_v": conv.weight_v.detach().double().clone()}
+    x1, x2 = torch.randn(2, 5, 9, 9), torch.randn(2, 5, 9, 9)
+    y = sn(x1).sum() + (sn(x2) ** 2).sum()        # two forwards, one backward
+    y.backward()
+    F = torch.nn.functional
+    yo = F.conv2d(x1.double(), O.spectral_weight(Pd, ""), conv.bias.detach().double(), 2, 1).sum() + \
+        (F.conv2d(x2.double(), O.spectral_weight(Pd, ""), conv.bias.detach().double(), 2, 1) ** 2).sum()
+    yo.backward()
+    assert rel(conv.weight_u, Pd["weight_u"]) < 1e-5 and rel(conv.weight_v, Pd["weight_v"]) < 1e-5
+    assert abs(float(y) - float(yo)) < 1e-4 * abs(float(yo))
+    assert rel(conv.weight_bar.grad, Pd["weight_bar"].grad) < 1e-4
+
+
+def _tiny_args(**kw):
+    from structure_knowledge_distillation_amd.networks.kd_model import default_args
+    return default_args(device=torch.device("cpu"), weight_decay=5e-4, lambda_pa=0.5, **kw)
+
+
+def test_netmodel_surface_and_step_pi_pa():
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel
+    torch.manual_seed(3)
+    model = NetModel(_tiny_args(batch_size=2, ho=False))
+    for attr in ("G_solver", "D_solver", "student", "adjust_learning_rate", "set_input", "optimize_parameters",
+                 "print_info", "evalute_model", "save_ckpt", "G_loss", "mc_G_loss", "pi_G_loss", "pa_G_loss", "D_loss"):
+        assert hasattr(model, attr), attr
+    assert model.name() == "kd_seg"
+    assert abs(model.adjust_learning_rate(1e-2, model.G_solver, 20000) - 1e-2 * 0.5 ** 0.9) < 1e-12
+    assert model.G_solver.param_groups[0]["lr"] == model.lr_poly(1e-2, 20000, 40000, 0.9)
+    for m in model.student.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    PS = {k: v.detach().clone() for k, v in model.student.state_dict().items()}
+    PT = {k: v.detach().clone() for k, v in model.teacher.state_dict().items()}
+    x, y = O.synthetic_batch(2, 96, 96)
+    model.adjust_learning_rate(1e-2, model.G_solver, 0)
+    model.set_input((x, y.float(), None, None))      # the loader hands float labels (datasets.py), .long() in set_input
+    model.optimize_parameters()
+    cfg = O.StepConfig(ho=False, weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
+    out = O.distillation_step(PS, PT, None, x, y, cfg)
+    for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
+        assert abs(getattr(model, k) - out[k]) <= 2e-5 * abs(out[k]), k
+    assert model.D_loss == 0.0
+    assert all(not p.requires_grad for p in model.teacher.parameters())
+    model.print_info(0, 0)
+
+
+@pytest.mark.timeout(600)
+def test_netmodel_full_step_with_ho_cpu_double():
+    """Pi+Pa+Ho at B=2, 512x512 (D needs 65x65 logits) through the C double vs the torch oracle."""
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel
+    torch.manual_seed(4)
+    model = NetModel(_tiny_args(batch_size=2))
+    for m in model.student.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    with torch.no_grad():
+        model.D_model.attn1.gamma.fill_(0.25)
+        model.D_model.attn2.gamma.fill_(-0.5)
+    snap = lambda mod: {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    PS, PT, PD = snap(model.student), snap(model.teacher), snap(model.D_model)
+    x, y = O.synthetic_batch(2, 512, 512)
+    alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(5))
+    model.gp_alpha = alpha
+    model.set_input((x, y, None, None))
+    model.optimize_parameters()
+    assert all(p.requires_grad for p in model._d_params)
+    out = O.distillation_step(PS, PT, PD, x, y, O.StepConfig(weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0), alpha=alpha)
+    for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
+        assert abs(getattr(model, k) - out[k]) <= 5e-5 * abs(out[k]), (k, getattr(model, k), out[k])
+    assert abs(model.D_loss - out["D_loss"]) <= 1e-3 * abs(out["D_loss"]), (model.D_loss, out["D_loss"])
+    after = model.D_model.state_dict()
+    for k in PD:
+        if k.endswith(("weight_u", "weight_v")):
+            assert rel(after[k], PD[k]) < 1e-4, k

@@ -1,0 +1,73 @@
+"""Repository contract: oracle/ is test infrastructure.  Nothing under the product package may
+import, link or execute it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+import ast
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "structure_knowledge_distillation_amd")
+
+
+def _py_files(top):
+    for d, _, files in os.walk(top):
+        for f in files:
+            if f.endswith(".py"):
+                yield os.path.join(d, f)
+
+
+def _imports(path):
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom):
+            yield ("." * node.level) + (node.module or "")
+
+
+def test_product_never_imports_oracle_or_reference():
+    for path in _py_files(PKG):
+        src = open(path).read()
+        for mod in _imports(path):
+            assert not mod.lstrip(".").startswith("oracle"), "%s imports %s" % (path, mod)
+        assert "/root/reference" not in src, path
+        assert "libskd_ref" not in src and "libabn_ref" not in src, path
+
+
+def test_native_sources_do_not_reference_oracle():
+    for d, _, files in os.walk(os.path.join(PKG, "csrc")):
+        for f in files:
+            src = open(os.path.join(d, f)).read()
+            assert "oracle" not in src.lower() or "oracle/" not in src, f
+
+
+def test_oracle_use_is_confined():
+    allowed_roots = {"tests", "oracle"}
+    for path in _py_files(ROOT):
+        relp = os.path.relpath(path, ROOT)
+        top = relp.split(os.sep)[0]
+        if top in allowed_roots or top.startswith(".") or top == "gpurun_out":
+            continue
+        uses = any(m.lstrip(".").startswith("oracle") for m in _imports(path))
+        if not uses:
+            continue
+        assert relp in ("bench.py", "__graft_entry__.py"), relp
+        src = open(path).read()
+        if relp == "bench.py":     # only inside cpu_baseline()
+            body = src.split("def cpu_baseline", 1)[1].split("\ndef ", 1)[0]
+            outside = src.replace(body, "")
+            assert not re.search(r"^\s*(from|import) oracle", outside, flags=re.M)
+        else:                      # only inside build() (compiles the checker) and smoke()
+            head = src.split("def build", 1)[0]
+            assert not re.search(r"^\s*(from|import) oracle", head, flags=re.M)
+
+
+def test_oracle_headers_say_test_infrastructure():
+    for f in os.listdir(os.path.join(ROOT, "oracle")):
+        if f.endswith((".py", ".c")):
+            assert "TEST INFRASTRUCTURE" in open(os.path.join(ROOT, "oracle", f)).read(), f
+
+
+def test_required_files_exist():
+    for f in ("bench.py", "__graft_entry__.py", "include/skd.h", "DESIGN.md", "INTEGRATION.md", "oracle/Makefile"):
+        assert os.path.exists(os.path.join(ROOT, f)), f

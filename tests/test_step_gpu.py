@@ -1,0 +1,274 @@
+"""-m gpu: the drop-in Python surface (libs.InPlaceABN*, utils.criterion.*, networks.*, NetModel) on
+cuda:0 against the CPU oracle (oracle/step_torch.py, pinned to the reference's own Python) on the
+same seeded inputs and weights.
+
+Tolerances:
+  losses mc / pi / pa / G           <= 1e-4 relative (north_star); observed ~1e-6
+  D loss (contains the WGAN-GP double backward)   <= 1e-3 relative
+  running statistics                 <= 1e-5 relative
+  parameter gradients                error vs the fp64 oracle <= 4x the error of the fp32 CPU
+                                     oracle vs the fp64 oracle for the same tensor, + 1e-6 absolute
+                                     (backbone gradients are ill-conditioned: SURVEY.md section 4)
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import abn_torch, step_torch as O
+from structure_knowledge_distillation_amd import _lib
+from structure_knowledge_distillation_amd import libs
+from structure_knowledge_distillation_amd.networks import pspnet_combine, sagan_models
+from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+from structure_knowledge_distillation_amd.utils import criterion as C
+from structure_knowledge_distillation_amd.utils import utils as U
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cpu_sd(mod, dtype=torch.float32):
+    return {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu().clone())
+            for k, v in mod.state_dict().items()}
+
+
+def no_dropout(mod):
+    for m in mod.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+
+
+@pytest.mark.parametrize("act", ["none", "leaky_relu", "elu"])
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (4, 64, 65, 65), (3, 128, 1, 1), (2, 19, 6, 6)])
+def test_inplace_abn_module_vs_oracle(act, shape):
+    torch.manual_seed(0)
+    mod = libs.InPlaceABNSync(shape[1], activation=act).to(DEV).train()
+    with torch.no_grad():
+        mod.weight.copy_(torch.randn(shape[1]))
+        mod.bias.copy_(torch.randn(shape[1]))
+    x = torch.randn(*shape) * 2 + 1
+    gz = torch.randn(*shape)
+    # oracle in fp64 (closed form + autograd)
+    xo = x.double().requires_grad_(True)
+    wo, bo = mod.weight.detach().cpu().double().requires_grad_(True), mod.bias.detach().cpu().double().requires_grad_(True)
+    rm, rv = torch.zeros(shape[1], dtype=torch.float64), torch.ones(shape[1], dtype=torch.float64)
+    zo = abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, act, 0.01)
+    zo.backward(gz.double())
+    # product: the op is in place on its input, so feed it a non-leaf
+    xg = x.to(DEV).requires_grad_(True)
+    inp = xg * 1.0
+    z = mod(inp)
+    assert z.data_ptr() == inp.data_ptr(), "in-place contract (mark_dirty)"
+    z.backward(gz.to(DEV))
+    assert rel(z, zo) < 3e-6
+    assert rel(xg.grad, xo.grad) < 2e-5
+    assert rel(mod.weight.grad, wo.grad) < 2e-5 and rel(mod.bias.grad, bo.grad) < 2e-5
+    assert rel(mod.running_mean, rm) < 1e-5 and rel(mod.running_var, rv) < 1e-5
+    assert sorted(mod.state_dict().keys()) == ["bias", "running_mean", "running_var", "weight"]
+    # eval mode uses the running statistics
+    mod.eval()
+    ze = mod(x.to(DEV).clone())
+    zeo = abn_torch.abn_autograd(x.double(), wo.detach(), bo.detach(), rm, rv, False, 0.1, 1e-5, act, 0.01)
+    assert rel(ze, zeo) < 3e-6
+
+
+def test_abn_error_behaviour():
+    mod = libs.InPlaceABN(4).to(DEV)
+    with pytest.raises(ValueError):
+        mod(torch.randn(2, 4, 6, 6, device=DEV).transpose(2, 3))          # functions.py:65-67
+    with pytest.raises(TypeError):
+        mod(torch.randn(2, 4, 6, 6, device=DEV).half())
+    with pytest.raises(_lib.SkdLibraryError):
+        libs.InPlaceABN(4)(torch.randn(2, 4, 6, 6))                        # no CPU fallback
+    with pytest.raises(ValueError):
+        libs.InPlaceABN(4, activation="relu6").to(DEV)(torch.randn(2, 4, 3, 3, device=DEV))
+
+
+def _preds(B, cs, ct, hw, gen, classes=19):
+    S = [torch.randn(B, classes, hw, hw, generator=gen), torch.randn(B, classes, hw, hw, generator=gen),
+         torch.randn(B, cs, hw, hw, generator=gen)] + [torch.zeros(1)] * 4
+    T = [torch.randn(B, classes, hw, hw, generator=gen), torch.randn(B, classes, hw, hw, generator=gen),
+         torch.randn(B, ct, hw, hw, generator=gen)] + [torch.zeros(1)] * 4
+    return S, T
+
+
+@pytest.mark.parametrize("hw,scale", [(33, 0.5), (65, 0.5), (65, 0.125), (65, 0.0625), (65, 0.03125)])
+def test_criteria_vs_oracle(hw, scale):
+    gen = torch.Generator().manual_seed(hw)
+    S, T = _preds(2, 128, 512, hw, gen)
+    y = torch.randint(0, 19, (2, 8 * hw - 8, 8 * hw - 8), generator=gen)
+    y[0, :16] = 255
+    So = [t.double().requires_grad_(True) for t in S[:3]] + S[3:]
+    To = [t.double() for t in T]
+    Sg = [t.to(DEV).requires_grad_(True) for t in S[:3]] + S[3:]
+    Tg = [t.to(DEV) for t in T]
+    want = [O.criterion_dsn(So, y), O.criterion_pixel_wise(So, To), O.criterion_pair_wise(So, To, scale, -5)]
+    got = [C.CriterionDSN()(Sg, y.to(DEV)), C.CriterionPixelWise()(Sg, Tg),
+           C.CriterionPairWiseforWholeFeatAfterPool(scale, -5)(Sg, Tg)]
+    for g, w, name in zip(got, want, ("dsn", "pixelwise", "pairwise")):
+        assert g.dim() == 0
+        assert abs(float(g) - float(w)) <= 1e-5 * abs(float(w)), name
+    (0.7 * got[0] + 10.0 * got[1] + 0.5 * got[2]).backward()
+    (0.7 * want[0] + 10.0 * want[1] + 0.5 * want[2]).backward()
+    for i in range(3):
+        assert rel(Sg[i].grad, So[i].grad) < 5e-5, i
+    # the helper surface of utils/utils.py
+    f = torch.randn(2, 16, 3, 3)
+    assert rel(U.similarity(f.to(DEV)), O.similarity(f.double())) < 1e-5
+    assert abs(float(U.sim_dis_compute(f.to(DEV), 2 * f.to(DEV) + 1)) - float(
+        ((O.similarity((2 * f + 1).double()) - O.similarity(f.double())) ** 2).sum() / 81 / 2)) < 1e-7
+
+
+def test_adv_criteria_and_errors():
+    d_s, d_t = [torch.randn(4, 1, 1, 1, device=DEV)], [torch.randn(4, 1, 1, 1, device=DEV)]
+    for kind in ("wgan-gp", "hinge"):
+        assert abs(float(C.CriterionAdv(kind)(d_s, d_t)) - float(O.criterion_adv([d_s[0].cpu()], [d_t[0].cpu()], kind))) < 1e-6
+        assert abs(float(C.CriterionAdvForG(kind)(d_s, d_s)) - float(O.criterion_adv_for_g([d_s[0].cpu()], kind))) < 1e-6
+    with pytest.raises(ValueError):
+        C.CriterionAdv("lsgan")
+    with pytest.raises(ValueError):
+        C.CriterionAdvForG("lsgan")
+    with pytest.raises(AssertionError):
+        C.CriterionPixelWise()([torch.randn(1, 3, 4, 4, device=DEV)], [torch.randn(1, 3, 4, 5, device=DEV)])
+
+
+def test_discriminator_step_vs_oracle():
+    """Three D forwards, then one backward (kd_model.py:153-165), spectral-norm u/v advancing on every
+    forward; the gradient of the earlier forwards is taken with the LATEST u, v as in the reference."""
+    torch.manual_seed(3)
+    D = sagan_models.Discriminator(1, 19, 2, 65, 64).to(DEV).train()
+    with torch.no_grad():
+        D.attn1.gamma.fill_(0.3)
+        D.attn2.gamma.fill_(-0.2)
+    assert sorted(D.state_dict().keys()) == sorted(O.discriminator_init().keys())
+    P32, P64 = cpu_sd(D), cpu_sd(D, torch.float64)
+    gen = torch.Generator().manual_seed(4)
+    pS, pT = [torch.randn(2, 19, 65, 65, generator=gen)], [torch.randn(2, 19, 65, 65, generator=gen)]
+    alpha = torch.rand(2, 1, 1, 1, generator=gen)
+
+    def oracle(P, dt):
+        O.require_grad(P)
+        s, t = [pS[0].to(dt)], [pT[0].to(dt)]
+        loss = 0.1 * O.criterion_adv(O.discriminator_forward(P, s[0]), O.discriminator_forward(P, t[0]))
+        # note the reference's order: D(T) first, then D(S) (kd_model.py:156-157)
+        return loss
+
+    def oracle_step(P, dt):
+        O.require_grad(P)
+        t_out = O.discriminator_forward(P, pT[0].to(dt))
+        s_out = O.discriminator_forward(P, pS[0].to(dt))
+        loss = 0.1 * O.criterion_adv(s_out, t_out) + 0.1 * O.criterion_gp(P, [pS[0].to(dt)], [pT[0].to(dt)], 10.0, alpha.to(dt))
+        keys = O.learnable_keys(P)
+        return loss, dict(zip(keys, torch.autograd.grad(loss, [P[k] for k in keys], allow_unused=True)))
+
+    l64, g64 = oracle_step(P64, torch.float64)
+    l32, g32 = oracle_step(P32, torch.float32)
+    d_t = D(pT[0].to(DEV))
+    d_s = D(pS[0].to(DEV))
+    loss = 0.1 * C.CriterionAdv("wgan-gp")(d_s, d_t) + 0.1 * C.CriterionAdditionalGP(D, 10.0)(
+        [pS[0].to(DEV)], [pT[0].to(DEV)], alpha=alpha.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(l64)) <= 1e-4 * abs(float(l64))
+    named = dict(D.named_parameters())
+    for k, gw in g64.items():
+        got = named[k].grad
+        assert got is not None, k
+        base = float((g32[k].double() - gw).norm())
+        err = float((got.detach().cpu().double() - gw).norm())
+        assert err <= 4 * base + 1e-5 * float(gw.norm()) + 1e-9, (k, err, base, float(gw.norm()))
+    after = D.state_dict()
+    for k in P64:
+        if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+            assert rel(after[k], P64[k]) < 1e-4, k
+    assert not named["l1.0.module.weight_u"].requires_grad and named["l1.0.module.weight_u"].grad is None
+
+
+def test_networks_forward_vs_oracle():
+    torch.manual_seed(5)
+    S = pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [2, 2, 2, 2], 19).to(DEV).train()
+    no_dropout(S)
+    assert sorted(S.state_dict().keys()) == sorted(O.pspnet_init(O.STUDENT, 19).keys())
+    P = cpu_sd(S, torch.float64)
+    x = torch.randn(2, 3, 161, 129) * 57
+    want = O.pspnet_forward(P, x.double(), O.STUDENT, True, dropout_p=0.0)
+    got = S(x.to(DEV))
+    assert len(got) == 7
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and rel(a, b) < 2e-5
+    after = S.state_dict()
+    for k in P:
+        if "running" in k:
+            assert rel(after[k], P[k]) < 1e-5, k
+    T = pspnet_combine.Res_pspnet(pspnet_combine.Bottleneck, [3, 4, 23, 3], 19).to(DEV).eval()
+    assert sorted(T.state_dict().keys()) == sorted(O.pspnet_init(O.TEACHER, 19).keys())
+    with torch.no_grad():
+        want = O.pspnet_forward(cpu_sd(T, torch.float64), x.double(), O.TEACHER, False)
+        got = T(x.to(DEV))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and rel(a, b) < 5e-5
+    with pytest.raises(ValueError):
+        pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [1, 1, 1, 1], 19)
+
+
+@pytest.mark.parametrize("ho", [False, True])
+def test_full_step_vs_oracle(ho):
+    """BASELINE configs 2 / 3 at B=2 (512x512, Pi+Pa[+Ho]); two consecutive steps (momentum, u/v and
+    running statistics carried over)."""
+    torch.manual_seed(1234)
+    B = 2
+    args = default_args(batch_size=B, device=DEV, ho=ho, weight_decay=5e-4, lambda_pa=0.5)
+    model = NetModel(args)
+    no_dropout(model.student)
+    with torch.no_grad():
+        model.D_model.attn1.gamma.fill_(0.25)
+        model.D_model.attn2.gamma.fill_(-0.5)
+    PS32, PT32, PD32 = cpu_sd(model.student), cpu_sd(model.teacher), cpu_sd(model.D_model)
+    PS64, PT64, PD64 = (cpu_sd(m, torch.float64) for m in (model.student, model.teacher, model.D_model))
+    cfg = O.StepConfig(ho=ho, weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
+    st32, st64 = {"G": {}, "D": {}}, {"G": {}, "D": {}}
+    for step in range(2):
+        images, labels = O.synthetic_batch(B, 512, 512, seed=step)
+        alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step))
+        lr_g = model.adjust_learning_rate(args.lr_g, model.G_solver, step)
+        lr_d = model.adjust_learning_rate(args.lr_d, model.D_solver, step)
+        model.gp_alpha = alpha.to(DEV)
+        model.set_input((images, labels, None, None))
+        # gradients of this step, before the optimizers overwrite anything we compare
+        model.forward()
+        model.G_solver.zero_grad()
+        model.student_backward()
+        gS = {k: p.grad.detach().cpu().clone() for k, p in model.student.named_parameters()}
+        model.G_solver.step()
+        if ho:
+            model.discriminator_backward()
+        o64 = O.distillation_step(PS64, PT64, PD64 if ho else None, images.double(), labels, cfg, st64,
+                                  alpha.double(), lr_g=lr_g, lr_d=lr_d)
+        o32 = O.distillation_step(PS32, PT32, PD32 if ho else None, images, labels, cfg, st32, alpha,
+                                  lr_g=lr_g, lr_d=lr_d)
+        for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
+            assert abs(getattr(model, k) - o64[k]) <= 1e-4 * abs(o64[k]), (step, k, getattr(model, k), o64[k])
+        if ho:
+            assert abs(model.D_loss - o64["D_loss"]) <= 1e-3 * abs(o64["D_loss"]), (step, model.D_loss, o64["D_loss"])
+        for a, b in zip(model.preds_S, o64["preds_S"]):
+            assert rel(a, b) < 1e-4
+        worst = 0.0
+        for k, gw in o64["grads_S"].items():
+            base = float((o32["grads_S"][k].double() - gw).norm())
+            err = float((gS[k].double() - gw).norm())
+            assert err <= 4 * base + 1e-5 * float(gw.norm()) + 1e-6, (step, k, err, base, float(gw.norm()))
+            worst = max(worst, err / (float(gw.norm()) + 1e-12))
+        after = model.student.state_dict()
+        for k in PS64:
+            if "running" in k:
+                assert rel(after[k], PS64[k]) < 1e-4, (step, k)
+    # parameters after two optimizer steps track the fp64 oracle as well as the fp32 CPU oracle does
+    after = model.student.state_dict()
+    for k in O.learnable_keys(PS64):
+        base = float((PS32[k].double() - PS64[k]).norm())
+        err = float((after[k].detach().cpu().double() - PS64[k]).norm())
+        assert err <= 4 * base + 1e-6 * float(PS64[k].norm()) + 1e-7, (k, err, base)
