@@ -1,0 +1,102 @@
+"""Pins oracle/step_torch.py against outputs of the reference's own Python committed as
+tests/golden/reference_vectors.pt (generator: tests/golden/make_golden.py).  Runs anywhere -- this is
+the pin that travels to the GPU box, where /root/reference does not exist."""
+import os
+
+import pytest
+import torch
+
+from oracle import step_torch as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.pt")
+dt = torch.float64
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(GOLD, weights_only=False)
+
+
+def check(t, rec, tol=1e-9):
+    f = t.detach().double().reshape(-1)
+    assert list(t.shape) == rec["shape"]
+    got = f[::rec["step"]][:rec["sample"].numel()]
+    assert torch.allclose(got, rec["sample"], rtol=tol * 1e3, atol=tol * float(rec["norm"] + 1e-30)), "sample mismatch"
+    assert abs(float(f.norm()) - float(rec["norm"])) <= tol * 1e2 * float(rec["norm"]) + 1e-30
+    assert abs(float(f.sum()) - float(rec["sum"])) <= tol * 1e4 * (float(rec["norm"]) * f.numel() ** 0.5 + 1e-30)
+
+
+def test_criteria(gold):
+    G = gold["criteria"]
+    g = torch.Generator().manual_seed(G["seed"])
+    S = [torch.randn(2, 19, 33, 33, generator=g, dtype=dt).requires_grad_(True), torch.randn(2, 19, 33, 33, generator=g, dtype=dt).requires_grad_(True),
+         torch.randn(2, 24, 33, 33, generator=g, dtype=dt).requires_grad_(True)] + [None] * 4
+    T = [torch.randn(2, 19, 33, 33, generator=g, dtype=dt), torch.randn(2, 19, 33, 33, generator=g, dtype=dt),
+         torch.randn(2, 40, 33, 33, generator=g, dtype=dt)] + [None] * 4
+    y = torch.randint(0, 19, (2, 129, 129), generator=g)
+    y[0, :9] = 255
+    crit = {"dsn": O.criterion_dsn(S, y), "pixelwise": O.criterion_pixel_wise(S, T)}
+    for scale in (0.5, 0.25, 0.1, 0.04):
+        crit["pairwise_%g" % scale] = O.criterion_pair_wise(S, T, scale, -5)
+    for k, want in G["losses"].items():
+        tol = 2e-6 if k.startswith("pairwise") else 1e-11      # the reference computes Pa in fp32 (utils.py:174)
+        assert abs(float(crit[k]) - float(want)) <= tol * abs(float(want)), k
+    (crit["dsn"] + 10 * crit["pixelwise"] + 0.5 * crit["pairwise_0.5"] + 2.0 * crit["pairwise_0.1"]).backward()
+    for i in range(3):
+        check(S[i].grad, G["grads"][i], 1e-6 if i == 2 else 1e-10)
+
+
+@pytest.mark.parametrize("name,arch", [("student", O.STUDENT), ("teacher", O.TEACHER)])
+def test_networks(gold, name, arch):
+    G = gold[name]
+    P = O.pspnet_init(arch, 19, seed=G["init_seed"], dtype=dt)
+    x = torch.randn(2, 3, *G["hw"], generator=torch.Generator().manual_seed(G["input_seed"]), dtype=dt) * 57
+    if name == "student":
+        for o, rec in zip(O.pspnet_forward(P, x, arch, True, dropout_p=0.0), G["train"]):
+            check(o, rec)
+        for k, rec in G["running"].items():
+            check(P[k], rec)
+    with torch.no_grad():
+        for o, rec in zip(O.pspnet_forward(P, x, arch, False), G["eval"]):
+            check(o, rec)
+
+
+def test_discriminator_step(gold):
+    G = gold["discriminator"]
+    P = O.discriminator_init(seed=G["init_seed"], dtype=dt)
+    P["attn1.gamma"].fill_(0.3)
+    P["attn2.gamma"].fill_(-0.2)
+    g = torch.Generator().manual_seed(G["input_seed"])
+    pS, pT = [torch.randn(2, 19, 65, 65, generator=g, dtype=dt)], [torch.randn(2, 19, 65, 65, generator=g, dtype=dt)]
+    alpha = torch.rand(2, 1, 1, 1, generator=g, dtype=dt)
+    O.require_grad(P)
+    dT, dS = O.discriminator_forward(P, pT[0]), O.discriminator_forward(P, pS[0])
+    assert torch.allclose(dT[0], G["d_out_T"], rtol=1e-9) and torch.allclose(dS[0], G["d_out_S"], rtol=1e-9)
+    check(dT[1], G["attn1_T"])
+    adv = 0.1 * O.criterion_adv(dS, dT)
+    gp = O.criterion_gp(P, pS, pT, 10.0, alpha)
+    assert abs(float(adv) - float(G["adv"])) < 1e-10 * abs(float(G["adv"])) and abs(float(gp) - float(G["gp"])) < 1e-9 * abs(float(G["gp"]))
+    assert abs(float(O.criterion_adv(dS, dT, "hinge")) - float(G["hinge"])) < 1e-10
+    keys = O.learnable_keys(P)
+    grads = dict(zip(keys, torch.autograd.grad(adv + 0.1 * gp, [P[k] for k in keys], allow_unused=True)))
+    assert sorted(grads) == sorted(G["grads"])
+    for k, rec in G["grads"].items():
+        check(grads[k], rec, 1e-8)
+    for k, want in G["uv_after"].items():
+        assert torch.allclose(P[k].detach(), want, rtol=1e-9, atol=1e-12), k
+
+
+def test_step_config1_pa(gold):
+    G = gold["step_config1_pa"]
+    s1, s2, s3 = G["seeds"]
+    PS, PT = O.pspnet_init(O.STUDENT, 19, seed=s1, dtype=dt), O.pspnet_init(O.TEACHER, 19, seed=s2, dtype=dt)
+    x, y = O.synthetic_batch(2, 256, 256, seed=s3, dtype=dt)
+    out = O.distillation_step(PS, PT, None, x, y, O.StepConfig(pi=True, pa=True, ho=False, lambda_pa=0.5, weight_decay=5e-4, dropout_p=0.0))
+    assert abs(out["mc_G_loss"] - float(G["mc"])) < 1e-10 * abs(float(G["mc"]))
+    assert abs(out["pi_G_loss"] - float(G["pi"])) < 1e-10 * abs(float(G["pi"]))
+    assert abs(out["pa_G_loss"] - float(G["pa"])) < 2e-6 * abs(float(G["pa"]))
+    for k, rec in G["grads"].items():
+        if float(rec["norm"]) > 1e-12:
+            check(out["grads_S"][k], rec, 2e-6)
+    for k, rec in G["after"].items():
+        check(PS[k], rec, 1e-7)
