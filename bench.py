@@ -45,7 +45,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--pairwise-sweep", action="store_true", help="also time the Pa kernels at large M")
     return ap.parse_args()
 
 
@@ -75,6 +74,42 @@ def cpu_baseline(seconds, size):
     return {"value": round(B * n / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d timed steps (+1 warm-up) of the full Pi+Pa+Ho step at batch %d, %dx%d, fp32, torch CPU "
                       "(oracle/step_torch.py); host CPU: %s" % (n, B, size, size, model)}
+
+
+def pairwise_sweep(dev):
+    """Pa Gram kernel (gram_loss_kernel, fp32 MFMA) at B=8, C_S=128, C_T=512 over the pool scales of
+    SURVEY.md 8d: M = 9 (reference default) ... 4225 (pool-scale -> 1/65).  FLOPs = 2*B*M^2*(Cs+Ct)
+    (full-matrix convention), timed with HIP events around back-to-back launches on the launch stream."""
+    import torch
+    from structure_knowledge_distillation_amd import _lib
+    lib = _lib.load()
+    B, Cs, Ct = 8, 128, 512
+    out = {}
+    for M in (9, 81, 289, 1089, 4225):
+        ldm = lib.skd_pairwise_ldm(M)
+        ps, pt = torch.randn(B, Cs, M, device=dev), torch.randn(B, Ct, M, device=dev)
+        fs, ft = torch.empty(B, Cs, ldm, device=dev), torch.empty(B, Ct, ldm, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        lib.skd_channel_l2_normalise(B, Cs, M, ps.data_ptr(), fs.data_ptr(), ldm, None, 0, None, st)
+        lib.skd_channel_l2_normalise(B, Ct, M, pt.data_ptr(), ft.data_ptr(), ldm, None, 0, None, st)
+        G = torch.empty(B, ldm, ldm, device=dev)
+        loss = torch.empty(1, device=dev)
+        ws = torch.empty(max(1, lib.skd_pairwise_workspace_floats(B, M)), device=dev)
+        call = lambda: lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, fs.data_ptr(), ft.data_ptr(), G.data_ptr(),
+                                                  loss.data_ptr(), ws.data_ptr(), st)
+        for _ in range(3):
+            call()
+        reps = 20 if M <= 1089 else 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tf = 2.0 * B * M * M * (Cs + Ct) / (ms * 1e-3) / 1e12
+        out["M=%d" % M] = {"us": round(ms * 1e3, 1), "TFLOPs": round(tf, 2), "frac_fp32_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    return out
 
 
 def summarise(recs, bytes_per_elem):
@@ -177,6 +212,8 @@ def main():
             "skd_abn_forward_train (stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
             "skd_abn_backward (reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),
         }
+    if world == 1:
+        line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.size)
     print(json.dumps(line), flush=True)

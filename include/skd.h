@@ -32,6 +32,9 @@ typedef void *skd_stream_t; /* hipStream_t */
 #define SKD_ACT_NONE 0
 #define SKD_ACT_LEAKY_RELU 1
 #define SKD_ACT_ELU 2
+/* forward-only (inference): the nn.ReLU that follows BatchNorm2d in networks/pspnet_combine.py:36,68,72,
+ * fused into the normalise pass.  Not invertible from the output, so the backward entries reject it. */
+#define SKD_ACT_RELU 3
 
 /* library / build identification: returns e.g. 950 for gfx950 */
 int skd_abi_version(void);
@@ -83,6 +86,12 @@ int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, 
 int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float *var,
                   const float *weight, const float *bias, float eps, int activation, float slope,
                   skd_stream_t stream);
+/* x <- act(bn(x) + residual): the tail of a residual block, `out = bn(conv(..)); out = out + residual;
+ * relu(out)` (networks/pspnet_combine.py:37-43, 78-82), in ONE in-place pass (12 B/element instead of
+ * 8 + 12 + 8).  mean/var as for skd_abn_apply; residual has the shape of x. */
+int skd_abn_apply_residual(int N, int C, int S, float *x, const float *residual, const float *mean,
+                           const float *var, const float *weight, const float *bias, float eps,
+                           int activation, float slope, skd_stream_t stream);
 /* running-stat update with an explicit sample count n (functions.py:209) */
 int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
                            const float *var, float momentum, double n, skd_stream_t stream);

@@ -26,6 +26,7 @@
 #define ACT_NONE 0
 #define ACT_LEAKY 1
 #define ACT_ELU 2
+#define ACT_RELU 3 /* nn.ReLU applied to the BatchNorm2d output, networks/pspnet_combine.py:36,68,72 */
 
 typedef void *stream_t;
 
@@ -196,11 +197,25 @@ int skd_abn_update_running(int C, float *rm, float *rv, const float *mean, const
 static void act_forward(int act, int64_t n, float *x, float slope) { /* functions.py:45-51 */
   if (act == ACT_LEAKY) skd_leaky_relu(n, x, slope, 0);
   else if (act == ACT_ELU) skd_elu(n, x, 0);
+  else if (act == ACT_RELU)
+    for (int64_t i = 0; i < n; ++i)
+      if (x[i] < 0.f) x[i] = 0.f;
 }
 
 int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float *var,
                   const float *weight, const float *bias, float eps, int act, float slope, stream_t st) {
   if (!skd_bn_forward(N, C, S, x, mean, var, weight, bias, x, x, eps, st)) return 0;
+  act_forward(act, (int64_t)N * C * S, x, slope);
+  return 1;
+}
+
+/* out = bn(conv); out = out + residual; relu(out)   (networks/pspnet_combine.py:37-43, 78-82) */
+int skd_abn_apply_residual(int N, int C, int S, float *x, const float *residual, const float *mean,
+                           const float *var, const float *weight, const float *bias, float eps, int act,
+                           float slope, stream_t st) {
+  if (!residual) return 0;
+  if (!skd_bn_forward(N, C, S, x, mean, var, weight, bias, x, x, eps, st)) return 0;
+  for (int64_t i = 0; i < (int64_t)N * C * S; ++i) x[i] = x[i] + residual[i];
   act_forward(act, (int64_t)N * C * S, x, slope);
   return 1;
 }
@@ -237,7 +252,7 @@ int skd_abn_backward_reduce(int N, int C, int S, const float *z, const float *dz
                             float slope, float *ws, stream_t st) {
   (void)ws;
   float *zc, *dzc;
-  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  if (N <= 0 || C <= 0 || S <= 0 || act == ACT_RELU) return 0;
   if (!undo_act(act, (int64_t)N * C * S, z, dz, slope, &zc, &dzc)) return 0;
   const int r = skd_bn_edz_eydz(N, C, S, zc, dzc, weight, bias, edz, eydz, eps, st);
   free(zc);
@@ -250,7 +265,7 @@ int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, co
                         float *dx, float *dweight, float *dbias, float eps, int act, float slope,
                         stream_t st) {
   float *zc, *dzc;
-  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  if (N <= 0 || C <= 0 || S <= 0 || act == ACT_RELU) return 0;
   if (!undo_act(act, (int64_t)N * C * S, z, dz, slope, &zc, &dzc)) return 0;
   const int r = skd_bn_backward(N, C, S, dzc, zc, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, st);
   free(zc);

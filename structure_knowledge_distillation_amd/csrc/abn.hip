@@ -98,6 +98,7 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, float slope) {
   if (ACT == SKD_ACT_LEAKY_RELU) return z < 0.f ? z * slope : z;        // bn.cu:302-315
   if (ACT == SKD_ACT_ELU) return z < 0.f ? expf(z) - 1.f : z;           // bn.cu:333-346
+  if (ACT == SKD_ACT_RELU) return z < 0.f ? 0.f : z;                    // nn.ReLU after BatchNorm2d, pspnet_combine.py:36,68,72
   return z;
 }
 // undo the activation on (z, dz) in registers: functions.py:54-62 / bn.cu:317-331,348-377
@@ -202,6 +203,13 @@ __global__ void abn_update_running_kernel(int C, float *running_mean, float *run
   running_var[c] = running_var[c] * (1.f - momentum) + momentum * var[c] * nf / (nf - 1.f);
 }
 
+struct F4x2 {
+  float4 a, b;
+};
+struct F1x2 {
+  float a, b;
+};
+
 // ---------------------------------------------------------------------------------------------
 // K2': normalise + affine + activation.  Writes z (and y when y != z, the legacy two-output form).
 // ---------------------------------------------------------------------------------------------
@@ -235,6 +243,30 @@ struct ApplyOp {
   }
 };
 
+// z = act(bn(x) + r): the tail of a residual block (pspnet_combine.py:41-43 / 80-82) in one pass.
+template <int ACT>
+struct ApplyResOp {
+  const float *xin, *rin;
+  float *zout;
+  float mean, inv_std, gamma, beta, slope;
+  __device__ __forceinline__ float one(float v, float r) const {
+    return act_fwd<ACT>(((v - mean) * inv_std) * gamma + beta + r, slope);
+  }
+  __device__ __forceinline__ F1x2 ld1(int i) const { return F1x2{xin[i], rin[i]}; }
+  __device__ __forceinline__ void use1(int i, F1x2 v) const { zout[i] = one(v.a, v.b); }
+  __device__ __forceinline__ F4x2 ld4(int i) const {
+    return F4x2{*reinterpret_cast<const float4 *>(xin + i), *reinterpret_cast<const float4 *>(rin + i)};
+  }
+  __device__ __forceinline__ void use4(int i, F4x2 v) const {
+    float4 z;
+    z.x = one(v.a.x, v.b.x);
+    z.y = one(v.a.y, v.b.y);
+    z.z = one(v.a.z, v.b.z);
+    z.w = one(v.a.w, v.b.w);
+    *reinterpret_cast<float4 *>(zout + i) = z;
+  }
+};
+
 template <int ACT, bool WRITE_Y>
 __global__ __launch_bounds__(kThreads) void abn_apply_kernel(
     const float *x, const float *__restrict__ mean, const float *__restrict__ var,
@@ -259,16 +291,30 @@ __global__ __launch_bounds__(kThreads) void abn_apply_kernel(
   }
 }
 
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void abn_apply_residual_kernel(
+    const float *x, const float *res, const float *__restrict__ mean, const float *__restrict__ var,
+    const float *__restrict__ weight, const float *__restrict__ bias, float *z, float eps, float slope,
+    int N, int C, int S, Plan pl) {
+  const Item it = decode(blockIdx.x, N, C, S, pl);
+  ApplyResOp<ACT> op;
+  op.mean = mean[it.c];
+  op.inv_std = inv_std_of(var[it.c], eps);
+  op.gamma = gamma_of(weight, it.c, eps);
+  op.beta = beta_of(bias, it.c);
+  op.slope = slope;
+  for (int n = it.n0; n < it.n1; ++n) {
+    const int64_t off = ((int64_t)n * C + it.c) * S + it.start;
+    op.xin = x + off;
+    op.rin = res + off;
+    op.zout = z + off;
+    stream_run(reinterpret_cast<uintptr_t>(op.xin), it.len, op);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3': edz / eydz partial sums with the activation undone in registers.
 // ---------------------------------------------------------------------------------------------
-struct F4x2 {
-  float4 a, b;
-};
-struct F1x2 {
-  float a, b;
-};
-
 template <int ACT>
 struct GradReduceOp {
   const float *z, *dz;
@@ -475,6 +521,9 @@ static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x
     case SKD_ACT_ELU:
       abn_apply_kernel<SKD_ACT_ELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
       break;
+    case SKD_ACT_RELU:
+      abn_apply_kernel<SKD_ACT_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      break;
     default:
       abn_apply_kernel<SKD_ACT_NONE, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
   }
@@ -523,6 +572,30 @@ int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float 
   return ok();
 }
 
+int skd_abn_apply_residual(int N, int C, int S, float *x, const float *residual, const float *mean,
+                           const float *var, const float *weight, const float *bias, float eps,
+                           int activation, float slope, skd_stream_t stream) {
+  if (!valid_dims(N, C, S) || !x || !residual || !mean || !var) return 0;
+  if (!same_phase(x, residual)) return 0;
+  const Plan pl = make_plan(N, C, S);
+  const dim3 grid((unsigned)pl.items), block(kThreads);
+  hipStream_t st = as_stream(stream);
+  switch (activation) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_apply_residual_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      break;
+    case SKD_ACT_RELU:
+      abn_apply_residual_kernel<SKD_ACT_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      break;
+    case SKD_ACT_NONE:
+      abn_apply_residual_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      break;
+    default:
+      return 0;
+  }
+  return ok();
+}
+
 int skd_abn_forward_train(int N, int C, int S, float *x, const float *weight, const float *bias,
                           float *running_mean, float *running_var, float *mean, float *var,
                           float momentum, float eps, int activation, float slope, float *workspace,
@@ -542,6 +615,7 @@ int skd_abn_backward_reduce(int N, int C, int S, const float *z, const float *dz
                             const float *bias, float *edz, float *eydz, float eps, int activation,
                             float slope, float *workspace, skd_stream_t stream) {
   if (!valid_dims(N, C, S) || !z || !dz || !edz || !eydz || !workspace) return 0;
+  if (activation == SKD_ACT_RELU) return 0;  // not invertible from the output: forward-only activation
   if (!same_phase(z, dz)) return 0;
   const Plan pl = make_plan(N, C, S);
   hipStream_t st = as_stream(stream);
@@ -566,6 +640,7 @@ int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, co
                         float *dx, float *dweight, float *dbias, float eps, int activation,
                         float slope, skd_stream_t stream) {
   if (!valid_dims(N, C, S) || !z || !dz || !var || !edz || !eydz) return 0;
+  if (activation == SKD_ACT_RELU) return 0;
   if (dweight && !weight) return 0;
   if (!same_phase(z, dz) || (dx && !same_phase(z, dx))) return 0;
   const Plan pl = make_plan(N, C, S);

@@ -27,7 +27,9 @@ from .. import _lib
 ACT_LEAKY_RELU = "leaky_relu"
 ACT_ELU = "elu"
 ACT_NONE = "none"
+ACT_RELU = "relu"          # forward-only (inference) fusion of the nn.ReLU that follows a BatchNorm2d
 _ACT_CODE = {ACT_NONE: 0, ACT_LEAKY_RELU: 1, ACT_ELU: 2}
+_EVAL_ACT_CODE = dict(_ACT_CODE, **{ACT_RELU: 3})
 
 
 def _act_code(name):
@@ -181,6 +183,44 @@ class _InPlaceABN(autograd.Function):
                 _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight),
                 _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, st), "skd_abn_backward_dx")
         return dx, dweight, dbias, None, None, None, None, None, None, None, None
+
+
+def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activation=ACT_RELU, slope=0.01,
+                   residual=None):
+    """Inference-only InPlace-ABN: ``x <- act(bn_running(x) [+ residual])`` in ONE in-place pass.
+
+    Fuses what networks/pspnet_combine.py runs as separate ops around an eval-mode BatchNorm2d
+    (= InPlaceABNSync(activation='none'), :12): the following nn.ReLU (:36, :68, :72) and, at the
+    tail of a residual block, ``out + residual`` then ReLU (:41-43, :80-82).  No autograd graph is
+    recorded: callers use it under ``torch.no_grad()`` with the module in eval mode (the frozen
+    teacher, kd_model.py:121-122)."""
+    if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+        raise RuntimeError("abn_eval_fused is inference-only; use inplace_abn for differentiable calls")
+    _lib.require_device(x, weight, bias, running_mean, running_var, residual)
+    if x.dtype != torch.float32:
+        raise TypeError("InPlaceABN kernels are fp32 only (got %s)" % x.dtype)
+    try:
+        act = _EVAL_ACT_CODE[activation]
+    except KeyError:
+        raise ValueError("unknown activation %r" % (activation,))
+    _check_contiguous(x, weight, bias, running_mean, running_var)
+    if x.numel() == 0:
+        return x
+    n, c, s = _dims(x)
+    lib, st = _lib.get(), _lib.stream_of(x)
+    if residual is None:
+        _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                     _lib.ptr(weight), _lib.ptr(bias), float(eps), act, float(slope), st),
+                   "skd_abn_apply")
+    else:
+        if residual.shape != x.shape:
+            raise ValueError("residual shape %s != input shape %s" % (tuple(residual.shape), tuple(x.shape)))
+        if not residual.is_contiguous() or not _same_phase(x, residual):
+            residual = residual.clone(memory_format=torch.contiguous_format)
+        _lib.check(lib.skd_abn_apply_residual(n, c, s, x.data_ptr(), residual.data_ptr(), running_mean.data_ptr(),
+                                              running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), float(eps),
+                                              act, float(slope), st), "skd_abn_apply_residual")
+    return x
 
 
 def inplace_abn(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-05,

@@ -6,7 +6,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .inplace_abn import inplace_abn, inplace_abn_sync
+from .inplace_abn import abn_eval_fused, inplace_abn, inplace_abn_sync
 
 _sync_group = {"group": None, "explicit": False}
 
@@ -56,6 +56,11 @@ class _ABNBase(nn.Module):
             if self.affine:
                 self.weight.fill_(1)
                 self.bias.zero_()
+
+    def fused_eval(self, x, activation="relu", residual=None):
+        """Inference-only: ``x <- activation(bn(x) [+ residual])`` with the running statistics, one pass."""
+        return abn_eval_fused(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                              activation, self.slope, residual)
 
     def extra_repr(self):
         rep = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"

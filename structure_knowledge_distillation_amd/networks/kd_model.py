@@ -138,7 +138,9 @@ class NetModel():
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
 
-        torch.backends.cudnn.benchmark = True        # MIOpen find mode
+        # MIOpen find mode is opt-in: this ROCm image ships no gfx950 find/kernel database, so "find"
+        # JIT-compiles every candidate solver for every convolution shape on a fresh machine.
+        torch.backends.cudnn.benchmark = os.environ.get("SKD_MIOPEN_FIND", "0") == "1"
         snap = getattr(args, "snapshot_dir", None)
         if snap and not os.path.exists(snap):
             os.makedirs(snap)

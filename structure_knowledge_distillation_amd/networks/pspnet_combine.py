@@ -18,6 +18,13 @@ affine_par = True
 BatchNorm2d = functools.partial(InPlaceABNSync, activation="none")   # pspnet_combine.py:12
 
 
+def _inference(module):
+    """True when no graph is being recorded and the module normalises with its running statistics:
+    then BN -> ReLU and BN -> (+ residual) -> ReLU collapse into single in-place passes of the ABN kernel
+    (libs.abn_eval_fused).  This is the frozen teacher's whole forward (kd_model.py:121-122)."""
+    return (not module.training) and (not torch.is_grad_enabled())
+
+
 def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
@@ -37,6 +44,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if _inference(self):
+            out = self.bn1.fused_eval(self.conv1(x), "relu")
+            residual = self.downsample(x) if self.downsample is not None else x
+            return self.bn2.fused_eval(self.conv2(out), "relu", residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = self.downsample(x) if self.downsample is not None else x
@@ -62,6 +73,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _inference(self):
+            out = self.bn1.fused_eval(self.conv1(x), "relu")
+            out = self.bn2.fused_eval(self.conv2(out), "relu")
+            residual = self.downsample(x) if self.downsample is not None else x
+            return self.bn3.fused_eval(self.conv3(out), "relu", residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -141,9 +157,14 @@ class ResNet(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = self.relu1(self.bn1(self.conv1(x)))
-        x = self.relu2(self.bn2(self.conv2(x)))
-        x = self.relu3(self.bn3(self.conv3(x)))
+        if _inference(self):
+            x = self.bn1.fused_eval(self.conv1(x), "relu")
+            x = self.bn2.fused_eval(self.conv2(x), "relu")
+            x = self.bn3.fused_eval(self.conv3(x), "relu")
+        else:
+            x = self.relu1(self.bn1(self.conv1(x)))
+            x = self.relu2(self.bn2(self.conv2(x)))
+            x = self.relu3(self.bn3(self.conv3(x)))
         x = self.maxpool(x)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)

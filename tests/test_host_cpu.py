@@ -100,6 +100,29 @@ def test_spectral_norm_wrapper_state_and_quirk():
     assert rel(conv.weight_bar.grad, Pd["weight_bar"].grad) < 1e-4
 
 
+def test_inference_fusion_equals_unfused_graph():
+    """Under no_grad + eval the networks take the fused BN->ReLU / BN->(+res)->ReLU passes; with grad enabled
+    they run the reference's op sequence.  Same numbers either way (teacher = Bottleneck, student = BasicBlock)."""
+    from structure_knowledge_distillation_amd.networks import pspnet_combine as PC
+    torch.manual_seed(7)
+    for block, layers in ((PC.Bottleneck, [3, 4, 23, 3]), (PC.BasicBlock, [2, 2, 2, 2])):
+        net = PC.Res_pspnet(block, layers, 19).eval()
+        for m in net.modules():     # non-trivial running statistics / affine parameters
+            if isinstance(m, PC.InPlaceABNSync):
+                with torch.no_grad():
+                    m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+                    m.weight.normal_(0, 1); m.bias.normal_(0, 0.2)
+        x = torch.randn(1, 3, 65, 49) * 57
+        with torch.no_grad():
+            fused = net(x)
+        plain = net(x.clone().requires_grad_(True))
+        for a, b in zip(fused, plain):
+            assert rel(a, b) < 1e-5
+    from structure_knowledge_distillation_amd import libs
+    with pytest.raises(RuntimeError):
+        libs.abn_eval_fused(torch.randn(1, 2, 3, 3, requires_grad=True) * 1.0, None, None, torch.zeros(2), torch.ones(2))
+
+
 def _tiny_args(**kw):
     from structure_knowledge_distillation_amd.networks.kd_model import default_args
     return default_args(device=torch.device("cpu"), weight_decay=5e-4, lambda_pa=0.5, **kw)

@@ -151,13 +151,6 @@ def test_discriminator_step_vs_oracle():
     pS, pT = [torch.randn(2, 19, 65, 65, generator=gen)], [torch.randn(2, 19, 65, 65, generator=gen)]
     alpha = torch.rand(2, 1, 1, 1, generator=gen)
 
-    def oracle(P, dt):
-        O.require_grad(P)
-        s, t = [pS[0].to(dt)], [pT[0].to(dt)]
-        loss = 0.1 * O.criterion_adv(O.discriminator_forward(P, s[0]), O.discriminator_forward(P, t[0]))
-        # note the reference's order: D(T) first, then D(S) (kd_model.py:156-157)
-        return loss
-
     def oracle_step(P, dt):
         O.require_grad(P)
         t_out = O.discriminator_forward(P, pT[0].to(dt))

@@ -1,0 +1,67 @@
+"""GPU tool (not product code): populate the in-tree MIOpen user find-db + kernel cache
+(structure_knowledge_distillation_amd/miopen_db/) for the convolution shapes of the distillation step.
+
+This ROCm image ships no gfx950 find-db / kernel-db, so on a fresh machine MIOpen either JIT-compiles
+every solver it tries (find mode: minutes per shape) or falls back to untuned heuristics (immediate
+mode: 58-70 TF/s on the dilated 3x3 convolutions instead of 106-124).  Running MIOpen's own tuner ONCE
+here and committing its (small, text + sqlite) output gives every later process find-quality kernels
+with no JIT: immediate mode consults the user find-db first.
+
+    python tools/miopen_tune.py <out_dir> [phase ...]
+"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PHASES = {  # name: (batch, find, what, timeout_s)
+    "teacher8": (8, True, "teacher", 500),
+    "student8": (8, True, "student", 900),
+    "full8": (8, True, "full", 400),
+    "full2": (2, False, "full", 400),
+}
+
+
+def child(phase):
+    sys.path.insert(0, ROOT)
+    batch, find, what, _ = PHASES[phase]
+    os.environ["SKD_MIOPEN_FIND"] = "1" if find else "0"
+    import torch
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    t0 = time.time()
+    args = default_args(batch_size=batch, device=dev, ho=(what == "full"), weight_decay=5e-4, lambda_pa=0.5)
+    model = NetModel(args)
+    x = torch.randn(batch, 3, 512, 512, device=dev) * 57
+    y = torch.randint(0, 19, (batch, 512, 512), device=dev)
+    model.set_input((x, y, None, None))
+    if what == "teacher":
+        with torch.no_grad():
+            model.parallel_teacher.eval()(model.images)
+    else:
+        for _ in range(2):
+            model.optimize_parameters()
+    torch.cuda.synchronize()
+    print("phase %s done in %.1f s" % (phase, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "child":
+        child(sys.argv[2])
+        sys.exit(0)
+    out = os.path.abspath(sys.argv[1])
+    phases = sys.argv[2:] or list(PHASES)
+    os.makedirs(os.path.join(out, "cache"), exist_ok=True)
+    env = dict(os.environ, MIOPEN_USER_DB_PATH=out, MIOPEN_CUSTOM_CACHE_DIR=os.path.join(out, "cache"))
+    for ph in phases:
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, __file__, "child", ph], env=env, timeout=PHASES[ph][3],
+                               capture_output=True, text=True)
+            msg = (r.stdout.strip().splitlines() or ["(no output)"])[-1] + (" | rc=%d %s" % (r.returncode, r.stderr[-400:]) if r.returncode else "")
+        except subprocess.TimeoutExpired:
+            msg = "phase %s TIMEOUT after %.0f s" % (ph, time.time() - t0)
+        print(msg, flush=True)
+        os.system("du -sh %s | tail -1" % out)
