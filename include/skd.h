@@ -177,6 +177,46 @@ int skd_spectral_norm_backward(int h, int w, const float *w_bar, const float *u,
                                float *workspace, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * 7. CriterionDSN, utils/criterion.py:179-188, fused:
+ *      loss = CE(up(main), target) + aux_weight * CE(up(dsn), target)
+ *    up = bilinear upsample (h,w) -> (H,W), align_corners=True (F.upsample, criterion.py:182,185);
+ *    CE = torch.nn.CrossEntropyLoss(ignore_index) with mean reduction over the non-ignored pixels
+ *    (criterion.py:175).  logits (B, C, h, w) fp32, target (B, H, W) int64; a target outside [0, C) that
+ *    is not ignore_index is skipped like ignore_index (PyTorch raises a device-side assert there).
+ *    One call produces the loss and dloss/dlogits for both heads (grad pointers may be NULL;
+ *    logits_dsn may be NULL -> single CE).  C <= 64.  No (B, C, H, W) tensor is ever materialised.
+ *    workspace: skd_ce_dsn_workspace_floats(...) floats.
+ * ---------------------------------------------------------------------------------- */
+int64_t skd_ce_dsn_workspace_floats(int B, int C, int h, int w, int H, int W);
+int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *logits_main,
+                       const float *logits_dsn, const int64_t *target, int ignore_index,
+                       float aux_weight, float *loss /* [1] */, float *grad_main /* (B,C,h,w) or NULL */,
+                       float *grad_dsn /* (B,C,h,w) or NULL */, float *workspace, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 8. Pyramid pooling module data movement, PSPModule, networks/pspnet_combine.py:86-112:
+ *      pool    : AdaptiveAvgPool2d(s) for every level s in `sizes` (host array, <= 4 levels, (1,2,3,6) in
+ *                the reference) from ONE read of the (planes, H, W) feature map.  Output layout: level k
+ *                occupies floats [planes * sum_{j<k} s_j^2, ...) as (planes, s_k * s_k); total
+ *                skd_ppm_pooled_floats().  Bins: [floor(i*H/s), ceil((i+1)*H/s)) (adaptive_avg_pool2d).
+ *      pool_backward : dx (planes, H, W) <- sum over levels / bins of gpooled[bin] / area(bin)  (overwrites)
+ *      concat  : cat (B, L*Cout + Cfeat, H, W) <- [bilinear(prior_k, (H,W), align_corners=True) for k] + [feats]
+ *                (F.upsample + torch.cat of pspnet_combine.py:110-111 without materialising the up-sampled
+ *                priors).  priors: host array of L device pointers, prior_k is (B, Cout, s_k, s_k).
+ *      concat_backward : gpriors[k] (B, Cout, s_k, s_k) <- pull-back of gcat[:, k*Cout:(k+1)*Cout]
+ *                (the gradient of feats is the channel slice gcat[:, L*Cout:] itself).
+ * ---------------------------------------------------------------------------------- */
+int64_t skd_ppm_pooled_floats(int planes, int nsizes, const int *sizes);
+int skd_ppm_pool(int planes, int H, int W, int nsizes, const int *sizes, const float *x, float *pooled,
+                 skd_stream_t stream);
+int skd_ppm_pool_backward(int planes, int H, int W, int nsizes, const int *sizes, const float *gpooled,
+                          float *dx, skd_stream_t stream);
+int skd_ppm_concat(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                   const float *const *priors, const float *feats, float *cat, skd_stream_t stream);
+int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                            const float *gcat, float *const *gpriors, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * 6. Deterministic two-stage sum (used by the loss kernels; exposed for tests).
  * ---------------------------------------------------------------------------------- */
 int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, float *workspace,

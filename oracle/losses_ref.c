@@ -232,3 +232,192 @@ int skd_spectral_norm_backward(int h, int w, const float *wb, const float *u, co
       gwb[(int64_t)i * w + j] = (float)((double)gw[(int64_t)i * w + j] / s - coef * (double)u[i] * (double)v[j]);
   return 1;
 }
+
+/* ---- CriterionDSN: bilinear upsample (align_corners) + cross-entropy(ignore_index), utils/criterion.py:179-188 ---- */
+int64_t skd_ce_dsn_workspace_floats(int B, int C, int h, int w, int H, int W) {
+  (void)B; (void)C; (void)h; (void)w; (void)H; (void)W;
+  return 8;
+}
+
+/* PyTorch upsample_bilinear2d, align_corners=True: scale = (in-1)/(out-1) in float; src = scale*dst;
+ * i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1 */
+static void tap_of(int dst, float scale, int in, int *i0, int *i1, float *l0, float *l1) {
+  const float src = scale * (float)dst;
+  *i0 = (int)src;
+  if (*i0 > in - 1) *i0 = in - 1;
+  *i1 = *i0 + (*i0 < in - 1 ? 1 : 0);
+  *l1 = src - (float)*i0;
+  *l0 = 1.f - *l1;
+}
+
+int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lm, const float *ld,
+                       const int64_t *target, int ignore_index, float aux_weight, float *loss,
+                       float *gm, float *gd, float *ws, stream_t st) {
+  (void)ws; (void)st;
+  if (B <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !lm || !target || !loss) return 0;
+  if (gd && !ld) return 0;
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const int heads = ld ? 2 : 1, hw = h * w;
+  double *acc = (double *)calloc((size_t)heads * B * C * hw, sizeof(double));
+  double *v = (double *)malloc(sizeof(double) * (size_t)C);
+  if (!acc || !v) return 0;
+  double sum[2] = {0.0, 0.0}, cnt = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int Y = 0; Y < H; ++Y) {
+      int y0, y1; float ly0, ly1;
+      tap_of(Y, sy, h, &y0, &y1, &ly0, &ly1);
+      for (int X = 0; X < W; ++X) {
+        const int64_t t = target[((int64_t)b * H + Y) * W + X];
+        if (t == (int64_t)ignore_index || t < 0 || t >= C) continue;
+        int x0, x1; float lx0, lx1;
+        tap_of(X, sx, w, &x0, &x1, &lx0, &lx1);
+        cnt += 1.0;
+        const double w00 = (double)ly0 * lx0, w01 = (double)ly0 * lx1, w10 = (double)ly1 * lx0, w11 = (double)ly1 * lx1;
+        for (int head = 0; head < heads; ++head) {
+          const float *p = (head == 0 ? lm : ld) + (int64_t)b * C * hw;
+          double mx = -INFINITY, z = 0.0;
+          for (int c = 0; c < C; ++c) {
+            const float *q = p + (int64_t)c * hw;
+            v[c] = w00 * q[y0 * w + x0] + w01 * q[y0 * w + x1] + w10 * q[y1 * w + x0] + w11 * q[y1 * w + x1];
+            if (v[c] > mx) mx = v[c];
+          }
+          for (int c = 0; c < C; ++c) z += exp(v[c] - mx);
+          sum[head] += log(z) - (v[t] - mx);                      /* -log_softmax(up)[target] */
+          double *a = acc + ((int64_t)head * B + b) * C * hw;
+          for (int c = 0; c < C; ++c) {
+            const double g = exp(v[c] - mx) / z - (c == (int)t ? 1.0 : 0.0);
+            a[(int64_t)c * hw + y0 * w + x0] += w00 * g;
+            a[(int64_t)c * hw + y0 * w + x1] += w01 * g;
+            a[(int64_t)c * hw + y1 * w + x0] += w10 * g;
+            a[(int64_t)c * hw + y1 * w + x1] += w11 * g;
+          }
+        }
+      }
+    }
+  loss[0] = (float)(sum[0] / cnt + (ld ? (double)aux_weight * sum[1] / cnt : 0.0));   /* criterion.py:188 */
+  for (int64_t i = 0; i < (int64_t)B * C * hw; ++i) {
+    if (gm) gm[i] = (float)(acc[i] / cnt);
+    if (gd) gd[i] = (float)((double)aux_weight * acc[(int64_t)B * C * hw + i] / cnt);
+  }
+  free(acc);
+  free(v);
+  return 1;
+}
+
+/* ---- pyramid pooling module, networks/pspnet_combine.py:86-112 ------------------------------------ */
+static int bin_start(int i, int n, int s) { return (i * n) / s; }                 /* adaptive_avg_pool2d */
+static int bin_end(int i, int n, int s) { return ((i + 1) * n + s - 1) / s; }
+
+int64_t skd_ppm_pooled_floats(int planes, int nsizes, const int *sizes) {
+  int64_t bins = 0;
+  if (planes <= 0 || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  for (int k = 0; k < nsizes; ++k) bins += (int64_t)sizes[k] * sizes[k];
+  return planes * bins;
+}
+
+int skd_ppm_pool(int planes, int H, int W, int nsizes, const int *sizes, const float *x, float *pooled, stream_t st) {
+  (void)st;
+  if (planes <= 0 || H <= 0 || W <= 0 || nsizes <= 0 || nsizes > 4 || !sizes || !x || !pooled) return 0;
+  int64_t off = 0;
+  for (int k = 0; k < nsizes; ++k) {
+    const int s = sizes[k];
+    for (int64_t p = 0; p < planes; ++p)
+      for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j) {
+          const int h0 = bin_start(i, H, s), h1 = bin_end(i, H, s), w0 = bin_start(j, W, s), w1 = bin_end(j, W, s);
+          double a = 0.0;
+          for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) a += x[p * (int64_t)H * W + (int64_t)h * W + w];
+          pooled[off + p * (s * s) + i * s + j] = (float)(a / ((h1 - h0) * (w1 - w0)));
+        }
+    off += (int64_t)planes * s * s;
+  }
+  return 1;
+}
+
+int skd_ppm_pool_backward(int planes, int H, int W, int nsizes, const int *sizes, const float *g, float *dx, stream_t st) {
+  (void)st;
+  if (planes <= 0 || H <= 0 || W <= 0 || nsizes <= 0 || nsizes > 4 || !sizes || !g || !dx) return 0;
+  double *acc = (double *)calloc((size_t)planes * H * W, sizeof(double));
+  if (!acc) return 0;
+  int64_t off = 0;
+  for (int k = 0; k < nsizes; ++k) {
+    const int s = sizes[k];
+    for (int64_t p = 0; p < planes; ++p)
+      for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j) {
+          const int h0 = bin_start(i, H, s), h1 = bin_end(i, H, s), w0 = bin_start(j, W, s), w1 = bin_end(j, W, s);
+          const double v = (double)g[off + p * (s * s) + i * s + j] / ((h1 - h0) * (w1 - w0));
+          for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) acc[p * (int64_t)H * W + (int64_t)h * W + w] += v;
+        }
+    off += (int64_t)planes * s * s;
+  }
+  for (int64_t e = 0; e < (int64_t)planes * H * W; ++e) dx[e] = (float)acc[e];
+  free(acc);
+  return 1;
+}
+
+int skd_ppm_concat(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                   const float *const *priors, const float *feats, float *cat, stream_t st) {
+  (void)st;
+  if (B <= 0 || Cout <= 0 || Cfeat < 0 || H <= 0 || W <= 0 || nsizes <= 0 || nsizes > 4 || !sizes || !priors || !cat) return 0;
+  const int Ctot = nsizes * Cout + Cfeat, HW = H * W;
+  for (int b = 0; b < B; ++b) {
+    for (int k = 0; k < nsizes; ++k) {
+      const int s = sizes[k];
+      const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+      for (int c = 0; c < Cout; ++c) {
+        const float *src = priors[k] + ((int64_t)b * Cout + c) * (s * s);
+        float *out = cat + ((int64_t)b * Ctot + k * Cout + c) * HW;
+        for (int Y = 0; Y < H; ++Y) {
+          int y0, y1; float ly0, ly1;
+          tap_of(Y, sy, s, &y0, &y1, &ly0, &ly1);
+          for (int X = 0; X < W; ++X) {
+            int x0, x1; float lx0, lx1;
+            tap_of(X, sx, s, &x0, &x1, &lx0, &lx1);
+            out[Y * W + X] = (float)((double)ly0 * ((double)lx0 * src[y0 * s + x0] + (double)lx1 * src[y0 * s + x1]) +
+                                     (double)ly1 * ((double)lx0 * src[y1 * s + x0] + (double)lx1 * src[y1 * s + x1]));
+          }
+        }
+      }
+    }
+    for (int c = 0; c < Cfeat; ++c)
+      memcpy(cat + ((int64_t)b * Ctot + nsizes * Cout + c) * HW, feats + ((int64_t)b * Cfeat + c) * HW, sizeof(float) * (size_t)HW);
+  }
+  return 1;
+}
+
+int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                            const float *gcat, float *const *gpriors, stream_t st) {
+  (void)st;
+  if (B <= 0 || Cout <= 0 || Cfeat < 0 || H <= 0 || W <= 0 || nsizes <= 0 || nsizes > 4 || !sizes || !gcat || !gpriors) return 0;
+  const int Ctot = nsizes * Cout + Cfeat, HW = H * W;
+  for (int k = 0; k < nsizes; ++k) {
+    const int s = sizes[k];
+    const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+    double *acc = (double *)malloc(sizeof(double) * (size_t)s * s);
+    if (!acc) return 0;
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < Cout; ++c) {
+        const float *g = gcat + ((int64_t)b * Ctot + k * Cout + c) * HW;
+        for (int q = 0; q < s * s; ++q) acc[q] = 0.0;
+        for (int Y = 0; Y < H; ++Y) {
+          int y0, y1; float ly0, ly1;
+          tap_of(Y, sy, s, &y0, &y1, &ly0, &ly1);
+          for (int X = 0; X < W; ++X) {
+            int x0, x1; float lx0, lx1;
+            tap_of(X, sx, s, &x0, &x1, &lx0, &lx1);
+            const double v = g[Y * W + X];
+            acc[y0 * s + x0] += (double)ly0 * lx0 * v;
+            acc[y0 * s + x1] += (double)ly0 * lx1 * v;
+            acc[y1 * s + x0] += (double)ly1 * lx0 * v;
+            acc[y1 * s + x1] += (double)ly1 * lx1 * v;
+          }
+        }
+        for (int q = 0; q < s * s; ++q) gpriors[k][((int64_t)b * Cout + c) * (s * s) + q] = (float)acc[q];
+      }
+    free(acc);
+  }
+  return 1;
+}

@@ -55,6 +55,13 @@ SIGNATURES = {
     "skd_spectral_workspace_floats": (_L, [_I, _I]),
     "skd_spectral_norm_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "skd_spectral_norm_backward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "skd_ce_dsn_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "skd_ce_dsn_forward": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
+    "skd_ppm_pooled_floats": (_L, [_I, _I, _P]),
+    "skd_ppm_pool": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_ppm_pool_backward": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_ppm_concat": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "skd_ppm_concat_backward": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_sum_f32": (_I, [_L, _P, _P, _F, _P, _P]),
 }
 
@@ -177,6 +184,16 @@ def check(ok, what):
 def ptr(t):
     """Device pointer of a tensor, or NULL for None (lib_cffi.cpp:62-63 convention)."""
     return None if t is None else t.data_ptr()
+
+
+def int_array(values):
+    """Host int[] argument (e.g. the pyramid sizes of skd_ppm_*)."""
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (``const float *const *`` arguments)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def stream_of(t):

@@ -4,6 +4,8 @@ Each function here is the differentiable form of one reference computation, exec
 hand-written gfx950 kernels behind the C ABI of include/skd.h (no eager fallback: CPU tensors
 raise, see _lib.require_device):
 
+    cross_entropy_dsn(m, d, y)   utils/criterion.py:179-188   csrc/ce_dsn.hip
+    ppm_pool / ppm_concat        networks/pspnet_combine.py:102-111   csrc/ppm.hip
     pixel_wise_loss(S, T)        utils/criterion.py:219-226   csrc/pixelwise.hip
     max_pool_argmax(x, kh, kw)   nn.MaxPool2d(k=s, ceil_mode=True) of criterion.py:243   csrc/pairwise.hip
     sim_dis(f_S, f_T)            utils/utils.py:170-183 (L2, similarity, sim_dis_compute)  csrc/pairwise.hip
@@ -55,6 +57,134 @@ class _PixelWise(Function):
 def pixel_wise_loss(logits_s, logits_t):
     """sum(-softmax(T) * log_softmax(S)) / W / H over the class dim of (N,C,W,H) logits; no grad to T."""
     return _PixelWise.apply(logits_s, logits_t.detach())
+
+
+class _CrossEntropyDSN(Function):
+    @staticmethod
+    def forward(ctx, logits_main, logits_dsn, target, ignore_index, aux_weight):
+        _lib.require_device(logits_main, logits_dsn, target)
+        lm = _f32c(logits_main, "cross_entropy_dsn")
+        ld = _f32c(logits_dsn, "cross_entropy_dsn") if logits_dsn is not None else None
+        if target.dtype != torch.int64:
+            raise TypeError("cross_entropy_dsn: int64 target expected (got %s)" % target.dtype)
+        tg = target if target.is_contiguous() else target.contiguous()
+        b, c, h, w = lm.shape
+        if ld is not None and ld.shape != lm.shape:
+            raise ValueError("main and dsn logits differ in shape")
+        if tg.dim() != 3 or tg.shape[0] != b:
+            raise ValueError("target must be (B, H, W)")
+        H, W = tg.shape[1], tg.shape[2]
+        lib, st = _lib.get(), _lib.stream_of(lm)
+        need_m = ctx.needs_input_grad[0]
+        need_d = ld is not None and ctx.needs_input_grad[1]
+        loss = lm.new_empty(())
+        gm = torch.empty_like(lm) if need_m else None
+        gd = torch.empty_like(ld) if need_d else None
+        ws = lm.new_empty((max(8, lib.skd_ce_dsn_workspace_floats(b, c, h, w, H, W)),))
+        _lib.check(lib.skd_ce_dsn_forward(b, c, h, w, H, W, lm.data_ptr(), _lib.ptr(ld), tg.data_ptr(),
+                                          int(ignore_index), float(aux_weight), loss.data_ptr(), _lib.ptr(gm),
+                                          _lib.ptr(gd), ws.data_ptr(), st), "skd_ce_dsn_forward")
+        ctx.save_for_backward(gm, gd)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gm, gd = ctx.saved_tensors
+        return (gm * g if gm is not None else None), (gd * g if gd is not None else None), None, None, None
+
+
+def cross_entropy_dsn(logits_main, logits_dsn, target, ignore_index=255, aux_weight=0.4):
+    """CE(up(main), target) + aux_weight * CE(up(dsn), target), up = bilinear align_corners upsample to the
+    target's size, CE = mean over non-ignored pixels (utils/criterion.py:179-188) -- one fused kernel chain
+    that never materialises a (B, C, H, W) tensor.  ``logits_dsn`` may be None (single CE)."""
+    return _CrossEntropyDSN.apply(logits_main, logits_dsn, target, ignore_index, aux_weight)
+
+
+class _PPMPool(Function):
+    """All pyramid levels of AdaptiveAvgPool2d from one read of the feature map."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        _lib.require_device(x)
+        x = _f32c(x, "ppm_pool")
+        b, c, h, w = x.shape
+        lib, st = _lib.get(), _lib.stream_of(x)
+        arr = _lib.int_array(sizes)
+        total = lib.skd_ppm_pooled_floats(b * c, len(sizes), arr)
+        if total <= 0:
+            raise ValueError("ppm_pool: bad pyramid sizes %r" % (sizes,))
+        buf = x.new_empty((total,))
+        _lib.check(lib.skd_ppm_pool(b * c, h, w, len(sizes), arr, x.data_ptr(), buf.data_ptr(), st), "skd_ppm_pool")
+        ctx.geom = (b, c, h, w, tuple(sizes))
+        outs, off = [], 0
+        for s_ in sizes:
+            n = b * c * s_ * s_
+            outs.append(buf[off:off + n].view(b, c, s_, s_))
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        b, c, h, w, sizes = ctx.geom
+        ref = next(g for g in grads if g is not None)
+        flat = torch.cat([(g if g is not None else ref.new_zeros((b, c, s_, s_))).reshape(-1)
+                          for g, s_ in zip(grads, sizes)]).to(torch.float32)
+        dx = ref.new_empty((b, c, h, w), dtype=torch.float32)
+        lib, st = _lib.get(), _lib.stream_of(flat)
+        _lib.check(lib.skd_ppm_pool_backward(b * c, h, w, len(sizes), _lib.int_array(sizes), flat.data_ptr(),
+                                             dx.data_ptr(), st), "skd_ppm_pool_backward")
+        return dx, None
+
+
+def ppm_pool(x, sizes=(1, 2, 3, 6)):
+    """[AdaptiveAvgPool2d(s)(x) for s in sizes] (pspnet_combine.py:102) -- one kernel, one read of x."""
+    return _PPMPool.apply(x, tuple(int(s_) for s_ in sizes))
+
+
+class _PPMConcat(Function):
+    """cat([upsample(p, (H, W), bilinear, align_corners=True) for p in priors] + [feats], 1)."""
+
+    @staticmethod
+    def forward(ctx, feats, *priors):
+        _lib.require_device(feats, *priors)
+        feats = _f32c(feats, "ppm_concat")
+        priors = [_f32c(p, "ppm_concat") for p in priors]
+        b, cf, h, w = feats.shape
+        cout = priors[0].shape[1]
+        sizes = []
+        for p in priors:
+            if p.shape[0] != b or p.shape[1] != cout or p.shape[2] != p.shape[3]:
+                raise ValueError("ppm_concat: priors must be (B, Cout, s, s)")
+            sizes.append(p.shape[2])
+        lib, st = _lib.get(), _lib.stream_of(feats)
+        cat = feats.new_empty((b, len(priors) * cout + cf, h, w))
+        _lib.check(lib.skd_ppm_concat(b, cout, cf, h, w, len(sizes), _lib.int_array(sizes), _lib.ptr_array(priors),
+                                      feats.data_ptr(), cat.data_ptr(), st), "skd_ppm_concat")
+        ctx.geom = (b, cout, cf, h, w, tuple(sizes))
+        return cat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gcat):
+        b, cout, cf, h, w, sizes = ctx.geom
+        gcat = _f32c(gcat, "ppm_concat backward")
+        lib, st = _lib.get(), _lib.stream_of(gcat)
+        gfeats = gcat[:, len(sizes) * cout:] if ctx.needs_input_grad[0] else None
+        gpriors = [None] * len(sizes)
+        if any(ctx.needs_input_grad[1:]):
+            gpriors = [gcat.new_empty((b, cout, s_, s_)) for s_ in sizes]
+            _lib.check(lib.skd_ppm_concat_backward(b, cout, cf, h, w, len(sizes), _lib.int_array(sizes),
+                                                   gcat.data_ptr(), _lib.ptr_array(gpriors), st),
+                       "skd_ppm_concat_backward")
+        return (gfeats,) + tuple(gpriors)
+
+
+def ppm_concat(priors, feats):
+    """The concatenated input of the PSP bottleneck (pspnet_combine.py:110-111): up-sampled priors followed by
+    the feature map, written directly into one (B, L*Cout + Cfeat, H, W) tensor."""
+    return _PPMConcat.apply(feats, *priors)
 
 
 def pool_out_size(n, k):

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as SF
 from ..libs import InPlaceABN, InPlaceABNSync  # noqa: F401  (re-exported like pspnet_combine.py:11)
 
 affine_par = True
@@ -103,6 +104,16 @@ class PSPModule(nn.Module):
                              InPlaceABNSync(out_features))
 
     def forward(self, feats):
+        sizes = []
+        for stage in self.stages:
+            o = stage[0].output_size
+            sizes.append(o[0] if isinstance(o, (tuple, list)) else o)
+        if feats.dtype == torch.float32 and len(sizes) <= 4 and feats.size(3) <= 256:
+            # csrc/ppm.hip: every pyramid level from one read of feats; priors up-sampled straight into the
+            # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
+            pooled = SF.ppm_pool(feats, sizes)
+            priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
+            return self.bottleneck(SF.ppm_concat(priors, feats))
         h, w = feats.size(2), feats.size(3)
         priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=True)
                   for stage in self.stages] + [feats]

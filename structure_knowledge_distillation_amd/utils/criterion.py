@@ -2,7 +2,7 @@
 arguments and list-indexing convention (``preds[0]`` logits, ``preds[1]`` DSN logits, ``preds[-5]``
 post-PSP feature), each returning a 0-dim tensor that participates in autograd.
 
-    CriterionDSN                              :168-188   bilinear upsample + CE(ignore 255), main + 0.4*aux
+    CriterionDSN                              :168-188   fused HIP kernels (csrc/ce_dsn.hip): upsample + CE, main + 0.4*aux
     CriterionPixelWise                        :211-226   fused HIP kernel (csrc/pixelwise.hip)
     CriterionPairWiseforWholeFeatAfterPool    :228-245   fused HIP kernels (csrc/pairwise.hip)
     CriterionAdvForG / CriterionAdv           :122-166   wgan-gp / hinge on D's (B,1,1,1) output
@@ -26,7 +26,10 @@ class CriterionDSN(nn.Module):
             print("disabled the reduce.")
 
     def forward(self, preds, target):
-        h, w = target.size(1), target.size(2)
+        if self.reduction == "mean" and preds[0].shape[1] <= 64 and preds[0].dtype == torch.float32:
+            # fused upsample + CE for both heads (csrc/ce_dsn.hip): nothing of size (B, C, H, W) is written
+            return SF.cross_entropy_dsn(preds[0], preds[1], target, self.ignore_index, 0.4)
+        h, w = target.size(1), target.size(2)     # reduce=False / very wide class counts: stock ops
         up = F.interpolate(preds[0], size=(h, w), mode="bilinear", align_corners=True)
         loss1 = F.cross_entropy(up, target, ignore_index=self.ignore_index, reduction=self.reduction)
         up = F.interpolate(preds[1], size=(h, w), mode="bilinear", align_corners=True)

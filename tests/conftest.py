@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")   # errors only: immediate-mode workspace warnings are noise
 
 
 def pytest_configure(config):

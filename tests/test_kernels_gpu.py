@@ -313,6 +313,74 @@ def test_spectral_norm(hip, ref, h, w):
     close(gg, gr, 5e-5, "grad_w_bar")
 
 
+@pytest.mark.parametrize("geom", [(2, 19, 9, 9, 65, 65), (8, 19, 65, 65, 512, 512), (2, 19, 33, 33, 256, 256), (3, 11, 46, 61, 360, 480),
+                                  (1, 3, 1, 1, 4, 4), (1, 40, 5, 7, 5, 7), (2, 21, 17, 9, 100, 3)])
+def test_ce_dsn(hip, ref, geom):
+    B, C, h, w, H, W = geom
+    g = torch.Generator().manual_seed(H + C)
+    lm, ld = torch.randn(B, C, h, w, generator=g) * 3, torch.randn(B, C, h, w, generator=g) * 3
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[0, : max(1, H // 16)] = 255
+    y[-1, -1, -1] = 255
+    lr, gmr, gdr = torch.empty(1), torch.empty_like(lm), torch.empty_like(ld)
+    assert ref.skd_ce_dsn_forward(B, C, h, w, H, W, P(lm), P(ld), P(y), 255, 0.4, P(lr), P(gmr), P(gdr), P(torch.empty(8)), None)
+    lg, gmg, gdg = torch.empty(1, device=DEV), torch.empty(B, C, h, w, device=DEV), torch.empty(B, C, h, w, device=DEV)
+    ws = torch.empty(hip.skd_ce_dsn_workspace_floats(B, C, h, w, H, W), device=DEV)
+    yg = y.to(DEV)
+    assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), P(gpu(ld)), P(yg), 255, 0.4, P(lg), P(gmg), P(gdg), P(ws), None)
+    close(lg, lr, 1e-5, "loss"); close(gmg, gmr, 5e-5, "grad main"); close(gdg, gdr, 5e-5, "grad dsn")
+    # loss only / single head; bit-reproducible
+    lg2 = torch.empty(1, device=DEV)
+    assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), P(gpu(ld)), P(yg), 255, 0.4, P(lg2), None, None, P(ws), None)
+    assert float(lg2) == float(lg)
+    assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), None, P(yg), 255, 0.4, P(lg2), P(gmg), None, P(ws), None)
+    up = torch.nn.functional.interpolate(lm.double(), size=(H, W), mode="bilinear", align_corners=True)
+    want = torch.nn.functional.cross_entropy(up, y, ignore_index=255)
+    close(lg2, want.reshape(1).float(), 1e-5, "single-head loss vs torch")
+    close(gmg, gmr, 5e-5, "single-head grad")
+    # every pixel ignored -> 0/0 = NaN, like CrossEntropyLoss(reduction='mean')
+    y255 = torch.full((B, H, W), 255, dtype=torch.int64, device=DEV)
+    assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), P(gpu(ld)), P(y255), 255, 0.4, P(lg2), None, None, P(ws), None)
+    assert float(lg2) != float(lg2)
+
+
+@pytest.mark.parametrize("geom", [(8, 512, 65, 65, 128), (2, 2048, 65, 65, 512), (2, 7, 33, 33, 5), (3, 4, 46, 61, 3), (1, 2, 7, 9, 2), (1, 1, 129, 129, 1)])
+def test_ppm(hip, ref, geom):
+    B, C, H, W, Cout = geom
+    sizes = (1, 2, 3, 6)
+    arr = (ctypes.c_int * 4)(*sizes)
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    total = hip.skd_ppm_pooled_floats(B * C, 4, arr)
+    assert total == ref.skd_ppm_pooled_floats(B * C, 4, arr) == B * C * 50
+    pr, pg = torch.empty(total), torch.empty(total, device=DEV)
+    assert ref.skd_ppm_pool(B * C, H, W, 4, arr, P(x), P(pr), None)
+    assert hip.skd_ppm_pool(B * C, H, W, 4, arr, P(gpu(x)), P(pg), None)
+    close(pg, pr, 1e-5, "pooled")
+    gp = torch.randn(total, generator=g)
+    dxr, dxg = torch.empty_like(x), torch.empty(B, C, H, W, device=DEV)
+    assert ref.skd_ppm_pool_backward(B * C, H, W, 4, arr, P(gp), P(dxr), None)
+    assert hip.skd_ppm_pool_backward(B * C, H, W, 4, arr, P(gpu(gp)), P(dxg), None)
+    close(dxg, dxr, 1e-5, "pool backward")
+    priors = [torch.randn(B, Cout, s, s, generator=g) for s in sizes]
+    pgs = [gpu(t) for t in priors]
+    cat_r, cat_g = torch.empty(B, 4 * Cout + C, H, W), torch.full((B, 4 * Cout + C, H, W), 7.0, device=DEV)
+    assert ref.skd_ppm_concat(B, Cout, C, H, W, 4, arr, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in priors]), P(x), P(cat_r), None)
+    assert hip.skd_ppm_concat(B, Cout, C, H, W, 4, arr, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in pgs]), P(gpu(x)), P(cat_g), None)
+    close(cat_g, cat_r, 1e-5, "concat")
+    assert torch.equal(cat_g[:, 4 * Cout:].cpu(), x), "feature slice is a bit-exact copy"
+    gc = torch.randn(B, 4 * Cout + C, H, W, generator=g)
+    gr, gg = [torch.empty_like(t) for t in priors], [torch.empty_like(t) for t in pgs]
+    assert ref.skd_ppm_concat_backward(B, Cout, C, H, W, 4, arr, P(gc), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gr]), None)
+    assert hip.skd_ppm_concat_backward(B, Cout, C, H, W, 4, arr, P(gpu(gc)), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gg]), None)
+    for a, b, s_ in zip(gg, gr, sizes):
+        close(a, b, 2e-5, "concat backward level %d" % s_)
+    # against torch's own ops
+    tp = torch.nn.functional.adaptive_avg_pool2d(x.double(), 3)
+    off = B * C * 5
+    close(pg[off:off + B * C * 9].view(B, C, 3, 3), tp.float(), 1e-5, "pool vs torch")
+
+
 def test_sum_f32(hip):
     for n in (0, 1, 255, 4097, 1 << 20):
         x = torch.randn(max(n, 1), device=DEV)[:n]

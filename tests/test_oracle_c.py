@@ -113,3 +113,67 @@ def test_spectral_c_vs_torch(ref):
     gwb = torch.empty(12, 40)
     assert ref.skd_spectral_norm_backward(12, 40, P(W), P(uc), P(vc), P(sig), P(gw), P(gwb), P(torch.empty(1)), None)
     assert rel(gwb, Pd["weight_bar"].grad.reshape(12, 40)) < 1e-4
+
+
+@pytest.mark.parametrize("geom", [(2, 19, 9, 9, 65, 65), (1, 5, 7, 4, 20, 33), (2, 11, 6, 8, 41, 57), (1, 3, 1, 1, 4, 4), (1, 4, 5, 5, 5, 5)])
+def test_ce_dsn_c_vs_torch(ref, geom):
+    B, C, h, w, H, W = geom
+    g = torch.Generator().manual_seed(H)
+    lm, ld = torch.randn(B, C, h, w, generator=g) * 3, torch.randn(B, C, h, w, generator=g) * 3
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[0, : max(1, H // 8)] = 255
+    lmo, ldo = lm.double().requires_grad_(True), ld.double().requires_grad_(True)
+    L = O.criterion_dsn([lmo, ldo], y)
+    L.backward()
+    loss, gm, gd = torch.empty(1), torch.empty_like(lm), torch.empty_like(ld)
+    assert ref.skd_ce_dsn_forward(B, C, h, w, H, W, P(lm), P(ld), P(y), 255, 0.4, P(loss), P(gm), P(gd), P(torch.empty(8)), None)
+    assert rel(loss, L.detach().reshape(1)) < 1e-6
+    assert rel(gm, lmo.grad) < 2e-5 and rel(gd, ldo.grad) < 2e-5
+    # single head, no gradients
+    assert ref.skd_ce_dsn_forward(B, C, h, w, H, W, P(lm), None, P(y), 255, 0.4, P(loss), None, None, P(torch.empty(8)), None)
+    want = F.cross_entropy(F.interpolate(lm.double(), size=(H, W), mode="bilinear", align_corners=True), y, ignore_index=255)
+    assert rel(loss, want.reshape(1)) < 1e-6
+
+
+@pytest.mark.parametrize("geom", [(2, 5, 65, 65), (1, 3, 33, 33), (2, 4, 46, 61), (1, 2, 7, 9)])
+def test_ppm_c_vs_torch(ref, geom):
+    """AdaptiveAvgPool2d(1,2,3,6), bilinear(align_corners) up-sampling + cat, and their backward."""
+    B, C, H, W = geom
+    sizes = (1, 2, 3, 6)
+    arr = (ctypes.c_int * 4)(*sizes)
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, C, H, W, generator=g)
+    xo = x.double().requires_grad_(True)
+    want = [F.adaptive_avg_pool2d(xo, s) for s in sizes]
+    total = ref.skd_ppm_pooled_floats(B * C, 4, arr)
+    assert total == B * C * 50
+    pooled = torch.empty(total)
+    assert ref.skd_ppm_pool(B * C, H, W, 4, arr, P(x), P(pooled), None)
+    off, gflat = 0, []
+    for s, w_ in zip(sizes, want):
+        n = B * C * s * s
+        assert rel(pooled[off:off + n].view(B, C, s, s), w_.detach()) < 1e-6
+        gflat.append(torch.randn(B, C, s, s, generator=g))
+        off += n
+    sum((w_ * gg.double()).sum() for w_, gg in zip(want, gflat)).backward()
+    dx = torch.empty_like(x)
+    assert ref.skd_ppm_pool_backward(B * C, H, W, 4, arr, P(torch.cat([t.reshape(-1) for t in gflat])), P(dx), None)
+    assert rel(dx, xo.grad) < 1e-6
+    # concat
+    Cout = 3
+    priors = [torch.randn(B, Cout, s, s, generator=g) for s in sizes]
+    po = [p.double().requires_grad_(True) for p in priors]
+    fo = x.double().requires_grad_(True)
+    cat_o = torch.cat([F.interpolate(p, size=(H, W), mode="bilinear", align_corners=True) for p in po] + [fo], 1)
+    cat = torch.empty(B, 4 * Cout + C, H, W)
+    ptrs = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in priors])
+    assert ref.skd_ppm_concat(B, Cout, C, H, W, 4, arr, ptrs, P(x), P(cat), None)
+    assert rel(cat, cat_o.detach()) < 1e-6
+    gc = torch.randn(B, 4 * Cout + C, H, W, generator=g)
+    (cat_o * gc.double()).sum().backward()
+    gp = [torch.empty_like(p) for p in priors]
+    gptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gp])
+    assert ref.skd_ppm_concat_backward(B, Cout, C, H, W, 4, arr, P(gc), gptrs, None)
+    for a, b in zip(gp, po):
+        assert rel(a, b.grad) < 1e-5
+    assert rel(gc[:, 4 * Cout:], fo.grad) == 0.0
