@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pairwise-sweep", action="store_true")
     return ap.parse_args()
 
 
@@ -212,7 +213,7 @@ def main():
             "skd_abn_forward_train (stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
             "skd_abn_backward (reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),
         }
-    if world == 1:
+    if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.size)

@@ -92,6 +92,29 @@ int skd_abn_apply(int N, int C, int S, float *x, const float *mean, const float 
 int skd_abn_apply_residual(int N, int C, int S, float *x, const float *residual, const float *mean,
                            const float *var, const float *weight, const float *bias, float eps,
                            int activation, float slope, skd_stream_t stream);
+/* Training-time BN -> (+ residual) -> ReLU as ONE op, out of place (networks/pspnet_combine.py:36-43, 68-82:
+ * BatchNorm2d = InPlace-ABN(activation='none'), then nn.ReLU, at block tails `out + residual` first).
+ * The convolution output x is left untouched and is what backward reads (y is recomputed from x, mean, var);
+ * `out` = act(bn(x) [+ residual]) is what the next layer consumes; the ReLU mask is `out > 0`.
+ *   apply_to / forward_train_to : generic out-of-place forms of skd_abn_apply / skd_abn_forward_train
+ *                                 (residual may be NULL; activation may be SKD_ACT_RELU)
+ *   relu_backward_reduce        : edz = mean(dz), eydz = mean(y*dz) with dz = dout * (out > 0)
+ *   relu_backward_dx            : dx = (dz - edz - y*eydz) * gamma * invStd ; dres = dz (may be NULL);
+ *                                 dweight / dbias accumulated (+=) like skd_bn_backward */
+int skd_abn_apply_to(int N, int C, int S, const float *x, const float *residual, float *out,
+                     const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                     int activation, float slope, skd_stream_t stream);
+int skd_abn_forward_train_to(int N, int C, int S, const float *x, const float *residual, float *out,
+                             const float *weight, const float *bias, float *running_mean,
+                             float *running_var, float *mean, float *var, float momentum, float eps,
+                             int activation, float slope, float *workspace, skd_stream_t stream);
+int skd_abn_relu_backward_reduce(int N, int C, int S, const float *x, const float *out, const float *dout,
+                                 const float *mean, const float *var, float *edz, float *eydz, float eps,
+                                 float *workspace, skd_stream_t stream);
+int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *out, const float *dout,
+                             const float *mean, const float *var, const float *weight, const float *edz,
+                             const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
+                             float eps, skd_stream_t stream);
 /* running-stat update with an explicit sample count n (functions.py:209) */
 int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
                            const float *var, float momentum, double n, skd_stream_t stream);

@@ -285,3 +285,74 @@ int skd_abn_backward(int N, int C, int S, const float *z, const float *dz, const
   }
   return skd_abn_backward_dx(N, C, S, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, st);
 }
+
+/* ---- training-time BN -> (+residual) -> ReLU, out of place (networks/pspnet_combine.py:36-43, 68-82) ---- */
+int skd_abn_apply_to(int N, int C, int S, const float *x, const float *residual, float *out, const float *mean,
+                     const float *var, const float *weight, const float *bias, float eps, int act, float slope,
+                     stream_t st) {
+  if (N <= 0 || C <= 0 || S <= 0 || !x || !out) return 0;
+  memcpy(out, x, sizeof(float) * (size_t)N * C * S);
+  if (residual) return skd_abn_apply_residual(N, C, S, out, residual, mean, var, weight, bias, eps, act, slope, st);
+  return skd_abn_apply(N, C, S, out, mean, var, weight, bias, eps, act, slope, st);
+}
+
+int skd_abn_forward_train_to(int N, int C, int S, const float *x, const float *residual, float *out,
+                             const float *weight, const float *bias, float *rm, float *rv, float *mean,
+                             float *var, float momentum, float eps, int act, float slope, float *ws, stream_t st) {
+  (void)ws;
+  if (!skd_bn_mean_var(N, C, S, x, mean, var, st)) return 0;
+  if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, (double)N * (double)S, st);
+  return skd_abn_apply_to(N, C, S, x, residual, out, mean, var, weight, bias, eps, act, slope, st);
+}
+
+int skd_abn_relu_backward_reduce(int N, int C, int S, const float *x, const float *out, const float *dout,
+                                 const float *mean, const float *var, float *edz, float *eydz, float eps,
+                                 float *ws, stream_t st) {
+  (void)ws; (void)st;
+  if (N <= 0 || C <= 0 || S <= 0) return 0;
+  const double norm = 1.0 / ((double)N * (double)S);
+  for (int c = 0; c < C; ++c) {
+    const float is = inv_std_of(var[c], eps);
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const int64_t off = ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) {
+        const float dz = out[off + i] > 0.f ? dout[off + i] : 0.f;      /* ReLU backward */
+        const float y = (x[off + i] - mean[c]) * is;                     /* bn.cu:158 */
+        s1 += dz;
+        s2 += (double)y * dz;
+      }
+    }
+    edz[c] = (float)(s1 * norm);
+    eydz[c] = (float)(s2 * norm);
+  }
+  return 1;
+}
+
+int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *out, const float *dout,
+                             const float *mean, const float *var, const float *weight, const float *edz,
+                             const float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
+                             stream_t st) {
+  (void)st;
+  if (N <= 0 || C <= 0 || S <= 0 || !dx) return 0;
+  for (int c = 0; c < C; ++c) {
+    const float is = inv_std_of(var[c], eps);
+    const float mul = gamma_of(weight, c, eps) * is;                     /* bn.cu:203 */
+    for (int n = 0; n < N; ++n) {
+      const int64_t off = ((int64_t)n * C + c) * S;
+      for (int i = 0; i < S; ++i) {
+        const float dz = out[off + i] > 0.f ? dout[off + i] : 0.f;
+        const float y = (x[off + i] - mean[c]) * is;
+        dx[off + i] = (dz - edz[c] - y * eydz[c]) * mul;                 /* bn.cu:209 */
+        if (dres) dres[off + i] = dz;
+      }
+    }
+    const float norm = (float)N * (float)S;
+    if (dweight) {
+      if (weight[c] > 0.f) dweight[c] += eydz[c] * norm;                 /* bn.cu:217-223 */
+      else if (weight[c] < 0.f) dweight[c] -= eydz[c] * norm;
+    }
+    if (dbias) dbias[c] += edz[c] * norm;                                /* bn.cu:226-229 */
+  }
+  return 1;
+}

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void l2_normalise_kernel(const float *__r
 // 128x128 fp32 MFMA tile over k-major panels:  acc[i][j] += sign * sum_k A[k][i] * B[k][j]
 // =============================================================================================
 constexpr int kTile = 128;
-constexpr int kBK = 16;
+constexpr int kBK = 32;   // 64 KiB of LDS per workgroup (2 stages x 2 panels): 2 workgroups per CU
 constexpr int kPanel = kBK * kTile;  // floats per panel per stage
 
 struct Segment {
@@ -222,8 +222,9 @@ struct Segment {
   int negate;   // accumulate with a minus sign
 };
 
+constexpr int kLoadsPerThread = kBK / 8;  // panel rows handled by one thread (8 rows per pass of 256 threads)
 struct TileRegs {
-  float4 a[2], b[2];
+  float4 a[kLoadsPerThread], b[kLoadsPerThread];
 };
 
 __device__ __forceinline__ void panel_load(const Segment &s, int k0, TileRegs &r) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void panel_load(const Segment &s, int k0, TileRegs &r
   const int row = t >> 5;       // 0..7
   const int c4 = (t & 31) * 4;  // 0..124
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < kLoadsPerThread; ++h) {
     const int k = k0 + row + 8 * h;
     if (k < s.K) {
       r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)k * s.lda + c4);
@@ -248,7 +249,7 @@ __device__ __forceinline__ void panel_store(float *lds_stage, const TileRegs &r)
   const int row = t >> 5;
   const int c4 = (t & 31) * 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < kLoadsPerThread; ++h) {
     *reinterpret_cast<float4 *>(lds_stage + (row + 8 * h) * kTile + c4) = r.a[h];
     *reinterpret_cast<float4 *>(lds_stage + kPanel + (row + 8 * h) * kTile + c4) = r.b[h];
   }
@@ -326,16 +327,24 @@ __device__ __forceinline__ void tile_gemm(const Segment (&seg)[NSEG], float *lds
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// gram + loss.  grid = (nt*nt, B): blockIdx.x -> (ti, tj)
+// gram + loss.  G is symmetric, so only the nt*(nt+1)/2 tiles with ti <= tj are computed: an off-diagonal
+// tile counts twice in the loss and is stored twice (as is, and transposed into the mirror position, 16 bytes
+// per lane per store: the C/D fragment holds 4 consecutive rows per register quad).
+// grid = (nt*(nt+1)/2, B): blockIdx.x -> (ti, tj) by walking the rows of the upper triangle.
 __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__restrict__ fs,
                                                                 const float *__restrict__ ft,
                                                                 float *__restrict__ G,
                                                                 float *__restrict__ part, int Cs,
                                                                 int Ct, int ldm, int nt) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kPanel];
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * 2 * kPanel floats
   __shared__ float red[2 * kWavesPerWG];
   const int b = blockIdx.y;
-  const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) {
+    rem -= nt - ti;
+    ++ti;
+  }
+  const int tj = ti + rem;
   const int i0 = ti * kTile, j0 = tj * kTile;
   Segment seg[2];
   seg[0].A = ft + (int64_t)b * Ct * ldm + i0;
@@ -353,21 +362,33 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const bool mirror = ti != tj;
+  float *Gb = G != nullptr ? G + (int64_t)b * ldm * ldm : nullptr;
   float sq = 0.f, unused = 0.f;
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
+    for (int bj = 0; bj < 2; ++bj) {
+      const int col = j0 + wj + bj * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float g = acc[bi][bj][r];
-        sq += g * g;  // padded rows/cols are exactly zero
-        if (G != nullptr) {
-          const int row = i0 + wi + bi * 32 + frag_row(r, lane);
-          const int col = j0 + wj + bj * 32 + (lane & 31);
-          G[((int64_t)b * ldm + row) * ldm + col] = g;
+      for (int q = 0; q < 4; ++q) {
+        const int row0 = i0 + wi + bi * 32 + 8 * q + 4 * (lane >> 5);  // rows row0 .. row0+3 = regs 4q .. 4q+3
+        float4 v;
+        v.x = acc[bi][bj][4 * q + 0];
+        v.y = acc[bi][bj][4 * q + 1];
+        v.z = acc[bi][bj][4 * q + 2];
+        v.w = acc[bi][bj][4 * q + 3];
+        sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);  // padded rows/cols are exactly zero
+        if (Gb != nullptr) {
+          Gb[(int64_t)(row0 + 0) * ldm + col] = v.x;
+          Gb[(int64_t)(row0 + 1) * ldm + col] = v.y;
+          Gb[(int64_t)(row0 + 2) * ldm + col] = v.z;
+          Gb[(int64_t)(row0 + 3) * ldm + col] = v.w;
+          if (mirror) *reinterpret_cast<float4 *>(Gb + (int64_t)col * ldm + row0) = v;  // G[col][row0..row0+3]
         }
       }
+    }
+  if (mirror) sq *= 2.f;
   block_sum2(sq, unused, red);
   if (threadIdx.x == 0) part[(int64_t)b * gridDim.x + blockIdx.x] = sq;
 }
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
                                                                    float *__restrict__ dpooled, int Cs,
                                                                    int M, int ldm, int ldc, int ntm,
                                                                    float coef) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kPanel];
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * 2 * kPanel floats
   const int b = blockIdx.y;
   const int tc = blockIdx.x / ntm, tm = blockIdx.x % ntm;
   const int c0 = tc * kTile, m0 = tm * kTile;
@@ -481,7 +502,20 @@ int skd_channel_l2_normalise(int B, int C, int M, const float *pooled, float *fh
 int64_t skd_pairwise_workspace_floats(int B, int M) {
   if (B <= 0 || M <= 0) return 1;
   const int64_t nt = cdiv(M, kTile);
-  return nt * nt * B;
+  return nt * (nt + 1) / 2 * B;
+}
+
+static constexpr size_t kGemmLds = sizeof(float) * 2 * 2 * kPanel;
+static bool gemm_lds_ready() {
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds) != hipSuccess) return false;
+    done = true;
+  }
+  return true;
 }
 
 int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *fhat_s,
@@ -492,11 +526,13 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(fhat_t)) & 15) return 0;
   hipStream_t st = as_stream(stream);
   const int nt = ldm / kTile;
-  gram_loss_kernel<<<dim3((unsigned)(nt * nt), B), dim3(kThreads), 0, st>>>(fhat_s, fhat_t, G, workspace,
-                                                                          Cs, Ct, ldm, nt);
+  const int ntri = nt * (nt + 1) / 2;
+  if (!gemm_lds_ready()) return 0;
+  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), kGemmLds, st>>>(fhat_s, fhat_t, G, workspace, Cs, Ct,
+                                                                             ldm, nt);
   if (!ok()) return 0;
   // utils.py:181: / (M*M) / B
-  return launch_final_sum(workspace, (int64_t)nt * nt * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
+  return launch_final_sum(workspace, (int64_t)ntri * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
 }
 
 int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t, const float *G,
@@ -508,7 +544,8 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *f
   const int ntm = ldm / kTile, ntc = ldc / kTile;
   // dL/dA_S = -2 G /(M^2 B); dFhat = Fhat (dA + dA^T) = -4/(M^2 B) Fhat G   (G symmetric)
   const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
-  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B), dim3(kThreads), 0, as_stream(stream)>>>(
+  if (!gemm_lds_ready()) return 0;
+  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B), dim3(kThreads), kGemmLds, as_stream(stream)>>>(
       fhat_s_t, G, norm_s, grad_loss, dpooled, Cs, M, ldm, ldc, ntm, coef);
   return ok();
 }

@@ -185,6 +185,101 @@ class _InPlaceABN(autograd.Function):
         return dx, dweight, dbias, None, None, None, None, None, None, None, None
 
 
+class _ABNRelu(autograd.Function):
+    """Training-time ``relu(bn(x) [+ residual])`` as one op (csrc/abn.hip, "out of place" section).
+
+    The reference runs InPlace-ABN(activation='none') and then nn.ReLU -- at the tail of a residual block
+    ``out + residual`` in between (networks/pspnet_combine.py:36-43, 68-82) -- keeping z and relu(z) alive.  Here the
+    convolution output x is kept instead of z (y is recomputed from x, mean, var in backward) and ``out`` is the
+    ReLU output, so the same two tensors per layer live on while the separate ReLU / add passes disappear.
+    Cross-replica statistics exactly as in _InPlaceABN."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, group):
+        _lib.require_device(x, weight, bias, running_mean, running_var, residual)
+        if x.dtype != torch.float32:
+            raise TypeError("InPlaceABN kernels are fp32 only (got %s)" % x.dtype)
+        _check_contiguous(x, weight, bias, running_mean, running_var)
+        ctx.eps = float(eps)
+        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        n, c, s = _dims(x)
+        lib, st = _lib.get(), _lib.stream_of(x)
+        out = torch.empty_like(x)
+        if residual is not None and (not residual.is_contiguous() or not _same_phase(x, residual)):
+            residual = residual.clone(memory_format=torch.contiguous_format)
+        if not _same_phase(x, out):   # cannot happen with the caching allocator's 512-byte granularity; be safe
+            raise RuntimeError("abn_relu: misaligned output allocation")
+        stat = x.new_empty((2, c))
+        mean, var = stat[0], stat[1]
+        ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+        if ctx.group is None:
+            _lib.check(lib.skd_abn_forward_train_to(
+                n, c, s, x.data_ptr(), _lib.ptr(residual), out.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(), float(momentum),
+                ctx.eps, _EVAL_ACT_CODE[ACT_RELU], 0.0, ws.data_ptr(), st), "skd_abn_forward_train_to")
+        else:
+            g = _group_size(ctx.group)
+            _lib.check(lib.skd_abn_stats(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), st),
+                       "skd_abn_stats")
+            gathered = x.new_empty((g, 2, c))
+            dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=ctx.group)
+            mean, var = combine_replica_stats(gathered)
+            mean, var = mean.contiguous(), var.contiguous()
+            if running_mean is not None:
+                _lib.check(lib.skd_abn_update_running(c, running_mean.data_ptr(), running_var.data_ptr(),
+                                                      mean.data_ptr(), var.data_ptr(), float(momentum),
+                                                      float(n * s * g), st), "skd_abn_update_running")
+            _lib.check(lib.skd_abn_apply_to(n, c, s, x.data_ptr(), _lib.ptr(residual), out.data_ptr(), mean.data_ptr(),
+                                            var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), ctx.eps,
+                                            _EVAL_ACT_CODE[ACT_RELU], 0.0, st), "skd_abn_apply_to")
+        ctx.has_residual = residual is not None
+        ctx.save_for_backward(x, out, weight, mean, var)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, out, weight, mean, var = ctx.saved_tensors
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
+        need_res = ctx.has_residual and ctx.needs_input_grad[5]
+        n, c, s = _dims(x)
+        dout = dout.contiguous()
+        if not _same_phase(x, dout):
+            dout = dout.clone(memory_format=torch.contiguous_format)
+        lib, st = _lib.get(), _lib.stream_of(x)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if need_res else None
+        dweight = torch.zeros_like(weight) if (need_dw and weight is not None) else None
+        dbias = torch.zeros_like(weight) if (need_db and weight is not None) else None
+        stat = x.new_empty((2, c))
+        edz, eydz = stat[0], stat[1]
+        ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+        _lib.check(lib.skd_abn_relu_backward_reduce(n, c, s, x.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                    mean.data_ptr(), var.data_ptr(), edz.data_ptr(), eydz.data_ptr(),
+                                                    ctx.eps, ws.data_ptr(), st), "skd_abn_relu_backward_reduce")
+        if ctx.group is not None:
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)   # libs/functions.py:271-272
+            stat.div_(_group_size(ctx.group))
+        _lib.check(lib.skd_abn_relu_backward_dx(n, c, s, x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(),
+                                                var.data_ptr(), _lib.ptr(weight), edz.data_ptr(), eydz.data_ptr(),
+                                                dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight), _lib.ptr(dbias),
+                                                ctx.eps, st), "skd_abn_relu_backward_dx")
+        return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
+
+
+def abn_relu_train(x, weight, bias, running_mean, running_var, residual=None, momentum=0.1, eps=1e-05, group=None,
+                   sync=True):
+    """relu(bn_batch(x) [+ residual]) with running-statistics update: the training-time fusion of
+    InPlace-ABN(activation='none') -> [+ residual] -> ReLU.  Differentiable (first order) w.r.t. x, weight,
+    bias and residual.  ``sync``: synchronise the statistics over ``group`` (default group when None and
+    torch.distributed is initialised) like InPlaceABNSync; False = this replica only (InPlaceABN)."""
+    if not sync:
+        group = None
+    elif group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = dist.group.WORLD
+    return _ABNRelu.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, group)
+
+
 def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activation=ACT_RELU, slope=0.01,
                    residual=None):
     """Inference-only InPlace-ABN: ``x <- act(bn_running(x) [+ residual])`` in ONE in-place pass.

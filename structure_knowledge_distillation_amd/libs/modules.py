@@ -6,7 +6,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .inplace_abn import abn_eval_fused, inplace_abn, inplace_abn_sync
+from .inplace_abn import abn_eval_fused, abn_relu_train, inplace_abn, inplace_abn_sync
 
 _sync_group = {"group": None, "explicit": False}
 
@@ -61,6 +61,22 @@ class _ABNBase(nn.Module):
         """Inference-only: ``x <- activation(bn(x) [+ residual])`` with the running statistics, one pass."""
         return abn_eval_fused(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                               activation, self.slope, residual)
+
+    def forward_relu(self, x, residual=None):
+        """``relu(self(x) [+ residual])`` for an ``activation='none'`` module -- BatchNorm2d followed by nn.ReLU in
+        networks/pspnet_combine.py -- as one fused op: training -> abn_relu_train, inference (no grad) ->
+        abn_eval_fused, anything else -> the plain op sequence."""
+        if self.activation != "none":
+            raise ValueError("forward_relu fuses BN(activation='none') + ReLU; this module has activation=%r" % self.activation)
+        if self.training:
+            sync = isinstance(self, InPlaceABNSync)
+            group = _sync_group["group"] if (sync and _sync_group["explicit"]) else None
+            return abn_relu_train(x, self.weight, self.bias, self.running_mean, self.running_var, residual,
+                                  self.momentum, self.eps, group, sync=sync)
+        if not torch.is_grad_enabled():
+            return self.fused_eval(x, "relu", residual)
+        out = self(x)
+        return torch.relu(out if residual is None else out + residual)
 
     def extra_repr(self):
         rep = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"

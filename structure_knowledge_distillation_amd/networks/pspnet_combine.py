@@ -19,11 +19,12 @@ affine_par = True
 BatchNorm2d = functools.partial(InPlaceABNSync, activation="none")   # pspnet_combine.py:12
 
 
-def _inference(module):
-    """True when no graph is being recorded and the module normalises with its running statistics:
-    then BN -> ReLU and BN -> (+ residual) -> ReLU collapse into single in-place passes of the ABN kernel
-    (libs.abn_eval_fused).  This is the frozen teacher's whole forward (kd_model.py:121-122)."""
-    return (not module.training) and (not torch.is_grad_enabled())
+def _fused(module, x):
+    """BN -> ReLU and BN -> (+ residual) -> ReLU collapse into single passes of the ABN kernels
+    (InPlaceABNSync.forward_relu): in place with the running statistics for the frozen teacher
+    (eval + no_grad, kd_model.py:121-122), out of place with batch statistics for the training student.
+    Eval mode WITH a graph (rare) and non-fp32 inputs take the reference's op sequence."""
+    return x.dtype == torch.float32 and (module.training or not torch.is_grad_enabled())
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -45,10 +46,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if _inference(self):
-            out = self.bn1.fused_eval(self.conv1(x), "relu")
+        if _fused(self, x):
+            out = self.bn1.forward_relu(self.conv1(x))
             residual = self.downsample(x) if self.downsample is not None else x
-            return self.bn2.fused_eval(self.conv2(out), "relu", residual)
+            return self.bn2.forward_relu(self.conv2(out), residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = self.downsample(x) if self.downsample is not None else x
@@ -74,11 +75,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if _inference(self):
-            out = self.bn1.fused_eval(self.conv1(x), "relu")
-            out = self.bn2.fused_eval(self.conv2(out), "relu")
+        if _fused(self, x):
+            out = self.bn1.forward_relu(self.conv1(x))
+            out = self.bn2.forward_relu(self.conv2(out))
             residual = self.downsample(x) if self.downsample is not None else x
-            return self.bn3.fused_eval(self.conv3(out), "relu", residual)
+            return self.bn3.forward_relu(self.conv3(out), residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
@@ -168,10 +169,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        if _inference(self):
-            x = self.bn1.fused_eval(self.conv1(x), "relu")
-            x = self.bn2.fused_eval(self.conv2(x), "relu")
-            x = self.bn3.fused_eval(self.conv3(x), "relu")
+        if _fused(self, x):
+            x = self.bn1.forward_relu(self.conv1(x))
+            x = self.bn2.forward_relu(self.conv2(x))
+            x = self.bn3.forward_relu(self.conv3(x))
         else:
             x = self.relu1(self.bn1(self.conv1(x)))
             x = self.relu2(self.bn2(self.conv2(x)))

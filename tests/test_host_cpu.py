@@ -184,3 +184,32 @@ def test_netmodel_full_step_with_ho_cpu_double():
     for k in PD:
         if k.endswith(("weight_u", "weight_v")):
             assert rel(after[k], PD[k]) < 1e-4, k
+
+
+def test_abn_relu_training_fusion_vs_autograd():
+    """relu(bn(x) [+ residual]) fused (C double) == the reference's op sequence under autograd, fp64."""
+    from structure_knowledge_distillation_amd import libs
+    torch.manual_seed(11)
+    for with_res in (False, True):
+        mod = libs.InPlaceABNSync(5, activation="none").train()
+        with torch.no_grad():
+            mod.weight.copy_(torch.randn(5)); mod.bias.copy_(torch.randn(5) * 0.3)
+        x, r, g = torch.randn(3, 5, 7, 6) * 2 + 0.5, torch.randn(3, 5, 7, 6), torch.randn(3, 5, 7, 6)
+        xo, ro = x.double().requires_grad_(True), r.double().requires_grad_(True)
+        wo, bo = mod.weight.detach().double().requires_grad_(True), mod.bias.detach().double().requires_grad_(True)
+        rm, rv = torch.zeros(5, dtype=torch.float64), torch.ones(5, dtype=torch.float64)
+        z = abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, "none", 0.01)
+        want = torch.relu(z + ro if with_res else z)
+        want.backward(g.double())
+        xg, rg = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        xin = xg * 1.0
+        got = mod.forward_relu(xin, rg if with_res else None)
+        assert got.data_ptr() != xin.data_ptr()            # out of place: the conv output is kept
+        got.backward(g)
+        assert rel(got, want) < 1e-5 and rel(xg.grad, xo.grad) < 1e-4
+        assert rel(mod.weight.grad, wo.grad) < 1e-4 and rel(mod.bias.grad, bo.grad) < 1e-4
+        assert rel(mod.running_mean, rm) < 1e-6 and rel(mod.running_var, rv) < 1e-6
+        if with_res:
+            assert rel(rg.grad, ro.grad) < 1e-5
+    with pytest.raises(ValueError):
+        libs.InPlaceABNSync(5, activation="leaky_relu").forward_relu(torch.randn(2, 5, 3, 3))

@@ -61,5 +61,45 @@ def main():
         print(json.dumps({"%dx%dx%d" % (N, C, S): row}), flush=True)
 
 
+def cold():
+    """HBM-resident behaviour: cycle over enough distinct tensors (> 1 GB in total) that neither the 32 MiB of
+    L2 nor the 256 MiB Infinity Cache can hold the working set between two visits of the same tensor."""
+    import torch
+    from structure_knowledge_distillation_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for (N, C, S) in ((8, 512, 4225), (8, 2048, 4225), (8, 64, 65536), (8, 256, 16641)):
+        n = max(2, int(1.5e9 // (N * C * S * 4)) + 1)
+        xs = [torch.randn(N, C, S, device=dev) for _ in range(n)]
+        rs = [torch.randn(N, C, S, device=dev) for _ in range(2)]
+        w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        m, v = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws = torch.empty(lib.skd_abn_workspace_floats(N, C, S), device=dev)
+        p = lambda t: t.data_ptr()
+        row = {}
+        for name, bpe, fn in (
+                ("apply_eval(8B)", 8, lambda x: lib.skd_abn_apply(N, C, S, p(x), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
+                ("stats(4B)", 4, lambda x: lib.skd_abn_stats(N, C, S, p(x), p(m), p(v), p(ws), st)),
+                ("forward_train(12B)", 12, lambda x: lib.skd_abn_forward_train(N, C, S, p(x), p(w), p(b), None, None, p(m), p(v), 0.1, 1e-5, 0, 0.01, p(ws), st))):
+            for x in xs:
+                fn(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2):
+                for x in xs:
+                    fn(x)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / (2 * n)
+            row[name] = {"us": round(ms * 1e3, 1), "GBs": round(bpe * N * C * S / (ms * 1e-3) / 1e9, 0)}
+        print(json.dumps({"cold %dx%dx%d (x%d tensors)" % (N, C, S, n): row}), flush=True)
+        del xs, rs
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cold":
+        cold()
+    else:
+        main()

@@ -1,0 +1,85 @@
+"""GPU diagnostic (not product code): layer-by-layer forward of the discriminator, cuda fp32 vs CPU fp64."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import step_torch as O  # noqa: E402
+from structure_knowledge_distillation_amd.networks import sagan_models  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def main():
+    torch.manual_seed(3)
+    D = sagan_models.Discriminator(1, 19, 2, 65, 64).to(DEV).train()
+    with torch.no_grad():
+        D.attn1.gamma.fill_(0.3)
+        D.attn2.gamma.fill_(-0.2)
+    P = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu().clone()) for k, v in D.state_dict().items()}
+    x = torch.randn(2, 19, 65, 65, generator=torch.Generator().manual_seed(4))
+    got = {}
+    hooks = []
+    for name, mod in D.named_modules():
+        if name in ("preprocess_additional", "l1.0", "l1", "l2.0", "l2", "l3.0", "l3", "attn1", "l4.0", "l4", "attn2", "last"):
+            hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: got.__setitem__(name, (o[0] if isinstance(o, tuple) else o).detach().clone())))
+    for mode in ("miopen", "no-miopen"):
+        torch.backends.cudnn.enabled = (mode == "miopen")
+        Pm = {k: v.clone() for k, v in P.items()}
+        Dm = sagan_models.Discriminator(1, 19, 2, 65, 64).to(DEV).train()
+        Dm.load_state_dict(D.state_dict())
+        hooks = []
+        got.clear()
+        for name, mod in Dm.named_modules():
+            if name in ("preprocess_additional", "l1.0", "l1", "l2.0", "l2", "l3.0", "l3", "attn1", "l4.0", "l4", "attn2", "last"):
+                hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: got.__setitem__(name, (o[0] if isinstance(o, tuple) else o).detach().clone())))
+        out = Dm(x.to(DEV))
+        # oracle intermediates
+        want = {}
+        pa = "preprocess_additional."
+        h = F.batch_norm(x.double(), Pm[pa + "running_mean"], Pm[pa + "running_var"], Pm[pa + "weight"], Pm[pa + "bias"], True, 0.1, 1e-5)
+        want["preprocess_additional"] = h
+        for i in (1, 2, 3):
+            pre = "l%d.0.module." % i
+            w = O.spectral_weight(Pm, pre)
+            want["w%d" % i] = w
+            h = F.conv2d(h, w, Pm[pre + "bias"], 2, 1)
+            want["l%d.0" % i] = h
+            h = F.leaky_relu(h, 0.1)
+            want["l%d" % i] = h
+        h, _ = O.self_attn(Pm, "attn1", h)
+        want["attn1"] = h
+        pre = "l4.0.module."
+        w = O.spectral_weight(Pm, pre)
+        want["w4"] = w
+        h = F.conv2d(h, w, Pm[pre + "bias"], 2, 1)
+        want["l4.0"] = h
+        h = F.leaky_relu(h, 0.1)
+        want["l4"] = h
+        h, _ = O.self_attn(Pm, "attn2", h)
+        want["attn2"] = h
+        want["last"] = F.conv2d(h, Pm["last.0.weight"], Pm["last.0.bias"])
+        print("== conv backend:", mode)
+        for k in ("preprocess_additional", "l1.0", "l1", "l2.0", "l2", "l3.0", "l3", "attn1", "l4.0", "l4", "attn2", "last"):
+            print("%-24s rel err %.3e" % (k, rel(got[k], want[k])))
+        for i in (1, 2, 3, 4):
+            mod = getattr(Dm, "l%d" % i)[0].module
+            print("SN weight l%d rel err %.3e   u %.3e v %.3e" % (i, rel(mod.weight, want["w%d" % i]), rel(mod.weight_u, Pm["l%d.0.module.weight_u" % i]),
+                                                                 rel(mod.weight_v, Pm["l%d.0.module.weight_v" % i])))
+        # same conv, same GPU inputs, MIOpen vs fp64 CPU, isolated
+        xin = want["preprocess_additional"].float()
+        y_gpu = F.conv2d(xin.to(DEV), want["w1"].float().to(DEV), Pm["l1.0.module.bias"].float().to(DEV), 2, 1)
+        print("isolated l1 conv on identical inputs: rel err %.3e" % rel(y_gpu, want["l1.0"]))
+
+
+if __name__ == "__main__":
+    main()
