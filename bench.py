@@ -113,6 +113,24 @@ def pairwise_sweep(dev):
     return out
 
 
+def abn_pmc_ratio():
+    """HBM traffic / algorithmic bytes of abn_apply_kernel from the committed rocprofv3 counter passes
+    (profiles/*_abn_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/abn_microbench.py;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  PMC counters cannot
+    be collected from inside this process, so the live line carries the profiled ratio and says where it is from."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_abn_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        row = d["abn_apply_kernel<3, false> grid=4194304"]          # (8, 2048, 65x65): 69.2 M elements, one shape per grid
+        return {"ratio": row["hbm_MB (2*FETCH + WRITE)"] * 1e6 / (8.0 * 8 * 2048 * 4225),
+                "source": os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE of the (8,2048,65,65) launch / its 8 B/elem)"}
+    except Exception:
+        return None
+
+
 def summarise(recs, bytes_per_elem):
     """[(ms, (N,C,S))] -> achieved GB/s over all launches (sum bytes / sum time) + launch stats."""
     if not recs:
@@ -121,6 +139,7 @@ def summarise(recs, bytes_per_elem):
     tot_b = sum(bytes_per_elem * d[0] * d[1] * d[2] for _, d in recs)
     big = [(ms, d) for ms, d in recs if d[0] * d[1] * d[2] >= (1 << 22)]
     out = {"launches": len(recs), "avg_us": round(1e3 * tot_ms / len(recs), 2),
+           "avg_elems": round(tot_b / bytes_per_elem / len(recs)),
            "achieved_GBs": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
     if big:
         bms = sum(ms for ms, _ in big)
@@ -170,7 +189,8 @@ def main():
 
     for i in range(a.warmup):
         step(i)
-    timed = ["skd_abn_apply", "skd_abn_forward_train", "skd_abn_backward", "skd_pixelwise_loss"]
+    timed = ["skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
+             "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx"]
     if not a.no_kernel_timing and rank == 0:
         _lib.enable_kernel_timing(timed)
     fence()
@@ -209,9 +229,18 @@ def main():
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_element": 8, "detail": ap}
+        pmc = abn_pmc_ratio()
+        if pmc is not None:
+            line["roofline"]["traffic"] = round(pmc["ratio"] * 8 * ap["avg_elems"] / 1e6, 2)
+            line["roofline"]["traffic_unit"] = "MB per average launch"
+            line["roofline"]["traffic_source"] = pmc["source"]
         line["kernels"] = {
-            "skd_abn_forward_train (stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
-            "skd_abn_backward (reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),
+            "skd_abn_apply_residual (teacher block tails, 12 B/elem)": summarise(recs.get("skd_abn_apply_residual", []), 12),
+            "skd_abn_forward_train (leaky-ReLU ABN: stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
+            "skd_abn_backward (leaky-ReLU ABN: reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),
+            "skd_abn_forward_train_to (BN+ReLU[+res] fused: stats+finalize+apply, >=12 B/elem)": summarise(recs.get("skd_abn_forward_train_to", []), 12),
+            "skd_abn_relu_backward_reduce (12 B/elem)": summarise(recs.get("skd_abn_relu_backward_reduce", []), 12),
+            "skd_abn_relu_backward_dx (>=16 B/elem)": summarise(recs.get("skd_abn_relu_backward_dx", []), 16),
         }
     if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)

@@ -80,36 +80,45 @@ __global__ __launch_bounds__(kThreads) void ce_rows_kernel(const float *__restri
     const float *pm = lm + (int64_t)b * C * hw;
     const float *pd = TWO ? ld + (int64_t)b * C * hw : nullptr;
     const int64_t *trow = target + ((int64_t)b * H + Y) * W;
-    float gm[CMAX], gd[TWO ? CMAX : 1];
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-      gm[c] = 0.f;
-      if (TWO) gd[c] = 0.f;
-    }
     int Xlo, Xhi;
     dst_range(x, sx, W, Xlo, Xhi);
-    for (int X = Xlo; X <= Xhi; ++X) {
-      const Tap tx = tap_of(X, sx, w);
-      float wt = 0.f;
-      if (tx.i0 == x) wt += tx.l0;
-      if (tx.i1 == x) wt += tx.l1;
-      const bool own = tx.i0 == x;
-      if (wt == 0.f && !own) continue;
-      const int64_t t = trow[X];
-      if (t == (int64_t)ignore_index || t < 0 || t >= C) continue;
-      const int o00 = ty.i0 * w + tx.i0, o01 = ty.i0 * w + tx.i1, o10 = ty.i1 * w + tx.i0, o11 = ty.i1 * w + tx.i1;
-      if (own) cnt += 1.f;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
 #pragma unroll
-      for (int head = 0; head < (TWO ? 2 : 1); ++head) {
-        const float *p = head == 0 ? pm : pd;
+    for (int head = 0; head < (TWO ? 2 : 1); ++head) {
+      const float *p = head == 0 ? pm : pd;
+      // vertical interpolation once per thread: the three source columns x-1, x, x+1 of this row pair
+      float a0[CMAX], a1[CMAX], a2[CMAX], g[CMAX];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+          const float *q = p + (int64_t)c * hw;
+          a0[c] = ty.l0 * q[ty.i0 * w + xm] + ty.l1 * q[ty.i1 * w + xm];
+          a1[c] = ty.l0 * q[ty.i0 * w + x] + ty.l1 * q[ty.i1 * w + x];
+          a2[c] = ty.l0 * q[ty.i0 * w + xp] + ty.l1 * q[ty.i1 * w + xp];
+          g[c] = 0.f;
+        }
+      float loss = 0.f;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        const Tap tx = tap_of(X, sx, w);
+        float wt = 0.f;
+        if (tx.i0 == x) wt += tx.l0;
+        if (tx.i1 == x) wt += tx.l1;
+        const bool own = tx.i0 == x;
+        if (wt == 0.f && !own) continue;
+        if (tx.i0 != x && tx.i0 != x - 1) continue;      // only taps {x-1, x} -> x or {x, x+1} reach column x
+        const int64_t t = trow[X];
+        if (t == (int64_t)ignore_index || t < 0 || t >= C) continue;
+        if (own && head == 0) cnt += 1.f;
+        const bool left = tx.i0 == x - 1 && x > 0;       // taps (x-1, x); otherwise (x, x+1) [or (x, x) at the border]
+        const bool same = tx.i1 == tx.i0;
         float v[CMAX];
         float mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
           if (c < C) {
-            const float *q = p + (int64_t)c * hw;
-            // upsample_bilinear2d: h0l*(w0l*v00 + w1l*v01) + h1l*(w0l*v10 + w1l*v11)
-            v[c] = ty.l0 * (tx.l0 * q[o00] + tx.l1 * q[o01]) + ty.l1 * (tx.l0 * q[o10] + tx.l1 * q[o11]);
+            const float lo = left ? a0[c] : a1[c];
+            const float hi = same ? lo : (left ? a1[c] : a2[c]);
+            v[c] = tx.l0 * lo + tx.l1 * hi;
             mx = fmaxf(mx, v[c]);
           }
         float z = 0.f, vt = 0.f;
@@ -120,30 +129,22 @@ __global__ __launch_bounds__(kThreads) void ce_rows_kernel(const float *__restri
             v[c] = expf(v[c] - mx);
             z += v[c];
           }
-        if (own) {
-          const float nll = logf(z) - vt;
-          if (head == 0) loss_m += nll; else loss_d += nll;
-        }
+        if (own) loss += logf(z) - vt;
         if (rowgrad != nullptr && wt != 0.f) {
-          const float s = wt / z;
+          const float sc = wt / z;
 #pragma unroll
           for (int c = 0; c < CMAX; ++c)
-            if (c < C) {
-              const float g = v[c] * s - (c == (int)t ? wt : 0.f);
-              if (head == 0) gm[c] += g; else gd[c] += g;
-            }
+            if (c < C) g[c] += v[c] * sc - (c == (int)t ? wt : 0.f);
         }
       }
-    }
-    if (rowgrad != nullptr) {
-      const int heads = TWO ? 2 : 1;
-      float *o = rowgrad + (((int64_t)b * heads) * C * H + Y) * w + x;
+      if (head == 0) loss_m = loss; else loss_d = loss;
+      if (rowgrad != nullptr) {
+        const int heads = TWO ? 2 : 1;
+        float *o = rowgrad + ((((int64_t)b * heads + head) * C) * H + Y) * w + x;
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c)
-        if (c < C) {
-          o[(int64_t)c * H * w] = gm[c];
-          if (TWO) o[((int64_t)C + c) * H * w] = gd[c];
-        }
+        for (int c = 0; c < CMAX; ++c)
+          if (c < C) o[(int64_t)c * H * w] = g[c];
+      }
     }
   }
   block_sum2(loss_m, loss_d, red);

@@ -111,31 +111,61 @@ __global__ __launch_bounds__(kThreads) void ppm_pool_kernel(const float *__restr
   }
 }
 
+// One workgroup per plane.  Per level and coordinate, the (<= 2, since H, W >= s) overlapping bins that contain it
+// and their 1/length are tabulated in LDS once; every element then needs 4 levels x (<= 2 x 2) table look-ups
+// instead of re-deriving bin edges with integer divisions.
 __global__ __launch_bounds__(kThreads) void ppm_pool_bwd_kernel(const float *__restrict__ g,
                                                                float *__restrict__ dx, int64_t planes,
                                                                int H, int W, Levels lv) {
-  const int64_t total = planes * H * W;
-  const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (e >= total) return;
-  const int w = (int)(e % W);
-  const int h = (int)((e / W) % H);
-  const int64_t plane = e / ((int64_t)W * H);
-  float acc = 0.f;
-  for (int k = 0; k < lv.n; ++k) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  // layout: gl[lv.bins] | first[L*(H+W)] (int) | count[L*(H+W)] (int) | inv[L*(H+W)*2]
+  const int HWsum = H + W;
+  float *gl = sm;
+  int *first = reinterpret_cast<int *>(sm + lv.bins);
+  int *count = first + lv.n * HWsum;
+  float *inv = reinterpret_cast<float *>(count + lv.n * HWsum);
+  const int64_t plane = blockIdx.x;
+  for (int o = threadIdx.x; o < lv.bins; o += kThreads) {
+    int k = 0;
+    while (k + 1 < lv.n && o >= lv.bin_off[k + 1]) ++k;
+    gl[o] = g[planes * lv.bin_off[k] + plane * (lv.size[k] * lv.size[k]) + (o - lv.bin_off[k])];
+  }
+  for (int o = threadIdx.x; o < lv.n * HWsum; o += kThreads) {
+    const int k = o / HWsum, pos = o - k * HWsum;
     const int s = lv.size[k];
-    const float *gk = g + planes * lv.bin_off[k] + plane * (s * s);
-    const int ia = (h * s) / H, ja = (w * s) / W;
-    for (int i = max(0, ia - 1); i <= min(s - 1, ia + 1); ++i) {
-      const int h0 = bin_start(i, H, s), h1 = bin_end(i, H, s);
-      if (h < h0 || h >= h1) continue;
-      for (int j = max(0, ja - 1); j <= min(s - 1, ja + 1); ++j) {
-        const int w0 = bin_start(j, W, s), w1 = bin_end(j, W, s);
-        if (w < w0 || w >= w1) continue;
-        acc += gk[i * s + j] / (float)((h1 - h0) * (w1 - w0));
+    const int n = pos < H ? H : W;            // rows first, then columns
+    const int c = pos < H ? pos : pos - H;
+    const int ia = (c * s) / n;
+    int f = ia;
+    if (ia > 0 && c < bin_end(ia - 1, n, s)) f = ia - 1;
+    int cnt = 1;
+    if (f + 1 < s && c >= bin_start(f + 1, n, s)) cnt = 2;
+    first[o] = f;
+    count[o] = cnt;
+    inv[2 * o] = 1.f / (float)(bin_end(f, n, s) - bin_start(f, n, s));
+    inv[2 * o + 1] = cnt == 2 ? 1.f / (float)(bin_end(f + 1, n, s) - bin_start(f + 1, n, s)) : 0.f;
+  }
+  __syncthreads();
+  float *out = dx + plane * (int64_t)H * W;
+  for (int e = threadIdx.x; e < H * W; e += kThreads) {
+    const int h = e / W, w = e - h * W;
+    float acc = 0.f;
+    for (int k = 0; k < lv.n; ++k) {
+      const int s = lv.size[k];
+      const int ro = k * HWsum + h, co = k * HWsum + H + w;
+      const float *gk = gl + lv.bin_off[k];
+      const int i0 = first[ro], j0 = first[co];
+      float t = gk[i0 * s + j0] * inv[2 * co];
+      if (count[co] == 2) t += gk[i0 * s + j0 + 1] * inv[2 * co + 1];
+      acc += t * inv[2 * ro];
+      if (count[ro] == 2) {
+        float u = gk[(i0 + 1) * s + j0] * inv[2 * co];
+        if (count[co] == 2) u += gk[(i0 + 1) * s + j0 + 1] * inv[2 * co + 1];
+        acc += u * inv[2 * ro + 1];
       }
     }
+    out[e] = acc;
   }
-  dx[e] = acc;
 }
 
 struct PriorPtrs {
@@ -247,9 +277,11 @@ int skd_ppm_pool_backward(int planes, int H, int W, int nsizes, const int *sizes
                           float *dx, skd_stream_t stream) {
   Levels lv;
   if (planes <= 0 || H <= 0 || W <= 0 || !gpooled || !dx || !make_levels(nsizes, sizes, lv)) return 0;
-  const int64_t total = (int64_t)planes * H * W;
-  ppm_pool_bwd_kernel<<<dim3((unsigned)cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream)>>>(
-      gpooled, dx, planes, H, W, lv);
+  for (int k = 0; k < nsizes; ++k)
+    if (sizes[k] > H || sizes[k] > W) return 0;  // a pixel would sit in more than two overlapping bins
+  const size_t smem = sizeof(float) * ((size_t)lv.bins + (size_t)lv.n * (H + W) * 4);
+  if (smem > 64 * 1024) return 0;
+  ppm_pool_bwd_kernel<<<dim3((unsigned)planes), dim3(kThreads), smem, as_stream(stream)>>>(gpooled, dx, planes, H, W, lv);
   return ok();
 }
 

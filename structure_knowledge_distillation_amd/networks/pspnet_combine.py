@@ -109,7 +109,8 @@ class PSPModule(nn.Module):
         for stage in self.stages:
             o = stage[0].output_size
             sizes.append(o[0] if isinstance(o, (tuple, list)) else o)
-        if feats.dtype == torch.float32 and len(sizes) <= 4 and feats.size(3) <= 256:
+        if (feats.dtype == torch.float32 and len(sizes) <= 4 and feats.size(3) <= 256
+                and min(feats.size(2), feats.size(3)) >= max(sizes)):
             # csrc/ppm.hip: every pyramid level from one read of feats; priors up-sampled straight into the
             # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
             pooled = SF.ppm_pool(feats, sizes)
