@@ -115,6 +115,12 @@ int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *o
                              const float *mean, const float *var, const float *weight, const float *edz,
                              const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
                              float eps, skd_stream_t stream);
+/* inference form for channels-last (NHWC) tensors: x is (rows = N*H*W, C) row-major, C % 4 == 0;
+ * x <- act(bn(x) [+ residual]) in place (residual may be NULL, same layout).  Lets the frozen teacher run its
+ * MIOpen convolutions NHWC-native. */
+int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, const float *mean,
+                       const float *var, const float *weight, const float *bias, float eps, int activation,
+                       float slope, skd_stream_t stream);
 /* running-stat update with an explicit sample count n (functions.py:209) */
 int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
                            const float *var, float momentum, double n, skd_stream_t stream);

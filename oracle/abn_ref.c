@@ -356,3 +356,19 @@ int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *o
   }
   return 1;
 }
+
+/* ---- inference BN -> (+residual) -> activation on a channels-last (rows, C) tensor ---- */
+int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, const float *mean, const float *var,
+                       const float *weight, const float *bias, float eps, int act, float slope, stream_t st) {
+  (void)st;
+  if (rows <= 0 || C <= 0 || (C & 3) || !x) return 0;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) {
+      const float y = (x[r * C + c] - mean[c]) * inv_std_of(var[c], eps);            /* bn.cu:158 */
+      float z = y * gamma_of(weight, c, eps) + beta_of(bias, c);                     /* bn.cu:159 */
+      if (residual) z = z + residual[r * C + c];
+      x[r * C + c] = z;
+    }
+  act_forward(act, rows * C, x, slope);
+  return 1;
+}

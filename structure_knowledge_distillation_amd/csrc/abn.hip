@@ -16,10 +16,40 @@
 //     activation in registers (z is never rewritten) and fuses it into both backward passes.
 // Algorithmic bytes/element (fp32): train fwd 12 (R,R,W), train bwd 20 (R z,dz; R z,dz, W dx),
 // eval fwd 8 -- versus 16-24 / 20-40 for the reference launch sequence.
+#include <stdlib.h>
+
 #include "skd_common.hpp"
 
 namespace skd {
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte global access with an optional non-temporal (streaming) cache policy.  Measured HBM-cold on MI355X
+// (tools/abn_microbench.py cold): nt loads AND nt stores together lift the in-place apply pass from 4.6-5.4 to
+// 4.9-6.0 TB/s when every tensor comes from HBM (PyTorch's own copy_/relu_ reach 5.2-5.9); either alone does
+// nothing.  INSIDE the training step, however, the convolution output is still partly in the Infinity Cache
+// when the apply pass reads it, and the same policy LOWERS the pass from 4.70 to 4.22 TB/s (bench.py A/B) --
+// so the default stays "normal" and SKD_ABN_NT (bit 0 loads, bit 1 stores) is an experiment switch.
+__device__ __forceinline__ float4 ldg4(const float *p, bool nt) {
+  if (nt) {
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ void stg4(float *p, float4 v, bool nt) {
+  if (nt) {
+    f32x4 t;
+    t[0] = v.x;
+    t[1] = v.y;
+    t[2] = v.z;
+    t[3] = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p));
+  } else {
+    *reinterpret_cast<float4 *>(p) = v;
+  }
+}
 
 constexpr int kChunk = 8192;  // max floats per workgroup run (32 KiB)
 
@@ -218,6 +248,7 @@ struct ApplyOp {
   const float *xin;
   float *yout, *zout;
   float mean, inv_std, gamma, beta, slope;
+  int nt;  // bit 0: non-temporal loads, bit 1: non-temporal stores (streaming data is touched exactly once)
   __device__ __forceinline__ float one(float v, float &y) const {
     y = (v - mean) * inv_std;  // bn.cu:158
     return act_fwd<ACT>(y * gamma + beta, slope);  // bn.cu:159 (+ fused K5/K7)
@@ -230,7 +261,7 @@ struct ApplyOp {
     zout[i] = z;
   }
   __device__ __forceinline__ float4 ld4(int i) const {
-    return *reinterpret_cast<const float4 *>(xin + i);
+    return ldg4(xin + i, nt & 1);
   }
   __device__ __forceinline__ void use4(int i, float4 v) const {
     float4 y, z;
@@ -239,7 +270,7 @@ struct ApplyOp {
     z.z = one(v.z, y.z);
     z.w = one(v.w, y.w);
     if (WRITE_Y) *reinterpret_cast<float4 *>(yout + i) = y;
-    *reinterpret_cast<float4 *>(zout + i) = z;
+    stg4(zout + i, z, nt & 2);
   }
 };
 
@@ -249,13 +280,14 @@ struct ApplyResOp {
   const float *xin, *rin;
   float *zout;
   float mean, inv_std, gamma, beta, slope;
+  int nt;
   __device__ __forceinline__ float one(float v, float r) const {
     return act_fwd<ACT>(((v - mean) * inv_std) * gamma + beta + r, slope);
   }
   __device__ __forceinline__ F1x2 ld1(int i) const { return F1x2{xin[i], rin[i]}; }
   __device__ __forceinline__ void use1(int i, F1x2 v) const { zout[i] = one(v.a, v.b); }
   __device__ __forceinline__ F4x2 ld4(int i) const {
-    return F4x2{*reinterpret_cast<const float4 *>(xin + i), *reinterpret_cast<const float4 *>(rin + i)};
+    return F4x2{ldg4(xin + i, nt & 1), ldg4(rin + i, nt & 1)};
   }
   __device__ __forceinline__ void use4(int i, F4x2 v) const {
     float4 z;
@@ -263,7 +295,7 @@ struct ApplyResOp {
     z.y = one(v.a.y, v.b.y);
     z.z = one(v.a.z, v.b.z);
     z.w = one(v.a.w, v.b.w);
-    *reinterpret_cast<float4 *>(zout + i) = z;
+    stg4(zout + i, z, nt & 2);
   }
 };
 
@@ -271,12 +303,13 @@ template <int ACT, bool WRITE_Y>
 __global__ __launch_bounds__(kThreads) void abn_apply_kernel(
     const float *x, const float *__restrict__ mean, const float *__restrict__ var,
     const float *__restrict__ weight, const float *__restrict__ bias, float *y, float *z, float eps,
-    float slope, int N, int C, int S, Plan pl, int reverse) {
+    float slope, int N, int C, int S, Plan pl, int reverse, int nt) {
   // `reverse`: walk the items backwards so that a pass that follows the statistics pass starts
   // on the lines that pass touched last (still resident in L2 / Infinity Cache).
   const int64_t w = reverse ? (pl.items - 1 - (int64_t)blockIdx.x) : (int64_t)blockIdx.x;
   const Item it = decode(w, N, C, S, pl);
   ApplyOp<ACT, WRITE_Y> op;
+  op.nt = nt;
   op.mean = mean[it.c];
   op.inv_std = inv_std_of(var[it.c], eps);
   op.gamma = gamma_of(weight, it.c, eps);
@@ -295,9 +328,10 @@ template <int ACT>
 __global__ __launch_bounds__(kThreads) void abn_apply_residual_kernel(
     const float *x, const float *res, const float *__restrict__ mean, const float *__restrict__ var,
     const float *__restrict__ weight, const float *__restrict__ bias, float *z, float eps, float slope,
-    int N, int C, int S, Plan pl) {
+    int N, int C, int S, Plan pl, int nt) {
   const Item it = decode(blockIdx.x, N, C, S, pl);
   ApplyResOp<ACT> op;
+  op.nt = nt;
   op.mean = mean[it.c];
   op.inv_std = inv_std_of(var[it.c], eps);
   op.gamma = gamma_of(weight, it.c, eps);
@@ -309,6 +343,57 @@ __global__ __launch_bounds__(kThreads) void abn_apply_residual_kernel(
     op.rin = res + off;
     op.zout = z + off;
     stream_run(reinterpret_cast<uintptr_t>(op.xin), it.len, op);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Inference BN -> (+ residual) -> activation for channels-last (NHWC) tensors: x is (rows = N*H*W, C) row-major,
+// the channel is the fastest dimension, so every thread keeps ONE channel quad's parameters in registers and
+// streams rows with 16-byte accesses.  Used by the frozen teacher, whose convolutions run NHWC-native in MIOpen
+// (no NCHW<->NHWC transposes around the igemm kernels).  C must be a multiple of 4.
+// ---------------------------------------------------------------------------------------------
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void abn_apply_nhwc_kernel(float *x, const float *res,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ var,
+                                                                 const float *__restrict__ weight,
+                                                                 const float *__restrict__ bias, float eps,
+                                                                 float slope, int64_t quads, int C4) {
+  // total threads is a multiple of C4, so a thread's channel quad never changes while it strides
+  const int64_t T = (int64_t)gridDim.x * kThreads;
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int c = (int)(t % C4) * 4;
+  float m[4], is[4], g[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = mean[c + k];
+    is[k] = inv_std_of(var[c + k], eps);
+    g[k] = gamma_of(weight, c + k, eps);
+    b[k] = beta_of(bias, c + k);
+  }
+  for (int64_t q = t; q < quads; q += 4 * T) {
+    float4 v[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t qq = q + u * T;
+      if (qq < quads) {
+        v[u] = *reinterpret_cast<const float4 *>(x + 4 * qq);
+        if (HAS_RES) r[u] = *reinterpret_cast<const float4 *>(res + 4 * qq);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t qq = q + u * T;
+      if (qq < quads) {
+        float4 z;
+        z.x = act_fwd<ACT>(((v[u].x - m[0]) * is[0]) * g[0] + b[0] + (HAS_RES ? r[u].x : 0.f), slope);
+        z.y = act_fwd<ACT>(((v[u].y - m[1]) * is[1]) * g[1] + b[1] + (HAS_RES ? r[u].y : 0.f), slope);
+        z.z = act_fwd<ACT>(((v[u].z - m[2]) * is[2]) * g[2] + b[2] + (HAS_RES ? r[u].z : 0.f), slope);
+        z.w = act_fwd<ACT>(((v[u].w - m[3]) * is[3]) * g[3] + b[3] + (HAS_RES ? r[u].w : 0.f), slope);
+        *reinterpret_cast<float4 *>(x + 4 * qq) = z;
+      }
+    }
   }
 }
 
@@ -397,6 +482,7 @@ struct GradDxOp {
   const float *z, *dz;
   float *dx;
   float beta, gamma, slope, inv_slope, edz, eydz, mul;
+  int nt;
   __device__ __forceinline__ float one(float zv, float dzv) const {
     act_undo<ACT>(zv, dzv, slope, inv_slope);
     const float y = (zv - beta) / gamma;   // bn.cu:208
@@ -405,7 +491,8 @@ struct GradDxOp {
   __device__ __forceinline__ F1x2 ld1(int i) const { return F1x2{z[i], dz[i]}; }
   __device__ __forceinline__ void use1(int i, F1x2 v) const { dx[i] = one(v.a, v.b); }
   __device__ __forceinline__ F4x2 ld4(int i) const {
-    return F4x2{*reinterpret_cast<const float4 *>(z + i), *reinterpret_cast<const float4 *>(dz + i)};
+    // z is the saved forward output (the next layer's backward may still want it): normal load; dz is dead after this
+    return F4x2{*reinterpret_cast<const float4 *>(z + i), ldg4(dz + i, nt & 1)};
   }
   __device__ __forceinline__ void use4(int i, F4x2 v) const {
     float4 r;
@@ -413,7 +500,7 @@ struct GradDxOp {
     r.y = one(v.a.y, v.b.y);
     r.z = one(v.a.z, v.b.z);
     r.w = one(v.a.w, v.b.w);
-    *reinterpret_cast<float4 *>(dx + i) = r;
+    stg4(dx + i, r, nt & 2);
   }
 };
 
@@ -422,10 +509,11 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_kernel(
     const float *z, const float *dz, const float *__restrict__ var,
     const float *__restrict__ weight, const float *__restrict__ bias,
     const float *__restrict__ edz, const float *__restrict__ eydz, float *dx, float *dweight,
-    float *dbias, float eps, float slope, int N, int C, int S, Plan pl, int reverse) {
+    float *dbias, float eps, float slope, int N, int C, int S, Plan pl, int reverse, int apply_nt) {
   const int64_t w = reverse ? (pl.items - 1 - (int64_t)blockIdx.x) : (int64_t)blockIdx.x;
   const Item it = decode(w, N, C, S, pl);
   GradDxOp<ACT> op;
+  op.nt = apply_nt;
   op.gamma = gamma_of(weight, it.c, eps);
   op.beta = beta_of(bias, it.c);
   op.slope = slope;
@@ -525,6 +613,7 @@ struct ReluGradDxOp {
   const float *x, *out, *dout;
   float *dx, *dres;
   float mean, inv_std, edz, eydz, mul;
+  int nt;
   __device__ __forceinline__ float one(float xv, float ov, float dv, float &dz) const {
     dz = ov > 0.f ? dv : 0.f;
     const float y = (xv - mean) * inv_std;
@@ -537,8 +626,8 @@ struct ReluGradDxOp {
     if (WRITE_RES) dres[i] = dz;
   }
   __device__ __forceinline__ F4x3 ld4(int i) const {
-    return F4x3{*reinterpret_cast<const float4 *>(x + i), *reinterpret_cast<const float4 *>(out + i),
-                *reinterpret_cast<const float4 *>(dout + i)};
+    // x, out and dout are all read for the last time here
+    return F4x3{ldg4(x + i, nt & 1), ldg4(out + i, nt & 1), ldg4(dout + i, nt & 1)};
   }
   __device__ __forceinline__ void use4(int i, F4x3 v) const {
     float4 r, d;
@@ -546,8 +635,8 @@ struct ReluGradDxOp {
     r.y = one(v.a.y, v.b.y, v.c.y, d.y);
     r.z = one(v.a.z, v.b.z, v.c.z, d.z);
     r.w = one(v.a.w, v.b.w, v.c.w, d.w);
-    *reinterpret_cast<float4 *>(dx + i) = r;
-    if (WRITE_RES) *reinterpret_cast<float4 *>(dres + i) = d;
+    stg4(dx + i, r, nt & 2);
+    if (WRITE_RES) stg4(dres + i, d, nt & 2);
   }
 };
 
@@ -556,10 +645,11 @@ __global__ __launch_bounds__(kThreads) void abn_relu_grad_dx_kernel(
     const float *x, const float *out, const float *dout, const float *__restrict__ mean,
     const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ edz,
     const float *__restrict__ eydz, float *dx, float *dres, float *dweight, float *dbias, float eps, int N, int C,
-    int S, Plan pl) {
+    int S, Plan pl, int apply_nt) {
   const int64_t w = pl.items - 1 - (int64_t)blockIdx.x;  // start on the lines the reduce pass touched last
   const Item it = decode(w, N, C, S, pl);
   ReluGradDxOp<WRITE_RES> op;
+  op.nt = apply_nt;
   op.mean = mean[it.c];
   op.inv_std = inv_std_of(var[it.c], eps);
   op.edz = edz[it.c];
@@ -641,6 +731,16 @@ static bool same_phase(const void *a, const void *b) {
   return ((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
+// Cache policy of the apply pass (SKD_ABN_NT: bit 0 non-temporal loads, bit 1 non-temporal stores).
+static int apply_nt_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("SKD_ABN_NT");
+    mode = e != nullptr ? atoi(e) & 3 : 0;
+  }
+  return mode;
+}
+
 template <bool WRITE_Y>
 static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x, const float *mean,
                          const float *var, const float *weight, const float *bias, float *y, float *z,
@@ -648,17 +748,49 @@ static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x
   const dim3 grid((unsigned)pl.items), block(kThreads);
   switch (act) {
     case SKD_ACT_LEAKY_RELU:
-      abn_apply_kernel<SKD_ACT_LEAKY_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      abn_apply_kernel<SKD_ACT_LEAKY_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse, apply_nt_mode());
       break;
     case SKD_ACT_ELU:
-      abn_apply_kernel<SKD_ACT_ELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      abn_apply_kernel<SKD_ACT_ELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse, apply_nt_mode());
       break;
     case SKD_ACT_RELU:
-      abn_apply_kernel<SKD_ACT_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      abn_apply_kernel<SKD_ACT_RELU, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse, apply_nt_mode());
       break;
     default:
-      abn_apply_kernel<SKD_ACT_NONE, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse);
+      abn_apply_kernel<SKD_ACT_NONE, WRITE_Y><<<grid, block, 0, st>>>(x, mean, var, weight, bias, y, z, eps, slope, N, C, S, pl, reverse, apply_nt_mode());
   }
+}
+
+template <bool HAS_RES>
+static int launch_apply_nhwc(int64_t rows, int C, float *x, const float *res, const float *mean, const float *var,
+                             const float *weight, const float *bias, float eps, int act, float slope, hipStream_t st) {
+  const int C4 = C / 4;
+  const int64_t quads = rows * C4;
+  // threads = a multiple of lcm(C4, 256), about quads / 4 (four 16-byte accesses in flight per thread)
+  int64_t unit = C4;
+  while (unit % kThreads != 0) unit *= 2;          // C4 = 16 * 2^k on this path; general C4: unit = lcm below
+  if (unit % C4 != 0 || unit > (1 << 20)) {         // non power-of-two channel counts
+    unit = (int64_t)C4 * kThreads;
+  }
+  int64_t threads = cdiv(cdiv(quads, 4), unit) * unit;
+  const int64_t cap = cdiv((int64_t)256 * 8 * kThreads, unit) * unit;   // ~8 workgroups per CU, then stride
+  if (threads > cap) threads = cap;
+  if (threads < unit) threads = unit;
+  const dim3 grid((unsigned)(threads / kThreads)), block(kThreads);
+  switch (act) {
+    case SKD_ACT_NONE:
+      abn_apply_nhwc_kernel<SKD_ACT_NONE, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      break;
+    case SKD_ACT_LEAKY_RELU:
+      abn_apply_nhwc_kernel<SKD_ACT_LEAKY_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      break;
+    case SKD_ACT_RELU:
+      abn_apply_nhwc_kernel<SKD_ACT_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      break;
+    default:
+      return 0;
+  }
+  return ok();
 }
 
 static int valid_dims(int N, int C, int S) { return N > 0 && C > 0 && S > 0; }
@@ -714,13 +846,13 @@ int skd_abn_apply_residual(int N, int C, int S, float *x, const float *residual,
   hipStream_t st = as_stream(stream);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_apply_residual_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     case SKD_ACT_RELU:
-      abn_apply_residual_kernel<SKD_ACT_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     case SKD_ACT_NONE:
-      abn_apply_residual_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, x, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     default:
       return 0;
@@ -780,13 +912,13 @@ int skd_abn_backward_dx(int N, int C, int S, const float *z, const float *dz, co
   const dim3 grid((unsigned)pl.items), block(kThreads);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_grad_dx_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+      abn_grad_dx_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1, apply_nt_mode());
       break;
     case SKD_ACT_ELU:
-      abn_grad_dx_kernel<SKD_ACT_ELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+      abn_grad_dx_kernel<SKD_ACT_ELU><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1, apply_nt_mode());
       break;
     default:
-      abn_grad_dx_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1);
+      abn_grad_dx_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, slope, N, C, S, pl, 1, apply_nt_mode());
   }
   return ok();
 }
@@ -810,6 +942,17 @@ int skd_abn_backward(int N, int C, int S, const float *z, const float *dz, const
 }
 
 
+
+int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, const float *mean, const float *var,
+                       const float *weight, const float *bias, float eps, int activation, float slope,
+                       skd_stream_t stream) {
+  if (rows <= 0 || C <= 0 || (C & 3) || !x || !mean || !var) return 0;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (residual && (reinterpret_cast<uintptr_t>(residual) & 15))) return 0;
+  hipStream_t st = as_stream(stream);
+  return residual ? launch_apply_nhwc<true>(rows, C, x, residual, mean, var, weight, bias, eps, activation, slope, st)
+                  : launch_apply_nhwc<false>(rows, C, x, residual, mean, var, weight, bias, eps, activation, slope, st);
+}
+
 // ---- out-of-place BN -> (+residual) -> activation (the training-time ReLU fusion) ------------------------
 
 static int launch_apply_to(int N, int C, int S, const float *x, const float *residual, float *out,
@@ -823,13 +966,13 @@ static int launch_apply_to(int N, int C, int S, const float *x, const float *res
   const dim3 grid((unsigned)pl.items), block(kThreads);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_apply_residual_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_LEAKY_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     case SKD_ACT_RELU:
-      abn_apply_residual_kernel<SKD_ACT_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_RELU><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     case SKD_ACT_NONE:
-      abn_apply_residual_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl);
+      abn_apply_residual_kernel<SKD_ACT_NONE><<<grid, block, 0, st>>>(x, residual, mean, var, weight, bias, out, eps, slope, N, C, S, pl, apply_nt_mode());
       break;
     default:
       return 0;
@@ -886,9 +1029,9 @@ int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *o
   const dim3 grid((unsigned)pl.items), block(kThreads);
   hipStream_t st = as_stream(stream);
   if (dres != nullptr)
-    abn_relu_grad_dx_kernel<true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl);
+    abn_relu_grad_dx_kernel<true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl, apply_nt_mode());
   else
-    abn_relu_grad_dx_kernel<false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl);
+    abn_relu_grad_dx_kernel<false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl, apply_nt_mode());
   return ok();
 }
 

@@ -298,11 +298,25 @@ def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activa
         act = _EVAL_ACT_CODE[activation]
     except KeyError:
         raise ValueError("unknown activation %r" % (activation,))
-    _check_contiguous(x, weight, bias, running_mean, running_var)
     if x.numel() == 0:
         return x
-    n, c, s = _dims(x)
     lib, st = _lib.get(), _lib.stream_of(x)
+    if (x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[1] % 4 == 0):
+        # channels-last (NHWC) activations: the frozen teacher's MIOpen convolutions run NHWC-native
+        _check_contiguous(weight, bias, running_mean, running_var)
+        if residual is not None:
+            if residual.shape != x.shape:
+                raise ValueError("residual shape %s != input shape %s" % (tuple(residual.shape), tuple(x.shape)))
+            if not residual.is_contiguous(memory_format=torch.channels_last) or residual.is_contiguous():
+                residual = residual.contiguous(memory_format=torch.channels_last)
+        rows = x.shape[0] * x.shape[2] * x.shape[3]
+        _lib.check(lib.skd_abn_apply_nhwc(rows, x.shape[1], x.data_ptr(), _lib.ptr(residual), running_mean.data_ptr(),
+                                          running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), float(eps), act,
+                                          float(slope), st), "skd_abn_apply_nhwc")
+        return x
+    _check_contiguous(x, weight, bias, running_mean, running_var)
+    n, c, s = _dims(x)
     if residual is None:
         _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                                      _lib.ptr(weight), _lib.ptr(bias), float(eps), act, float(slope), st),

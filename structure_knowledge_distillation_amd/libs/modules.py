@@ -93,6 +93,8 @@ class InPlaceABN(_ABNBase):
         super().__init__(num_features, eps, momentum, affine, activation, slope)
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            return self.fused_eval(x, self.activation)      # inference: no autograd node, NCHW or NHWC
         return inplace_abn(x, self.weight, self.bias, self.running_mean, self.running_var,
                            self.training, self.momentum, self.eps, self.activation, self.slope)
 
@@ -107,6 +109,8 @@ class InPlaceABNSync(_ABNBase):
         self.devices = list(devices) if devices else []
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            return self.fused_eval(x, self.activation)      # inference: no autograd node, NCHW or NHWC
         extra = {"group": _sync_group["group"]} if _sync_group["explicit"] else None
         return inplace_abn_sync(x, self.weight, self.bias, self.running_mean, self.running_var,
                                 extra, self.training, self.momentum, self.eps, self.activation,

@@ -102,6 +102,13 @@ class NetModel():
         print_model_parm_nums(teacher, "teacher_model")
         for p in teacher.parameters():
             p.requires_grad_(False)
+        # The frozen teacher runs channels-last: MIOpen's fastest fp32 kernels on gfx950 are NHWC igemm kernels, and
+        # with NCHW tensors MIOpen wraps each of them in NCHW<->NHWC transposes (5.6 ms per step, profiles/).  Its
+        # eval-mode BN (+ReLU, +residual) has an NHWC kernel (skd_abn_apply_nhwc); the student stays NCHW.
+        self.teacher_nhwc = (os.environ.get("SKD_TEACHER_NHWC", "1") == "1" and torch.device(device).type == "cuda")
+        if self.teacher_nhwc:
+            os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
+            teacher.to(memory_format=torch.channels_last)
         self.parallel_teacher = self.DataParallelModelProcess(teacher, 2, "eval", device)
         self.teacher = teacher
 
@@ -179,7 +186,10 @@ class NetModel():
     def forward(self):
         args = self.args
         with torch.no_grad():
-            self.preds_T = self.parallel_teacher.eval()(self.images, parallel=args.parallel)
+            images_T = self.images.contiguous(memory_format=torch.channels_last) if self.teacher_nhwc else self.images
+            preds_T = self.parallel_teacher.eval()(images_T, parallel=args.parallel)
+            # the three entries the criteria / D read are handed on in the reference's NCHW layout
+            self.preds_T = [t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
         self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
 
     def student_backward(self):

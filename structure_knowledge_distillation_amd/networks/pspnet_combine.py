@@ -113,6 +113,8 @@ class PSPModule(nn.Module):
                 and min(feats.size(2), feats.size(3)) >= max(sizes)):
             # csrc/ppm.hip: every pyramid level from one read of feats; priors up-sampled straight into the
             # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
+            if not feats.is_contiguous():
+                feats = feats.contiguous()     # channels-last teacher features: the PPM kernels work on NCHW planes
             pooled = SF.ppm_pool(feats, sizes)
             priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
             return self.bottleneck(SF.ppm_concat(priors, feats))

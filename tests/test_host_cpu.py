@@ -213,3 +213,30 @@ def test_abn_relu_training_fusion_vs_autograd():
             assert rel(rg.grad, ro.grad) < 1e-5
     with pytest.raises(ValueError):
         libs.InPlaceABNSync(5, activation="leaky_relu").forward_relu(torch.randn(2, 5, 3, 3))
+
+
+def test_channels_last_inference_abn_and_teacher():
+    """NHWC inference path (skd_abn_apply_nhwc through the C double): same numbers as the NCHW path."""
+    from structure_knowledge_distillation_amd import libs
+    from structure_knowledge_distillation_amd.networks import pspnet_combine as PC
+    torch.manual_seed(12)
+    mod = libs.InPlaceABNSync(8, activation="none").eval()
+    with torch.no_grad():
+        mod.running_mean.normal_(0, 0.3); mod.running_var.uniform_(0.5, 1.5); mod.weight.normal_(0, 1); mod.bias.normal_(0, 0.2)
+        x, r = torch.randn(2, 8, 5, 7), torch.randn(2, 8, 5, 7)
+        for act, res in (("relu", None), ("relu", r), ("none", None), ("leaky_relu", r)):
+            want = mod.fused_eval(x.clone(), act, res)
+            xl = x.clone().contiguous(memory_format=torch.channels_last)
+            got = mod.fused_eval(xl, act, res)          # residual given in NCHW: converted internally
+            assert got.data_ptr() == xl.data_ptr() and got.is_contiguous(memory_format=torch.channels_last)
+            assert rel(got, want) < 1e-6
+        net = PC.Res_pspnet(PC.Bottleneck, [3, 4, 23, 3], 19).eval()
+        for m in net.modules():
+            if isinstance(m, PC.InPlaceABNSync):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.normal_(0, 1); m.bias.normal_(0, 0.2)
+        img = torch.randn(1, 3, 65, 49) * 57
+        want = net(img)
+        net.to(memory_format=torch.channels_last)
+        got = net(img.contiguous(memory_format=torch.channels_last))
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and rel(a, b) < 1e-5

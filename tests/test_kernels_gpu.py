@@ -204,6 +204,23 @@ def test_abn_relu_training_fusion(hip, ref, shape, with_res):
         assert torch.equal(drg.cpu(), drr), "dres = dout * (out > 0), exact"
 
 
+@pytest.mark.parametrize("rows,C", [(35, 8), (8 * 65 * 65, 256), (2 * 129 * 129, 64), (1000, 2048), (7, 20), (4225, 48)])
+@pytest.mark.parametrize("act", [0, 1, 3])
+def test_abn_apply_nhwc(hip, ref, rows, C, act):
+    """Channels-last inference BN -> (+residual) -> activation (the frozen teacher's layout)."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + torch.randn(1, C, generator=g) * 5
+    r = torch.randn(rows, C, generator=g)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    for res in (None, r):
+        xr, xg = x.clone(), gpu(x)
+        assert ref.skd_abn_apply_nhwc(rows, C, P(xr), P(res), P(rm), P(rv), P(w), P(b), 1e-5, act, 0.01, None)
+        assert hip.skd_abn_apply_nhwc(rows, C, P(xg), P(gpu(res)), P(gpu(rm)), P(gpu(rv)), P(gpu(w)), P(gpu(b)), 1e-5, act, 0.01, None)
+        close(xg, xr, 2e-5, "nhwc apply")
+    assert hip.skd_abn_apply_nhwc(rows, 6, P(gpu(x)), None, P(gpu(rm)), P(gpu(rv)), None, None, 1e-5, 0, 0.01, None) == 0   # C % 4
+
+
 def test_abn_legacy_entries(hip, ref):
     """The nine reference exports (libs/src/bn.h:7-19) with their original argument lists."""
     N, C, S = 3, 6, 257

@@ -69,7 +69,8 @@ def cold():
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
-    for (N, C, S) in ((8, 512, 4225), (8, 2048, 4225), (8, 64, 65536), (8, 256, 16641)):
+    print(json.dumps({"SKD_ABN_NT": os.environ.get("SKD_ABN_NT", "0")}), flush=True)
+    for (N, C, S) in ((8, 512, 4225), (8, 2048, 4225), (8, 64, 65536)):
         n = max(2, int(1.5e9 // (N * C * S * 4)) + 1)
         xs = [torch.randn(N, C, S, device=dev) for _ in range(n)]
         rs = [torch.randn(N, C, S, device=dev) for _ in range(2)]
@@ -79,7 +80,10 @@ def cold():
         ws = torch.empty(lib.skd_abn_workspace_floats(N, C, S), device=dev)
         p = lambda t: t.data_ptr()
         row = {}
+        ys = [torch.empty_like(xs[0]) for _ in range(2)]
         for name, bpe, fn in (
+                ("torch copy_(8B)", 8, lambda x: ys[0].copy_(x)),
+                ("torch relu_(8B)", 8, lambda x: torch.relu_(x)),
                 ("apply_eval(8B)", 8, lambda x: lib.skd_abn_apply(N, C, S, p(x), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
                 ("stats(4B)", 4, lambda x: lib.skd_abn_stats(N, C, S, p(x), p(m), p(v), p(ws), st)),
                 ("forward_train(12B)", 12, lambda x: lib.skd_abn_forward_train(N, C, S, p(x), p(w), p(b), None, None, p(m), p(v), 0.1, 1e-5, 0, 0.01, p(ws), st))):

@@ -17,6 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASES = {  # name: (batch, find, what, timeout_s)
     "teacher8": (8, True, "teacher", 500),
+    "teacher8_nhwc": (8, True, "teacher_nhwc", 500),
     "student8": (8, True, "student", 900),
     "full8": (8, True, "full", 400),
     "full2": (2, False, "full", 400),
@@ -27,6 +28,7 @@ def child(phase):
     sys.path.insert(0, ROOT)
     batch, find, what, _ = PHASES[phase]
     os.environ["SKD_MIOPEN_FIND"] = "1" if find else "0"
+    os.environ["SKD_TEACHER_NHWC"] = "1" if what == "teacher_nhwc" else os.environ.get("SKD_TEACHER_NHWC", "0")
     import torch
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     dev = torch.device("cuda", 0)
@@ -37,9 +39,10 @@ def child(phase):
     x = torch.randn(batch, 3, 512, 512, device=dev) * 57
     y = torch.randint(0, 19, (batch, 512, 512), device=dev)
     model.set_input((x, y, None, None))
-    if what == "teacher":
-        with torch.no_grad():
-            model.parallel_teacher.eval()(model.images)
+    if what in ("teacher", "teacher_nhwc"):
+        with torch.no_grad():      # the teacher's problems only (the student forward is already in the db)
+            imgs = model.images.contiguous(memory_format=torch.channels_last) if model.teacher_nhwc else model.images
+            model.parallel_teacher.eval()(imgs)
     else:
         for _ in range(2):
             model.optimize_parameters()
