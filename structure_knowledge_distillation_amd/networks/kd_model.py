@@ -143,6 +143,8 @@ class NetModel():
                 CriterionAdditionalGP(self.parallel_D, args.lambda_gp))
         self.criterion_adv_for_G = self.DataParallelCriterionProcess(CriterionAdvForG(args.adv_loss_type))
 
+        self._teacher_stream = (torch.cuda.Stream(device=device) if (os.environ.get("SKD_TEACHER_STREAM", "1") == "1"
+                                                                    and torch.device(device).type == "cuda") else None)
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
 
@@ -183,14 +185,31 @@ class NetModel():
         optimizer.param_groups[0]["lr"] = lr
         return lr
 
-    def forward(self):
+    def _teacher_forward(self):
         args = self.args
         with torch.no_grad():
             images_T = self.images.contiguous(memory_format=torch.channels_last) if self.teacher_nhwc else self.images
             preds_T = self.parallel_teacher.eval()(images_T, parallel=args.parallel)
             # the three entries the criteria / D read are handed on in the reference's NCHW layout
-            self.preds_T = [t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
+            return [t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
+
+    def forward(self):
+        args = self.args
+        side = self._teacher_stream
+        if side is None:
+            self.preds_T = self._teacher_forward()
+            self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
+            return
+        # The frozen teacher does not depend on the student: run it on its own HIP stream so that the two
+        # forwards fill each other's launch tails (kd_model.py:121-123 runs them back to back).
+        main = torch.cuda.current_stream(self.images.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.preds_T = self._teacher_forward()
         self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
+        main.wait_stream(side)
+        for t in self.preds_T:
+            t.record_stream(main)
 
     def student_backward(self):
         args = self.args

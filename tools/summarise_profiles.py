@@ -25,7 +25,7 @@ def category(n):
             if key in n:
                 return name
         return "skd other"
-    if n.startswith(("igemm_", "miopenSp3AsmConv", "Cijk_", "naive_conv", "gcnAsmConv", "MIOpenConv")) or "Conv" in n:
+    if n.startswith(("igemm_", "miopenSp3AsmConv", "Cijk_", "naive_conv", "gcnAsmConv", "MIOpenConv")) or "Conv" in n or "grouped_conv" in n or "_ZN2ck" in n:
         return "convolutions / GEMMs (MIOpen, rocBLAS)"
     if "batched_transpose" in n or "SubTensorOp" in n:
         return "MIOpen layout transposes / tensor ops"
