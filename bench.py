@@ -113,28 +113,36 @@ def pairwise_sweep(dev):
     return out
 
 
-def abn_pmc_ratio():
-    """HBM traffic / algorithmic bytes of abn_apply_kernel from the committed rocprofv3 counter passes
-    (profiles/*_abn_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/abn_microbench.py;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  PMC counters cannot
-    be collected from inside this process, so the live line carries the profiled ratio and says where it is from."""
+def abn_pmc_ratio(kernel, bytes_per_elem):
+    """HBM traffic / algorithmic bytes of an ABN kernel from the committed rocprofv3 counter passes
+    (profiles/*_abn_pmc.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/abn_microbench.py, averaged
+    over all launches of the kernel; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    gfx950).  PMC counters cannot be collected from inside this process, so the live line carries the profiled ratio
+    and says where it is from."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_abn_pmc.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        row = d["abn_apply_kernel<3, false> grid=4194304"]          # (8, 2048, 65x65): 69.2 M elements, one shape per grid
-        return {"ratio": row["hbm_MB (2*FETCH + WRITE)"] * 1e6 / (8.0 * 8 * 2048 * 4225),
-                "source": os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE of the (8,2048,65,65) launch / its 8 B/elem)"}
-    except Exception:
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_abn_pmc.json")), reverse=True):
+        try:
+            row = json.load(open(path)).get("ALL LAUNCHES " + kernel)
+            if row and row.get("launch_mean_elems"):
+                hbm = (2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1e3
+                return {"ratio": hbm / (bytes_per_elem * row["launch_mean_elems"]),
+                        "source": os.path.relpath(path, ROOT) + " (2*FETCH_SIZE + WRITE_SIZE over all %s launches of "
+                                  "tools/abn_microbench.py / their algorithmic bytes)" % kernel}
+        except Exception:
+            continue
+    return None
 
 
-def summarise(recs, bytes_per_elem):
-    """[(ms, (N,C,S))] -> achieved GB/s over all launches (sum bytes / sum time) + launch stats."""
+def summarise(recs, bytes_per_elem, nhwc=False):
+    """[(ms, first four C-ABI args)] -> achieved GB/s over all launches (sum of algorithmic bytes / sum of time).
+    NCHW entries: args = (N, C, S, ...); skd_abn_apply_nhwc: args = (rows, C, x, residual) with 8 B/element, 12 with
+    a residual."""
     if not recs:
         return None
+    if nhwc:
+        recs = [(ms, (d[0], d[1], 1.5 if d[3] else 1.0)) for ms, d in recs]      # third factor scales 8 -> 12 B
+    else:
+        recs = [(ms, (d[0], d[1], d[2])) for ms, d in recs]
     tot_ms = sum(ms for ms, _ in recs)
     tot_b = sum(bytes_per_elem * d[0] * d[1] * d[2] for _, d in recs)
     big = [(ms, d) for ms, d in recs if d[0] * d[1] * d[2] >= (1 << 22)]
@@ -189,7 +197,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
-    timed = ["skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
+    timed = ["skd_abn_apply_nhwc", "skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
              "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx"]
     if not a.no_kernel_timing and rank == 0:
         _lib.enable_kernel_timing(timed)
@@ -222,16 +230,25 @@ def main():
                                         zip(("G", "mc", "pi", "pa", "D"), losses)}},
         "step_fp32_mfma_frac": round(value / world * STEP_TFLOP_PER_IMAGE / MFMA_F32_PEAK_TFLOPS, 4),
     }
-    ap = summarise(recs.get("skd_abn_apply", []), 8)
+    nhwc_recs = recs.get("skd_abn_apply_nhwc", [])
+    if len(nhwc_recs) > len(recs.get("skd_abn_apply", [])):
+        ap = summarise(nhwc_recs, 8, nhwc=True)
+        pmc_kernel = "abn_apply_nhwc_kernel<3, false>"
+        kname = ("abn_apply_nhwc_kernel (skd_abn_apply_nhwc: the frozen teacher's eval-mode InPlace-ABN + ReLU [+ residual], "
+                 "channels-last, in place; 8 algorithmic bytes per element, 12 with the residual read)")
+    else:
+        ap = summarise(recs.get("skd_abn_apply", []), 8)
+        pmc_kernel = "abn_apply_kernel<3, false>"
+        kname = "abn_apply_kernel (skd_abn_apply: teacher eval-mode InPlace-ABN + ReLU, NCHW, in place)"
     if ap:
         ach = ap.get("achieved_GBs_large", ap["achieved_GBs"])
-        line["roofline"] = {"kernel": "abn_apply_kernel (skd_abn_apply: teacher eval-mode InPlace-ABN, in place)",
+        line["roofline"] = {"kernel": kname,
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                            "algorithmic_bytes_per_element": 8, "detail": ap}
-        pmc = abn_pmc_ratio()
+                            "algorithmic_bytes_per_element": "8 (12 with residual)", "detail": ap}
+        pmc = abn_pmc_ratio(pmc_kernel, 8)
         if pmc is not None:
-            line["roofline"]["traffic"] = round(pmc["ratio"] * 8 * ap["avg_elems"] / 1e6, 2)
+            line["roofline"]["traffic"] = round(pmc["ratio"] * 8 * ap["avg_elems"] / 1e6, 2)   # avg_elems is byte-weighted
             line["roofline"]["traffic_unit"] = "MB per average launch"
             line["roofline"]["traffic_source"] = pmc["source"]
         line["kernels"] = {

@@ -143,19 +143,19 @@ class _TimedLib:
             e0.record()
             r = fn(*args)
             e1.record()
-            rec.append((e0, e1, args[:3]))
+            rec.append((e0, e1, args[:4]))
             return r
         return timed
 
 
 def enable_kernel_timing(names):
-    """Start collecting (start event, end event, first three int args) for every call of ``names``."""
+    """Start collecting (start event, end event, first four args) for every call of ``names``."""
     global _timing
     _timing = {n: [] for n in names}
 
 
 def disable_kernel_timing():
-    """Stop collecting; returns {name: [(ms, (N, C, S)), ...]} (synchronises the device)."""
+    """Stop collecting; returns {name: [(ms, first four args), ...]} (synchronises the device)."""
     global _timing
     import torch
     out = {}

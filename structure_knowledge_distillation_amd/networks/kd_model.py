@@ -143,7 +143,7 @@ class NetModel():
                 CriterionAdditionalGP(self.parallel_D, args.lambda_gp))
         self.criterion_adv_for_G = self.DataParallelCriterionProcess(CriterionAdvForG(args.adv_loss_type))
 
-        self._teacher_stream = (torch.cuda.Stream(device=device) if (os.environ.get("SKD_TEACHER_STREAM", "1") == "1"
+        self._teacher_stream = (torch.cuda.Stream(device=device) if (os.environ.get("SKD_TEACHER_STREAM", "0") == "1"
                                                                     and torch.device(device).type == "cuda") else None)
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
@@ -201,7 +201,9 @@ class NetModel():
             self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
             return
         # The frozen teacher does not depend on the student: run it on its own HIP stream so that the two
-        # forwards fill each other's launch tails (kd_model.py:121-123 runs them back to back).
+        # forwards fill each other's launch tails (kd_model.py:121-123 runs them back to back).  Measured +0.7 %
+        # (83.8 -> 83.2 ms per step); off by default because co-running kernels blur the per-kernel HIP-event and
+        # rocprofv3 timings the roofline figures are read from (SKD_TEACHER_STREAM=1 enables it).
         main = torch.cuda.current_stream(self.images.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):

@@ -40,6 +40,8 @@ def main():
         p = lambda t: t.data_ptr()
         calls = {
             "apply_eval(8B)": (8, lambda: lib.skd_abn_apply(N, C, S, p(x), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
+            "apply_nhwc(8B)": (8, lambda: lib.skd_abn_apply_nhwc(N * S, C, p(x), None, p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
+            "apply_nhwc_residual(12B)": (12, lambda: lib.skd_abn_apply_nhwc(N * S, C, p(x), p(r), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
             "apply_residual(12B)": (12, lambda: lib.skd_abn_apply_residual(N, C, S, p(x), p(r), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st)),
             "stats(4B)": (4, lambda: lib.skd_abn_stats(N, C, S, p(x), p(m), p(v), p(ws), st)),
             "forward_train(12B)": (12, lambda: lib.skd_abn_forward_train(N, C, S, p(x), p(w), p(b), p(rm), p(rv), p(m), p(v), 0.1, 1e-5, 0, 0.01, p(ws), st)),

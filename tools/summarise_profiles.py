@@ -79,6 +79,29 @@ def main():
                 acc[(key, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
         for (k, grid), v in acc.items():
             pmc.setdefault("%s grid=%d" % (k, grid), {})[name] = round(sum(v) / len(v), 1)
+    # per kernel name over ALL its launches of the microbench (every shape contributes the same number of
+    # launches, so the averages pair with the mean element count of tools/abn_microbench.SHAPES)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from abn_microbench import SHAPES
+        mean_elems = sum(n * c * s_ for n, c, s_ in SHAPES) / float(len(SHAPES))
+    except Exception:
+        mean_elems = None
+    byname = {}
+    for name, sub in (("FETCH_SIZE_KB", "pmc_fetch"), ("WRITE_SIZE_KB", "pmc_write")):
+        path = os.path.join(G, sub, "abn_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            n = r["Kernel_Name"]
+            if "skd::" in n:
+                acc[n.split("skd::(anonymous namespace)::")[1].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            byname.setdefault("ALL LAUNCHES " + k, {})[name] = round(sum(v) / len(v), 1)
+    for k, d in byname.items():
+        d["launch_mean_elems"] = mean_elems
+    pmc.update(byname)
     if pmc:
         for k, d in pmc.items():
             if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
