@@ -123,9 +123,8 @@ def abn_pmc_ratio(kernel, bytes_per_elem):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_abn_pmc.json")), reverse=True):
         try:
             row = json.load(open(path)).get("ALL LAUNCHES " + kernel)
-            if row and row.get("launch_mean_elems"):
-                hbm = (2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1e3
-                return {"ratio": hbm / (bytes_per_elem * row["launch_mean_elems"]),
+            if row and row.get("hbm_over_algorithmic"):
+                return {"ratio": row["hbm_over_algorithmic"],
                         "source": os.path.relpath(path, ROOT) + " (2*FETCH_SIZE + WRITE_SIZE over all %s launches of "
                                   "tools/abn_microbench.py / their algorithmic bytes)" % kernel}
         except Exception:
@@ -233,7 +232,7 @@ def main():
     nhwc_recs = recs.get("skd_abn_apply_nhwc", [])
     if len(nhwc_recs) > len(recs.get("skd_abn_apply", [])):
         ap = summarise(nhwc_recs, 8, nhwc=True)
-        pmc_kernel = "abn_apply_nhwc_kernel<3, false>"
+        pmc_kernel = "abn_apply_nhwc_kernel<3, false, 1>"
         kname = ("abn_apply_nhwc_kernel (skd_abn_apply_nhwc: the frozen teacher's eval-mode InPlace-ABN + ReLU [+ residual], "
                  "channels-last, in place; 8 algorithmic bytes per element, 12 with the residual read)")
     else:

@@ -353,8 +353,58 @@ __global__ __launch_bounds__(kThreads) void abn_apply_residual_kernel(
 // streams rows with 16-byte accesses.  Used by the frozen teacher, whose convolutions run NHWC-native in MIOpen
 // (no NCHW<->NHWC transposes around the igemm kernels).  C must be a multiple of 4.
 // ---------------------------------------------------------------------------------------------
-template <int ACT, bool HAS_RES>
+// Fast form for power-of-two channel counts (every layer of this path): a workgroup owns a contiguous run of
+// 256 * 8 quads (32 KiB); quad q of thread t sits at base + u*256 + t, so its channel quad is (t + u*256) mod C4 --
+// constant for C4 <= 256, cycling through NSETS = C4/256 register sets above that.  Eight 16-byte loads per lane.
+template <int ACT, bool HAS_RES, int NSETS>
 __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_kernel(float *x, const float *res,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ var,
+                                                                 const float *__restrict__ weight,
+                                                                 const float *__restrict__ bias, float eps,
+                                                                 float slope, int64_t quads, int C4) {
+  constexpr int U = 8;
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * U);
+  float m[NSETS][4], is[NSETS][4], g[NSETS][4], b[NSETS][4];
+#pragma unroll
+  for (int s = 0; s < NSETS; ++s) {
+    const int c = ((threadIdx.x + s * kThreads) & (C4 - 1)) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m[s][k] = mean[c + k];
+      is[s][k] = inv_std_of(var[c + k], eps);
+      g[s][k] = gamma_of(weight, c + k, eps);
+      b[s][k] = beta_of(bias, c + k);
+    }
+  }
+  float4 v[U], r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t q = base + u * kThreads + threadIdx.x;
+    if (q < quads) {
+      v[u] = *reinterpret_cast<const float4 *>(x + 4 * q);
+      if (HAS_RES) r[u] = *reinterpret_cast<const float4 *>(res + 4 * q);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t q = base + u * kThreads + threadIdx.x;
+    if (q < quads) {
+      constexpr int dummy = 0;
+      const int s = NSETS == 1 ? dummy : (u % NSETS);
+      float4 z;
+      z.x = act_fwd<ACT>(((v[u].x - m[s][0]) * is[s][0]) * g[s][0] + b[s][0] + (HAS_RES ? r[u].x : 0.f), slope);
+      z.y = act_fwd<ACT>(((v[u].y - m[s][1]) * is[s][1]) * g[s][1] + b[s][1] + (HAS_RES ? r[u].y : 0.f), slope);
+      z.z = act_fwd<ACT>(((v[u].z - m[s][2]) * is[s][2]) * g[s][2] + b[s][2] + (HAS_RES ? r[u].z : 0.f), slope);
+      z.w = act_fwd<ACT>(((v[u].w - m[s][3]) * is[s][3]) * g[s][3] + b[s][3] + (HAS_RES ? r[u].w : 0.f), slope);
+      *reinterpret_cast<float4 *>(x + 4 * q) = z;
+    }
+  }
+}
+
+// generic channel counts (any C % 4 == 0): grid-stride, total threads a multiple of C4
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void abn_apply_nhwc_generic_kernel(float *x, const float *res,
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ var,
                                                                  const float *__restrict__ weight,
@@ -761,31 +811,47 @@ static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x
   }
 }
 
+template <int ACT, bool HAS_RES>
+static void launch_apply_nhwc_act(int64_t quads, int C4, float *x, const float *res, const float *mean,
+                                  const float *var, const float *weight, const float *bias, float eps, float slope,
+                                  hipStream_t st) {
+  const dim3 block(kThreads);
+  const bool pow2 = (C4 & (C4 - 1)) == 0;
+  if (pow2 && C4 <= 4 * kThreads) {
+    const dim3 grid((unsigned)cdiv(quads, (int64_t)kThreads * 8));
+    if (C4 <= kThreads)
+      abn_apply_nhwc_kernel<ACT, HAS_RES, 1><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+    else if (C4 == 2 * kThreads)
+      abn_apply_nhwc_kernel<ACT, HAS_RES, 2><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+    else
+      abn_apply_nhwc_kernel<ACT, HAS_RES, 4><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+    return;
+  }
+  // threads = a multiple of lcm(C4, 256), about quads / 4 (four 16-byte accesses in flight per thread)
+  int64_t unit = C4;
+  while (unit % kThreads != 0) unit *= 2;
+  int64_t threads = cdiv(cdiv(quads, 4), unit) * unit;
+  const int64_t cap = cdiv((int64_t)256 * 8 * kThreads, unit) * unit;   // ~8 workgroups per CU, then stride
+  if (threads > cap) threads = cap;
+  if (threads < unit) threads = unit;
+  abn_apply_nhwc_generic_kernel<ACT, HAS_RES><<<dim3((unsigned)(threads / kThreads)), block, 0, st>>>(
+      x, res, mean, var, weight, bias, eps, slope, quads, C4);
+}
+
 template <bool HAS_RES>
 static int launch_apply_nhwc(int64_t rows, int C, float *x, const float *res, const float *mean, const float *var,
                              const float *weight, const float *bias, float eps, int act, float slope, hipStream_t st) {
   const int C4 = C / 4;
   const int64_t quads = rows * C4;
-  // threads = a multiple of lcm(C4, 256), about quads / 4 (four 16-byte accesses in flight per thread)
-  int64_t unit = C4;
-  while (unit % kThreads != 0) unit *= 2;          // C4 = 16 * 2^k on this path; general C4: unit = lcm below
-  if (unit % C4 != 0 || unit > (1 << 20)) {         // non power-of-two channel counts
-    unit = (int64_t)C4 * kThreads;
-  }
-  int64_t threads = cdiv(cdiv(quads, 4), unit) * unit;
-  const int64_t cap = cdiv((int64_t)256 * 8 * kThreads, unit) * unit;   // ~8 workgroups per CU, then stride
-  if (threads > cap) threads = cap;
-  if (threads < unit) threads = unit;
-  const dim3 grid((unsigned)(threads / kThreads)), block(kThreads);
   switch (act) {
     case SKD_ACT_NONE:
-      abn_apply_nhwc_kernel<SKD_ACT_NONE, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      launch_apply_nhwc_act<SKD_ACT_NONE, HAS_RES>(quads, C4, x, res, mean, var, weight, bias, eps, slope, st);
       break;
     case SKD_ACT_LEAKY_RELU:
-      abn_apply_nhwc_kernel<SKD_ACT_LEAKY_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      launch_apply_nhwc_act<SKD_ACT_LEAKY_RELU, HAS_RES>(quads, C4, x, res, mean, var, weight, bias, eps, slope, st);
       break;
     case SKD_ACT_RELU:
-      abn_apply_nhwc_kernel<SKD_ACT_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
+      launch_apply_nhwc_act<SKD_ACT_RELU, HAS_RES>(quads, C4, x, res, mean, var, weight, bias, eps, slope, st);
       break;
     default:
       return 0;

@@ -101,6 +101,31 @@ def main():
             byname.setdefault("ALL LAUNCHES " + k, {})[name] = round(sum(v) / len(v), 1)
     for k, d in byname.items():
         d["launch_mean_elems"] = mean_elems
+        if mean_elems and "nhwc" not in k and "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
+            bpe = 12 if "residual" in k else (8 if "apply_kernel" in k else None)
+            if bpe:
+                d["hbm_over_algorithmic"] = round((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1e3 / (bpe * mean_elems), 4)
+    # the channels-last apply kernel: 32 elements per launched thread, so every launch's algorithmic bytes follow
+    # from its Grid_Size and the ratio can be summed launch by launch (template arg 2 = has residual -> 12 B/elem)
+    sums = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
+    for idx, sub in ((0, "pmc_fetch"), (1, "pmc_write")):
+        path = os.path.join(G, sub, "abn_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        for r in csv.DictReader(open(path)):
+            n = r["Kernel_Name"]
+            if "abn_apply_nhwc_kernel<" in n:
+                key = n.split("skd::(anonymous namespace)::")[1].split("(")[0]
+                sums[key][idx] += float(r["Counter_Value"])
+                if idx == 0:
+                    sums[key][2] += float(r["Grid_Size"])
+    for key, (f, w, threads) in sums.items():
+        bpe = 12 if ", true," in key else 8
+        d = byname.setdefault("ALL LAUNCHES " + key, {})
+        d.pop("launch_mean_elems", None)
+        d["algorithmic_MB_sum"] = round(bpe * 32 * threads / 1e6, 1)
+        d["hbm_MB_sum (2*FETCH + WRITE)"] = round((2 * f + w) / 1e3, 1)
+        d["hbm_over_algorithmic"] = round((2 * f + w) * 1e3 / (bpe * 32 * threads), 4) if threads else None
     pmc.update(byname)
     if pmc:
         for k, d in pmc.items():
