@@ -36,7 +36,7 @@ class Self_Attn(nn.Module):
 class NativeBatchNorm2d(nn.BatchNorm2d):
     """``nn.BatchNorm2d`` evaluated by PyTorch's own kernels instead of MIOpen's batch-norm.
 
-    Same parameters, buffers and state-dict keys.  Measured on MI355X (tools/diag_dfwd.py): MIOpen's
+    Same parameters, buffers and state-dict keys.  Measured on MI355X (tests/diagnostics/diag_dfwd.py): MIOpen's
     training-mode batch-norm is off by 4.6e-4 relative on the discriminator's (B, 19, 65, 65) input -- enough
     to break the 1e-4 loss tolerance and to put 1-3 % of error on every D gradient -- while the native kernel
     agrees with the fp64 reference to 5e-8.  It also keeps WGAN-GP's double backward on PyTorch's formulas."""

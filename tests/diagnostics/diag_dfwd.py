@@ -1,8 +1,8 @@
-"""GPU diagnostic (not product code): layer-by-layer forward of the discriminator, cuda fp32 vs CPU fp64."""
+"""GPU diagnostic (test infrastructure, may use the oracle; not product code): layer-by-layer forward of the discriminator, cuda fp32 vs CPU fp64."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
 import torch  # noqa: E402

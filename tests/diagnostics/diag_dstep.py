@@ -1,9 +1,9 @@
-"""GPU diagnostic (not product code): per-parameter gradient error of the discriminator step, split into
+"""GPU diagnostic (test infrastructure, may use the oracle; not product code): per-parameter gradient error of the discriminator step, split into
 the adversarial part and the WGAN-GP part, product (cuda fp32) vs CPU oracle (fp32 and fp64)."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
 import torch  # noqa: E402
