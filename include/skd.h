@@ -121,6 +121,35 @@ int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *o
 int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, const float *mean,
                        const float *var, const float *weight, const float *bias, float eps, int activation,
                        float slope, skd_stream_t stream);
+/* Channels-last (NHWC) TRAINING forms: x is (rows = N*H*W, C) row-major, C a power of two in [4, 1024].
+ * Same maths and conventions as the NCHW entries above (statistics over the rows of each channel, running-stat
+ * update with n = rows, dweight / dbias accumulated); `out` may equal `x` (the in-place InPlace-ABN) or be a
+ * separate tensor (the BN -> [+ residual] -> ReLU fusion, which keeps x for backward).  They let MIOpen run its
+ * NHWC-native fp32 kernels without NCHW<->NHWC transposes.  workspace: skd_abn_nhwc_workspace_floats(rows, C). */
+int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C);
+int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *workspace,
+                       skd_stream_t stream);
+int skd_abn_apply_nhwc_to(int64_t rows, int C, const float *x, const float *residual, float *out,
+                          const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                          int activation, float slope, skd_stream_t stream);
+int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float *residual, float *out,
+                               const float *weight, const float *bias, float *running_mean, float *running_var,
+                               float *mean, float *var, float momentum, float eps, int activation, float slope,
+                               float *workspace, skd_stream_t stream);
+int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *weight,
+                                 const float *bias, float *edz, float *eydz, float eps, int activation,
+                                 float slope, float *workspace, skd_stream_t stream);
+int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
+                             const float *weight, const float *bias, const float *edz, const float *eydz,
+                             float *dx, float *dweight, float *dbias, float eps, int activation, float slope,
+                             skd_stream_t stream);
+int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                      const float *mean, const float *var, float *edz, float *eydz, float eps,
+                                      float *workspace, skd_stream_t stream);
+int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                  const float *mean, const float *var, const float *weight, const float *edz,
+                                  const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
+                                  float eps, skd_stream_t stream);
 /* running-stat update with an explicit sample count n (functions.py:209) */
 int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
                            const float *var, float momentum, double n, skd_stream_t stream);

@@ -372,3 +372,98 @@ int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, con
   act_forward(act, rows * C, x, slope);
   return 1;
 }
+
+/* ---- channels-last (NHWC) training forms: x is (rows, C) row-major.  Restated by transposing to the (1, C, rows)
+ * NCHW problem the entries above solve, calling them, and transposing back -- the maths is layout independent. ---- */
+static float *to_planes(int64_t rows, int C, const float *x) {
+  float *p = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (p && x)
+    for (int64_t r = 0; r < rows; ++r)
+      for (int c = 0; c < C; ++c) p[(int64_t)c * rows + r] = x[r * C + c];
+  return p;
+}
+static void from_planes(int64_t rows, int C, const float *p, float *x) {
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) x[r * C + c] = p[(int64_t)c * rows + r];
+}
+static int nhwc_ok(int64_t rows, int C) { return rows > 0 && rows < 2147483647 && C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
+
+int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C) { return nhwc_ok(rows, C) ? 2 * (int64_t)C : 0; }
+
+int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *ws, stream_t st) {
+  (void)ws;
+  if (!nhwc_ok(rows, C)) return 0;
+  float *p = to_planes(rows, C, x);
+  const int r = p ? skd_bn_mean_var(1, C, (int)rows, p, mean, var, st) : 0;
+  free(p);
+  return r;
+}
+
+int skd_abn_apply_nhwc_to(int64_t rows, int C, const float *x, const float *residual, float *out, const float *mean,
+                          const float *var, const float *weight, const float *bias, float eps, int act, float slope,
+                          stream_t st) {
+  if (!nhwc_ok(rows, C) || !x || !out) return 0;
+  if (out != x) memcpy(out, x, sizeof(float) * (size_t)rows * C);
+  return skd_abn_apply_nhwc(rows, C, out, residual, mean, var, weight, bias, eps, act, slope, st);
+}
+
+int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float *residual, float *out,
+                               const float *weight, const float *bias, float *rm, float *rv, float *mean, float *var,
+                               float momentum, float eps, int act, float slope, float *ws, stream_t st) {
+  if (!skd_abn_stats_nhwc(rows, C, x, mean, var, ws, st)) return 0;
+  if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, (double)rows, st);
+  return skd_abn_apply_nhwc_to(rows, C, x, residual, out, mean, var, weight, bias, eps, act, slope, st);
+}
+
+int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *weight,
+                                 const float *bias, float *edz, float *eydz, float eps, int act, float slope,
+                                 float *ws, stream_t st) {
+  if (!nhwc_ok(rows, C)) return 0;
+  float *pz = to_planes(rows, C, z), *pd = to_planes(rows, C, dz);
+  const int r = (pz && pd) ? skd_abn_backward_reduce(1, C, (int)rows, pz, pd, weight, bias, edz, eydz, eps, act, slope, ws, st) : 0;
+  free(pz); free(pd);
+  return r;
+}
+
+int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
+                             const float *weight, const float *bias, const float *edz, const float *eydz, float *dx,
+                             float *dweight, float *dbias, float eps, int act, float slope, stream_t st) {
+  if (!nhwc_ok(rows, C) || !dx) return 0;
+  float *pz = to_planes(rows, C, z), *pd = to_planes(rows, C, dz), *px = to_planes(rows, C, NULL);
+  int r = 0;
+  if (pz && pd && px) {
+    r = skd_abn_backward_dx(1, C, (int)rows, pz, pd, var, weight, bias, edz, eydz, px, dweight, dbias, eps, act, slope, st);
+    if (r) from_planes(rows, C, px, dx);
+  }
+  free(pz); free(pd); free(px);
+  return r;
+}
+
+int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                      const float *mean, const float *var, float *edz, float *eydz, float eps,
+                                      float *ws, stream_t st) {
+  if (!nhwc_ok(rows, C)) return 0;
+  float *px = to_planes(rows, C, x), *po = to_planes(rows, C, out), *pd = to_planes(rows, C, dout);
+  const int r = (px && po && pd) ? skd_abn_relu_backward_reduce(1, C, (int)rows, px, po, pd, mean, var, edz, eydz, eps, ws, st) : 0;
+  free(px); free(po); free(pd);
+  return r;
+}
+
+int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                  const float *mean, const float *var, const float *weight, const float *edz,
+                                  const float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
+                                  stream_t st) {
+  if (!nhwc_ok(rows, C) || !dx) return 0;
+  float *px = to_planes(rows, C, x), *po = to_planes(rows, C, out), *pd = to_planes(rows, C, dout);
+  float *pdx = to_planes(rows, C, NULL), *pdr = dres ? to_planes(rows, C, NULL) : NULL;
+  int r = 0;
+  if (px && po && pd && pdx && (!dres || pdr)) {
+    r = skd_abn_relu_backward_dx(1, C, (int)rows, px, po, pd, mean, var, weight, edz, eydz, pdx, pdr, dweight, dbias, eps, st);
+    if (r) {
+      from_planes(rows, C, pdx, dx);
+      if (dres) from_planes(rows, C, pdr, dres);
+    }
+  }
+  free(px); free(po); free(pd); free(pdx); free(pdr);
+  return r;
+}

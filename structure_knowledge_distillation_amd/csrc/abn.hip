@@ -859,6 +859,312 @@ static int launch_apply_nhwc(int64_t rows, int C, float *x, const float *res, co
   return ok();
 }
 
+
+// =============================================================================================
+// Channels-last (NHWC) TRAINING kernels: x is (rows = N*H*W, C) row-major.
+// MIOpen's fastest fp32 kernels on gfx950 are NHWC implicit-GEMM kernels; handing it NCHW tensors costs a
+// transpose before and after each of them (4.5 ms per step for the student's forward/backward, profiles/).
+// With the channel as the fastest dimension a thread owns ONE channel quad (its statistics accumulate in
+// registers, its parameters live in registers) and a workgroup walks a contiguous slab of rows:
+//   256 threads = (256 / C4) rows x C4 channel quads per pass, 8 passes in flight per loop trip.
+// Per-workgroup partials use the same [c][P][2] layout as the NCHW path, so the finalize kernels (double
+// accumulation, fixed order, running-stat update) are shared: they are called with (N, S) = (rows, 1), which makes
+// the pivot x[c * S] the first row's element of channel c.
+// Power-of-two C with 4 <= C <= 1024 (every training layer of this path: 64 ... 512).
+// =============================================================================================
+constexpr int kNhwcRowsPerThread = 8;
+
+struct NhwcGeom {
+  int C4, log2C4, rpp;  // channel quads, log2, rows per pass (256 / C4)
+  int rows_per_wg;      // rpp * kNhwcRowsPerThread
+  int P;                // workgroups = partial slots per channel
+};
+
+static bool make_nhwc_geom(int64_t rows, int C, NhwcGeom &g) {
+  if (rows <= 0 || C < 4 || C > 4 * kThreads || (C & (C - 1))) return false;
+  g.C4 = C / 4;
+  g.log2C4 = 0;
+  while ((1 << g.log2C4) < g.C4) ++g.log2C4;
+  g.rpp = kThreads / g.C4;
+  g.rows_per_wg = g.rpp * kNhwcRowsPerThread;
+  const int64_t P = cdiv(rows, g.rows_per_wg);
+  if (P > (1 << 24)) return false;
+  g.P = (int)P;
+  return true;
+}
+
+// combine the partial sums of the rpp threads that share a channel quad, write [c][P][2] partials
+__device__ __forceinline__ void nhwc_store_partials(float (&s1)[4], float (&s2)[4], float *__restrict__ part,
+                                                    const NhwcGeom &g, float *lds) {
+  const int t = threadIdx.x;
+  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
+  float *mine = lds + (int64_t)t * 8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mine[k] = s1[k];
+    mine[4 + k] = s2[k];
+  }
+  __syncthreads();
+  if (rsub == 0) {
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    for (int r = 0; r < g.rpp; ++r) {
+      const float *o = lds + ((int64_t)(r << g.log2C4) + cq) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float *dst = part + ((int64_t)(cq * 4 + k) * g.P + blockIdx.x) * 2;
+      dst[0] = a[k];
+      dst[1] = a[4 + k];
+    }
+  }
+}
+
+// K1 (NHWC): shifted sums of (x - K), (x - K)^2 with K = x[0][c]
+__global__ __launch_bounds__(kThreads) void abn_stats_nhwc_kernel(const float *__restrict__ x,
+                                                                 float *__restrict__ part, int64_t rows,
+                                                                 NhwcGeom g) {
+  __shared__ float lds[kThreads * 8];
+  const int t = threadIdx.x;
+  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
+  const float4 K = *reinterpret_cast<const float4 *>(x + cq * 4);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
+  float4 v[kNhwcRowsPerThread];
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) v[u] = *reinterpret_cast<const float4 *>(x + (r << (g.log2C4 + 2)) + cq * 4);
+  }
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const float d0 = v[u].x - K.x, d1 = v[u].y - K.y, d2 = v[u].z - K.z, d3 = v[u].w - K.w;
+      s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+      s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
+    }
+  }
+  nhwc_store_partials(s1, s2, part, g, lds);
+}
+
+// K2 (NHWC), out of place or in place: out = act(bn(x) [+ residual]) with given mean / var
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void abn_apply_nhwc_train_kernel(const float *x, const float *res, float *out,
+                                                                       const float *__restrict__ mean,
+                                                                       const float *__restrict__ var,
+                                                                       const float *__restrict__ weight,
+                                                                       const float *__restrict__ bias, float eps,
+                                                                       float slope, int64_t rows, NhwcGeom g) {
+  const int t = threadIdx.x;
+  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
+  float m[4], is[4], gm[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = mean[cq * 4 + k];
+    is[k] = inv_std_of(var[cq * 4 + k], eps);
+    gm[k] = gamma_of(weight, cq * 4 + k, eps);
+    b[k] = beta_of(bias, cq * 4 + k);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
+  float4 v[kNhwcRowsPerThread], r4[kNhwcRowsPerThread];
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const int64_t o = (r << (g.log2C4 + 2)) + cq * 4;
+      v[u] = *reinterpret_cast<const float4 *>(x + o);
+      if (HAS_RES) r4[u] = *reinterpret_cast<const float4 *>(res + o);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      float4 z;
+      z.x = act_fwd<ACT>(((v[u].x - m[0]) * is[0]) * gm[0] + b[0] + (HAS_RES ? r4[u].x : 0.f), slope);
+      z.y = act_fwd<ACT>(((v[u].y - m[1]) * is[1]) * gm[1] + b[1] + (HAS_RES ? r4[u].y : 0.f), slope);
+      z.z = act_fwd<ACT>(((v[u].z - m[2]) * is[2]) * gm[2] + b[2] + (HAS_RES ? r4[u].z : 0.f), slope);
+      z.w = act_fwd<ACT>(((v[u].w - m[3]) * is[3]) * gm[3] + b[3] + (HAS_RES ? r4[u].w : 0.f), slope);
+      *reinterpret_cast<float4 *>(out + (r << (g.log2C4 + 2)) + cq * 4) = z;
+    }
+  }
+}
+
+// K3 (NHWC): edz / eydz partials.  MODE 0: y from the saved OUTPUT z (activation ACT undone in registers, the
+// in-place ABN);  MODE 1: fused BN+ReLU: inputs (x, out, dout), y from x, mask = out > 0.
+template <int ACT, int MODE>
+__global__ __launch_bounds__(kThreads) void abn_grad_partial_nhwc_kernel(
+    const float *__restrict__ a_, const float *__restrict__ b_, const float *__restrict__ c_,
+    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ part, float eps, float slope, int64_t rows, NhwcGeom g) {
+  __shared__ float lds[kThreads * 8];
+  const int t = threadIdx.x;
+  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
+  float p0[4], p1[4];  // MODE 0: beta, gamma   MODE 1: mean, inv_std
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (MODE == 0) {
+      p0[k] = beta_of(bias, cq * 4 + k);
+      p1[k] = gamma_of(weight, cq * 4 + k, eps);
+    } else {
+      p0[k] = mean[cq * 4 + k];
+      p1[k] = inv_std_of(var[cq * 4 + k], eps);
+    }
+  }
+  const float inv_slope = 1.f / slope;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
+  float4 va[kNhwcRowsPerThread], vb[kNhwcRowsPerThread], vc[kNhwcRowsPerThread];
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const int64_t o = (r << (g.log2C4 + 2)) + cq * 4;
+      va[u] = *reinterpret_cast<const float4 *>(a_ + o);
+      vb[u] = *reinterpret_cast<const float4 *>(b_ + o);
+      if (MODE == 1) vc[u] = *reinterpret_cast<const float4 *>(c_ + o);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const float A[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+      const float B[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      const float Cc[4] = {MODE == 1 ? vc[u].x : 0.f, MODE == 1 ? vc[u].y : 0.f, MODE == 1 ? vc[u].z : 0.f,
+                           MODE == 1 ? vc[u].w : 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float y, dz;
+        if (MODE == 0) {
+          float zv = A[k];
+          dz = B[k];
+          act_undo<ACT>(zv, dz, slope, inv_slope);
+          y = (zv - p0[k]) / p1[k];
+        } else {
+          dz = B[k] > 0.f ? Cc[k] : 0.f;          // (x, out, dout)
+          y = (A[k] - p0[k]) * p1[k];
+        }
+        s1[k] += dz;
+        s2[k] += y * dz;
+      }
+    }
+  }
+  nhwc_store_partials(s1, s2, part, g, lds);
+}
+
+// K4 (NHWC): dx (and dres for MODE 1), dweight / dbias by workgroup 0
+template <int ACT, int MODE, bool WRITE_RES>
+__global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
+    const float *a_, const float *b_, const float *c_, const float *__restrict__ mean,
+    const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ bias,
+    const float *__restrict__ edz, const float *__restrict__ eydz, float *dx, float *dres, float *dweight,
+    float *dbias, float eps, float slope, int64_t rows, NhwcGeom g) {
+  const int t = threadIdx.x;
+  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
+  float p0[4], p1[4], e[4], ey[4], mul[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;
+    const float gam = gamma_of(weight, c, eps), is = inv_std_of(var[c], eps);
+    if (MODE == 0) {
+      p0[k] = beta_of(bias, c);
+      p1[k] = gam;
+    } else {
+      p0[k] = mean[c];
+      p1[k] = is;
+    }
+    e[k] = edz[c];
+    ey[k] = eydz[c];
+    mul[k] = gam * is;
+  }
+  const float inv_slope = 1.f / slope;
+  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
+  float4 va[kNhwcRowsPerThread], vb[kNhwcRowsPerThread], vc[kNhwcRowsPerThread];
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const int64_t o = (r << (g.log2C4 + 2)) + cq * 4;
+      va[u] = *reinterpret_cast<const float4 *>(a_ + o);
+      vb[u] = *reinterpret_cast<const float4 *>(b_ + o);
+      if (MODE == 1) vc[u] = *reinterpret_cast<const float4 *>(c_ + o);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
+    const int64_t r = r0 + (int64_t)u * g.rpp;
+    if (r < rows) {
+      const float A[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+      const float B[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      const float Cc[4] = {MODE == 1 ? vc[u].x : 0.f, MODE == 1 ? vc[u].y : 0.f, MODE == 1 ? vc[u].z : 0.f,
+                           MODE == 1 ? vc[u].w : 0.f};
+      float D[4], R[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float y, dz;
+        if (MODE == 0) {
+          float zv = A[k];
+          dz = B[k];
+          act_undo<ACT>(zv, dz, slope, inv_slope);
+          y = (zv - p0[k]) / p1[k];
+        } else {
+          dz = B[k] > 0.f ? Cc[k] : 0.f;
+          y = (A[k] - p0[k]) * p1[k];
+        }
+        D[k] = (dz - e[k] - y * ey[k]) * mul[k];
+        R[k] = dz;
+      }
+      const int64_t o = (r << (g.log2C4 + 2)) + cq * 4;
+      *reinterpret_cast<float4 *>(dx + o) = make_float4(D[0], D[1], D[2], D[3]);
+      if (WRITE_RES) *reinterpret_cast<float4 *>(dres + o) = make_float4(R[0], R[1], R[2], R[3]);
+    }
+  }
+  if (blockIdx.x == 0 && rsub == 0) {
+    const float norm = (float)rows;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = cq * 4 + k;
+      if (dweight != nullptr) {
+        const float wv = weight[c];
+        if (wv > 0.f)
+          dweight[c] += ey[k] * norm;
+        else if (wv < 0.f)
+          dweight[c] -= ey[k] * norm;
+      }
+      if (dbias != nullptr) dbias[c] += e[k] * norm;
+    }
+  }
+}
+
+template <bool HAS_RES>
+static int launch_apply_nhwc_train(int act, const float *x, const float *res, float *out, const float *mean,
+                                   const float *var, const float *weight, const float *bias, float eps, float slope,
+                                   int64_t rows, const NhwcGeom &g, hipStream_t st) {
+  const dim3 grid((unsigned)g.P), block(kThreads);
+  switch (act) {
+    case SKD_ACT_NONE:
+      abn_apply_nhwc_train_kernel<SKD_ACT_NONE, HAS_RES><<<grid, block, 0, st>>>(x, res, out, mean, var, weight, bias, eps, slope, rows, g);
+      break;
+    case SKD_ACT_LEAKY_RELU:
+      abn_apply_nhwc_train_kernel<SKD_ACT_LEAKY_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, out, mean, var, weight, bias, eps, slope, rows, g);
+      break;
+    case SKD_ACT_ELU:
+      abn_apply_nhwc_train_kernel<SKD_ACT_ELU, HAS_RES><<<grid, block, 0, st>>>(x, res, out, mean, var, weight, bias, eps, slope, rows, g);
+      break;
+    case SKD_ACT_RELU:
+      abn_apply_nhwc_train_kernel<SKD_ACT_RELU, HAS_RES><<<grid, block, 0, st>>>(x, res, out, mean, var, weight, bias, eps, slope, rows, g);
+      break;
+    default:
+      return 0;
+  }
+  return ok();
+}
+
 static int valid_dims(int N, int C, int S) { return N > 0 && C > 0 && S > 0; }
 
 }  // namespace
@@ -1098,6 +1404,127 @@ int skd_abn_relu_backward_dx(int N, int C, int S, const float *x, const float *o
     abn_relu_grad_dx_kernel<true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl, apply_nt_mode());
   else
     abn_relu_grad_dx_kernel<false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, N, C, S, pl, apply_nt_mode());
+  return ok();
+}
+
+
+// ---- channels-last (NHWC) training entries ---------------------------------------------------------------
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g)) return 0;
+  return (int64_t)g.P * C * 2;
+}
+
+int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *workspace,
+                       skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || !x || !mean || !var || !workspace || !aligned16(x)) return 0;
+  hipStream_t st = as_stream(stream);
+  abn_stats_nhwc_kernel<<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(x, workspace, rows, g);
+  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
+      x, workspace, mean, var, nullptr, nullptr, (int)(rows > 2147483647 ? 2147483647 : rows), C, 1, g.P, 0.f, 0.0);
+  return rows > 2147483647 ? 0 : ok();
+}
+
+int skd_abn_apply_nhwc_to(int64_t rows, int C, const float *x, const float *residual, float *out,
+                          const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                          int activation, float slope, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || !x || !out || !mean || !var) return 0;
+  if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual))) return 0;
+  hipStream_t st = as_stream(stream);
+  return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
+                  : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
+}
+
+int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float *residual, float *out,
+                               const float *weight, const float *bias, float *running_mean, float *running_var,
+                               float *mean, float *var, float momentum, float eps, int activation, float slope,
+                               float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !mean || !var || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual))) return 0;
+  hipStream_t st = as_stream(stream);
+  abn_stats_nhwc_kernel<<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(x, workspace, rows, g);
+  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
+      x, workspace, mean, var, running_mean, running_var, (int)rows, C, 1, g.P, momentum, (double)rows);
+  return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
+                  : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
+}
+
+int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *weight,
+                                 const float *bias, float *edz, float *eydz, float eps, int activation, float slope,
+                                 float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !z || !dz || !edz || !eydz || !workspace) return 0;
+  if (!aligned16(z) || !aligned16(dz) || activation == SKD_ACT_RELU) return 0;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)g.P), block(kThreads);
+  switch (activation) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_grad_partial_nhwc_kernel<SKD_ACT_LEAKY_RELU, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+      break;
+    case SKD_ACT_ELU:
+      abn_grad_partial_nhwc_kernel<SKD_ACT_ELU, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+      break;
+    default:
+      abn_grad_partial_nhwc_kernel<SKD_ACT_NONE, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+  }
+  abn_grad_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(workspace, edz, eydz, (int)rows, C, 1, g.P);
+  return ok();
+}
+
+int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
+                             const float *weight, const float *bias, const float *edz, const float *eydz, float *dx,
+                             float *dweight, float *dbias, float eps, int activation, float slope,
+                             skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || !z || !dz || !var || !edz || !eydz || !dx) return 0;
+  if (!aligned16(z) || !aligned16(dz) || !aligned16(dx) || activation == SKD_ACT_RELU || (dweight && !weight)) return 0;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)g.P), block(kThreads);
+  switch (activation) {
+    case SKD_ACT_LEAKY_RELU:
+      abn_grad_dx_nhwc_kernel<SKD_ACT_LEAKY_RELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+      break;
+    case SKD_ACT_ELU:
+      abn_grad_dx_nhwc_kernel<SKD_ACT_ELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+      break;
+    default:
+      abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+  }
+  return ok();
+}
+
+int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                      const float *mean, const float *var, float *edz, float *eydz, float eps,
+                                      float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !dout || !mean || !var || !edz || !eydz || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(out) || !aligned16(dout)) return 0;
+  hipStream_t st = as_stream(stream);
+  abn_grad_partial_nhwc_kernel<SKD_ACT_NONE, 1><<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(
+      x, out, dout, mean, var, nullptr, nullptr, workspace, eps, 0.f, rows, g);
+  abn_grad_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(workspace, edz, eydz, (int)rows, C, 1, g.P);
+  return ok();
+}
+
+int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                  const float *mean, const float *var, const float *weight, const float *edz,
+                                  const float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
+                                  skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || !x || !out || !dout || !mean || !var || !edz || !eydz || !dx) return 0;
+  if (!aligned16(x) || !aligned16(out) || !aligned16(dout) || !aligned16(dx) || (dres && !aligned16(dres)) || (dweight && !weight)) return 0;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)g.P), block(kThreads);
+  if (dres != nullptr)
+    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g);
+  else
+    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g);
   return ok();
 }
 

@@ -75,6 +75,115 @@ def combine_replica_stats(gathered):
     return mean, var
 
 
+def _is_nhwc(x):
+    return x.dim() == 4 and (not x.is_contiguous()) and x.is_contiguous(memory_format=torch.channels_last)
+
+
+class _Geom:
+    """Layout of one activation tensor and the C-ABI entry set that goes with it.
+
+    NCHW (the reference's layout, lib_cffi.cpp:24-34): (N, C, S) + the skd_abn_* entries.
+    Channels-last: (rows = N*H*W, C) + the skd_abn_*_nhwc entries (C a power of two in [4, 1024]); lets MIOpen
+    run its NHWC-native fp32 kernels without transposes."""
+
+    def __init__(self, x):
+        self.nhwc = _is_nhwc(x)
+        if self.nhwc:
+            c = x.shape[1]
+            if c < 4 or c > 1024 or (c & (c - 1)):
+                raise ValueError("channels-last InPlaceABN needs a power-of-two channel count in [4, 1024] (got %d)" % c)
+            self.rows, self.c = x.shape[0] * x.shape[2] * x.shape[3], c
+            self.count = self.rows
+        else:
+            _check_contiguous(x)
+            self.n, self.c, self.s = _dims(x)
+            self.count = self.n * self.s
+
+    def like(self, t):
+        """t in this tensor's memory format (gradients arrive in whatever format autograd produced)."""
+        if self.nhwc:
+            return t if _is_nhwc(t) else t.contiguous(memory_format=torch.channels_last)
+        return t.contiguous()
+
+    def workspace(self, lib, ref):
+        n = (lib.skd_abn_nhwc_workspace_floats(self.rows, self.c) if self.nhwc
+             else lib.skd_abn_workspace_floats(self.n, self.c, self.s))
+        return ref.new_empty((max(1, n),))
+
+    def _d(self):
+        return (self.rows, self.c) if self.nhwc else (self.n, self.c, self.s)
+
+    def stats(self, lib, x, mean, var, ws, st):
+        fn = lib.skd_abn_stats_nhwc if self.nhwc else lib.skd_abn_stats
+        _lib.check(fn(*self._d(), x.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), st), "skd_abn_stats")
+
+    def forward_train(self, lib, x, res, out, weight, bias, rm, rv, mean, var, momentum, eps, act, slope, ws, st):
+        if self.nhwc:
+            _lib.check(lib.skd_abn_forward_train_nhwc(self.rows, self.c, x.data_ptr(), _lib.ptr(res), out.data_ptr(),
+                                                      _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
+                                                      mean.data_ptr(), var.data_ptr(), momentum, eps, act, slope,
+                                                      ws.data_ptr(), st), "skd_abn_forward_train_nhwc")
+        elif res is None and out.data_ptr() == x.data_ptr():
+            _lib.check(lib.skd_abn_forward_train(self.n, self.c, self.s, x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                                                 _lib.ptr(rm), _lib.ptr(rv), mean.data_ptr(), var.data_ptr(), momentum,
+                                                 eps, act, slope, ws.data_ptr(), st), "skd_abn_forward_train")
+        else:
+            _lib.check(lib.skd_abn_forward_train_to(self.n, self.c, self.s, x.data_ptr(), _lib.ptr(res), out.data_ptr(),
+                                                    _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
+                                                    mean.data_ptr(), var.data_ptr(), momentum, eps, act, slope,
+                                                    ws.data_ptr(), st), "skd_abn_forward_train_to")
+
+    def apply_to(self, lib, x, res, out, mean, var, weight, bias, eps, act, slope, st):
+        if self.nhwc:
+            _lib.check(lib.skd_abn_apply_nhwc_to(self.rows, self.c, x.data_ptr(), _lib.ptr(res), out.data_ptr(),
+                                                 mean.data_ptr(), var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), eps,
+                                                 act, slope, st), "skd_abn_apply_nhwc_to")
+        elif res is None and out.data_ptr() == x.data_ptr():
+            _lib.check(lib.skd_abn_apply(self.n, self.c, self.s, x.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                         _lib.ptr(weight), _lib.ptr(bias), eps, act, slope, st), "skd_abn_apply")
+        else:
+            _lib.check(lib.skd_abn_apply_to(self.n, self.c, self.s, x.data_ptr(), _lib.ptr(res), out.data_ptr(),
+                                            mean.data_ptr(), var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), eps, act,
+                                            slope, st), "skd_abn_apply_to")
+
+    def backward_reduce(self, lib, z, dz, weight, bias, edz, eydz, eps, act, slope, ws, st):
+        fn = lib.skd_abn_backward_reduce_nhwc if self.nhwc else lib.skd_abn_backward_reduce
+        _lib.check(fn(*self._d(), z.data_ptr(), dz.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(),
+                      eydz.data_ptr(), eps, act, slope, ws.data_ptr(), st), "skd_abn_backward_reduce")
+
+    def backward_dx(self, lib, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, st):
+        fn = lib.skd_abn_backward_dx_nhwc if self.nhwc else lib.skd_abn_backward_dx
+        _lib.check(fn(*self._d(), z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                      edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight), _lib.ptr(dbias), eps, act, slope,
+                      st), "skd_abn_backward_dx")
+
+    def relu_backward_reduce(self, lib, x, out, dout, mean, var, edz, eydz, eps, ws, st):
+        fn = lib.skd_abn_relu_backward_reduce_nhwc if self.nhwc else lib.skd_abn_relu_backward_reduce
+        _lib.check(fn(*self._d(), x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                      edz.data_ptr(), eydz.data_ptr(), eps, ws.data_ptr(), st), "skd_abn_relu_backward_reduce")
+
+    def relu_backward_dx(self, lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, st):
+        fn = lib.skd_abn_relu_backward_dx_nhwc if self.nhwc else lib.skd_abn_relu_backward_dx
+        _lib.check(fn(*self._d(), x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                      _lib.ptr(weight), edz.data_ptr(), eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres),
+                      _lib.ptr(dweight), _lib.ptr(dbias), eps, st), "skd_abn_relu_backward_dx")
+
+
+def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib, st):
+    """Cross-replica statistics (libs/functions.py:185-209): all_gather [mean, var], the reference combine rule,
+    running-stat update with n = count * replicas.  Returns contiguous (mean, var)."""
+    g = _group_size(group)
+    gathered = stat.new_empty((g, 2, c))
+    dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=group)
+    mean, var = combine_replica_stats(gathered)
+    mean, var = mean.contiguous(), var.contiguous()
+    if running_mean is not None:
+        _lib.check(lib.skd_abn_update_running(c, running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
+                                              var.data_ptr(), float(momentum), float(count * g), st),
+                   "skd_abn_update_running")
+    return mean, var
+
+
 class _InPlaceABN(autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps,
@@ -89,49 +198,32 @@ class _InPlaceABN(autograd.Function):
         ctx.group = group if (group is not None and _group_size(group) > 1) else None
         if x.dim() < 2:
             raise ValueError("InPlaceABN expects (N, C, ...) input")
-        _check_contiguous(x, weight, bias, running_mean, running_var)
-        n, c, s = _dims(x)
-        lib = _lib.get()
-        st = _lib.stream_of(x)
-
+        _check_contiguous(weight, bias, running_mean, running_var)
         if x.numel() == 0:
+            _check_contiguous(x)
             ctx.var = running_var
             ctx.save_for_backward(x, weight, bias)
             ctx.mark_dirty(x)
             return x
+        geo = _Geom(x)          # raises ValueError("Non-contiguous input") like libs/functions.py:65-67
+        c = geo.c
+        lib = _lib.get()
+        st = _lib.stream_of(x)
 
         if ctx.training:
             stat = x.new_empty((2, c))
             mean, var = stat[0], stat[1]
-            ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+            ws = geo.workspace(lib, x)
             if ctx.group is None:
-                _lib.check(lib.skd_abn_forward_train(
-                    n, c, s, x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
-                    _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(),
-                    float(momentum), ctx.eps, ctx.act, ctx.slope, ws.data_ptr(), st),
-                    "skd_abn_forward_train")
+                geo.forward_train(lib, x, None, x, weight, bias, running_mean, running_var, mean, var, float(momentum),
+                                  ctx.eps, ctx.act, ctx.slope, ws, st)
             else:
-                g = _group_size(ctx.group)
-                _lib.check(lib.skd_abn_stats(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                                             ws.data_ptr(), st), "skd_abn_stats")
-                gathered = x.new_empty((g, 2, c))
-                dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=ctx.group)
-                mean, var = combine_replica_stats(gathered)
-                mean, var = mean.contiguous(), var.contiguous()
-                if running_mean is not None:
-                    # libs/functions.py:177,208-209: n counts the samples of ALL replicas
-                    _lib.check(lib.skd_abn_update_running(
-                        c, running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
-                        var.data_ptr(), float(momentum), float(n * s * g), st),
-                        "skd_abn_update_running")
-                _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                                             _lib.ptr(weight), _lib.ptr(bias), ctx.eps, ctx.act,
-                                             ctx.slope, st), "skd_abn_apply")
+                geo.stats(lib, x, mean, var, ws, st)
+                mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
+                geo.apply_to(lib, x, None, x, mean, var, weight, bias, ctx.eps, ctx.act, ctx.slope, st)
         else:
             var = running_var
-            _lib.check(lib.skd_abn_apply(n, c, s, x.data_ptr(), running_mean.data_ptr(),
-                                         running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
-                                         ctx.eps, ctx.act, ctx.slope, st), "skd_abn_apply")
+            geo.apply_to(lib, x, None, x, running_mean, running_var, weight, bias, ctx.eps, ctx.act, ctx.slope, st)
 
         ctx.var = var
         ctx.save_for_backward(x, weight, bias)
@@ -145,14 +237,15 @@ class _InPlaceABN(autograd.Function):
         var = ctx.var
         del ctx.var
         need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
-        n, c, s = _dims(z)
         if z.numel() == 0:
             return (torch.zeros_like(z) if need_dx else None,
                     torch.zeros_like(weight) if need_dw and weight is not None else None,
                     torch.zeros_like(bias) if need_db and bias is not None else None,
                     None, None, None, None, None, None, None, None)
-        dz = dz.contiguous()
-        if not _same_phase(z, dz):
+        geo = _Geom(z)
+        c = geo.c
+        dz = geo.like(dz)
+        if not geo.nhwc and not _same_phase(z, dz):
             dz = dz.clone(memory_format=torch.contiguous_format)
         lib = _lib.get()
         st = _lib.stream_of(z)
@@ -160,78 +253,58 @@ class _InPlaceABN(autograd.Function):
         dx = torch.empty_like(z) if need_dx else None
         dweight = torch.zeros_like(weight) if (need_dw and weight is not None) else None
         dbias = torch.zeros_like(bias) if (need_db and bias is not None) else None
-        stat = z.new_empty((2, c))
+        stat = z.new_zeros((2, c))          # functions.py:146-147: inference-mode backward uses edz = eydz = 0
         edz, eydz = stat[0], stat[1]
-        ws = z.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
-
-        if ctx.group is None or not ctx.training:
-            _lib.check(lib.skd_abn_backward(
-                n, c, s, z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight),
-                _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight),
-                _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, 1 if ctx.training else 0,
-                ws.data_ptr(), st), "skd_abn_backward")
-        else:
-            _lib.check(lib.skd_abn_backward_reduce(
-                n, c, s, z.data_ptr(), dz.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
-                edz.data_ptr(), eydz.data_ptr(), ctx.eps, ctx.act, ctx.slope, ws.data_ptr(), st),
-                "skd_abn_backward_reduce")
-            # libs/functions.py:271-272: reduce_add(...) / number of replicas
-            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)
-            stat.div_(_group_size(ctx.group))
-            _lib.check(lib.skd_abn_backward_dx(
-                n, c, s, z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight),
-                _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight),
-                _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, st), "skd_abn_backward_dx")
-        return dx, dweight, dbias, None, None, None, None, None, None, None, None
+        if ctx.training:
+            ws = geo.workspace(lib, z)
+            geo.backward_reduce(lib, z, dz, weight, bias, edz, eydz, ctx.eps, ctx.act, ctx.slope, ws, st)
+            if ctx.group is not None:
+                dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)   # libs/functions.py:271-272
+                stat.div_(_group_size(ctx.group))
+        if dx is None and geo.nhwc:
+            dx = torch.empty_like(z)        # the channels-last dx entry always writes dx
+        geo.backward_dx(lib, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, ctx.eps, ctx.act, ctx.slope, st)
+        return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None, None
 
 
 class _ABNRelu(autograd.Function):
-    """Training-time ``relu(bn(x) [+ residual])`` as one op (csrc/abn.hip, "out of place" section).
+    """Training-time ``relu(bn(x) [+ residual])`` as one op (csrc/abn.hip, "out of place" sections).
 
     The reference runs InPlace-ABN(activation='none') and then nn.ReLU -- at the tail of a residual block
     ``out + residual`` in between (networks/pspnet_combine.py:36-43, 68-82) -- keeping z and relu(z) alive.  Here the
     convolution output x is kept instead of z (y is recomputed from x, mean, var in backward) and ``out`` is the
     ReLU output, so the same two tensors per layer live on while the separate ReLU / add passes disappear.
-    Cross-replica statistics exactly as in _InPlaceABN."""
+    Works on NCHW and on channels-last tensors; cross-replica statistics exactly as in _InPlaceABN."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, group):
         _lib.require_device(x, weight, bias, running_mean, running_var, residual)
         if x.dtype != torch.float32:
             raise TypeError("InPlaceABN kernels are fp32 only (got %s)" % x.dtype)
-        _check_contiguous(x, weight, bias, running_mean, running_var)
+        _check_contiguous(weight, bias, running_mean, running_var)
         ctx.eps = float(eps)
         ctx.group = group if (group is not None and _group_size(group) > 1) else None
-        n, c, s = _dims(x)
+        geo = _Geom(x)
+        c = geo.c
         lib, st = _lib.get(), _lib.stream_of(x)
         out = torch.empty_like(x)
-        if residual is not None and (not residual.is_contiguous() or not _same_phase(x, residual)):
-            residual = residual.clone(memory_format=torch.contiguous_format)
-        if not _same_phase(x, out):   # cannot happen with the caching allocator's 512-byte granularity; be safe
+        if residual is not None:
+            residual = geo.like(residual)
+            if not geo.nhwc and not _same_phase(x, residual):
+                residual = residual.clone(memory_format=torch.contiguous_format)
+        if not geo.nhwc and not _same_phase(x, out):   # cannot happen with the caching allocator's 512-byte granularity
             raise RuntimeError("abn_relu: misaligned output allocation")
         stat = x.new_empty((2, c))
         mean, var = stat[0], stat[1]
-        ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
+        ws = geo.workspace(lib, x)
+        relu = _EVAL_ACT_CODE[ACT_RELU]
         if ctx.group is None:
-            _lib.check(lib.skd_abn_forward_train_to(
-                n, c, s, x.data_ptr(), _lib.ptr(residual), out.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
-                _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(), float(momentum),
-                ctx.eps, _EVAL_ACT_CODE[ACT_RELU], 0.0, ws.data_ptr(), st), "skd_abn_forward_train_to")
+            geo.forward_train(lib, x, residual, out, weight, bias, running_mean, running_var, mean, var, float(momentum),
+                              ctx.eps, relu, 0.0, ws, st)
         else:
-            g = _group_size(ctx.group)
-            _lib.check(lib.skd_abn_stats(n, c, s, x.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), st),
-                       "skd_abn_stats")
-            gathered = x.new_empty((g, 2, c))
-            dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=ctx.group)
-            mean, var = combine_replica_stats(gathered)
-            mean, var = mean.contiguous(), var.contiguous()
-            if running_mean is not None:
-                _lib.check(lib.skd_abn_update_running(c, running_mean.data_ptr(), running_var.data_ptr(),
-                                                      mean.data_ptr(), var.data_ptr(), float(momentum),
-                                                      float(n * s * g), st), "skd_abn_update_running")
-            _lib.check(lib.skd_abn_apply_to(n, c, s, x.data_ptr(), _lib.ptr(residual), out.data_ptr(), mean.data_ptr(),
-                                            var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), ctx.eps,
-                                            _EVAL_ACT_CODE[ACT_RELU], 0.0, st), "skd_abn_apply_to")
+            geo.stats(lib, x, mean, var, ws, st)
+            mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
+            geo.apply_to(lib, x, residual, out, mean, var, weight, bias, ctx.eps, relu, 0.0, st)
         ctx.has_residual = residual is not None
         ctx.save_for_backward(x, out, weight, mean, var)
         return out
@@ -242,9 +315,10 @@ class _ABNRelu(autograd.Function):
         x, out, weight, mean, var = ctx.saved_tensors
         need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
         need_res = ctx.has_residual and ctx.needs_input_grad[5]
-        n, c, s = _dims(x)
-        dout = dout.contiguous()
-        if not _same_phase(x, dout):
+        geo = _Geom(x)
+        c = geo.c
+        dout = geo.like(dout)
+        if not geo.nhwc and not _same_phase(x, dout):
             dout = dout.clone(memory_format=torch.contiguous_format)
         lib, st = _lib.get(), _lib.stream_of(x)
         dx = torch.empty_like(x)
@@ -253,17 +327,12 @@ class _ABNRelu(autograd.Function):
         dbias = torch.zeros_like(weight) if (need_db and weight is not None) else None
         stat = x.new_empty((2, c))
         edz, eydz = stat[0], stat[1]
-        ws = x.new_empty((max(1, lib.skd_abn_workspace_floats(n, c, s)),))
-        _lib.check(lib.skd_abn_relu_backward_reduce(n, c, s, x.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                                    mean.data_ptr(), var.data_ptr(), edz.data_ptr(), eydz.data_ptr(),
-                                                    ctx.eps, ws.data_ptr(), st), "skd_abn_relu_backward_reduce")
+        ws = geo.workspace(lib, x)
+        geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st)
         if ctx.group is not None:
             dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)   # libs/functions.py:271-272
             stat.div_(_group_size(ctx.group))
-        _lib.check(lib.skd_abn_relu_backward_dx(n, c, s, x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(),
-                                                var.data_ptr(), _lib.ptr(weight), edz.data_ptr(), eydz.data_ptr(),
-                                                dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight), _lib.ptr(dbias),
-                                                ctx.eps, st), "skd_abn_relu_backward_dx")
+        geo.relu_backward_dx(lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, ctx.eps, st)
         return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
 
 

@@ -96,6 +96,12 @@ class NetModel():
         print_model_parm_nums(student, "student_model")
         self.parallel_student = self.DataParallelModelProcess(student, 2, "train", device)
         self.student = student
+        # Channels-last student (SKD_STUDENT_NHWC=1): every convolution NHWC-native in MIOpen, InPlace-ABN through the
+        # skd_abn_*_nhwc training kernels.  Needs the find-db tuned for the NHWC problems (tools/miopen_tune.py).
+        self.student_nhwc = (os.environ.get("SKD_STUDENT_NHWC", "0") == "1" and torch.device(device).type == "cuda")
+        if self.student_nhwc:
+            os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
+            student.to(memory_format=torch.channels_last)
 
         teacher = Res_pspnet(Bottleneck, [3, 4, 23, 3], num_classes=args.classes_num)
         load_T_model(teacher, getattr(args, "T_ckpt_path", None))
@@ -193,12 +199,21 @@ class NetModel():
             # the three entries the criteria / D read are handed on in the reference's NCHW layout
             return [t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
 
+    def _student_forward(self):
+        args = self.args
+        if not self.student_nhwc:
+            return self.parallel_student.train()(self.images, parallel=args.parallel)
+        preds = self.parallel_student.train()(self.images.contiguous(memory_format=torch.channels_last),
+                                              parallel=args.parallel)
+        # logits / DSN logits / PSP feature go to the criteria and to D in the reference's NCHW layout
+        return [t.contiguous() for t in preds[:3]] + list(preds[3:])
+
     def forward(self):
         args = self.args
         side = self._teacher_stream
         if side is None:
             self.preds_T = self._teacher_forward()
-            self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
+            self.preds_S = self._student_forward()
             return
         # The frozen teacher does not depend on the student: run it on its own HIP stream so that the two
         # forwards fill each other's launch tails (kd_model.py:121-123 runs them back to back).  Measured +0.7 %
@@ -208,7 +223,7 @@ class NetModel():
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self.preds_T = self._teacher_forward()
-        self.preds_S = self.parallel_student.train()(self.images, parallel=args.parallel)
+        self.preds_S = self._student_forward()
         main.wait_stream(side)
         for t in self.preds_T:
             t.record_stream(main)

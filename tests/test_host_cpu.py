@@ -240,3 +240,62 @@ def test_channels_last_inference_abn_and_teacher():
         got = net(img.contiguous(memory_format=torch.channels_last))
         for a, b in zip(got, want):
             assert a.shape == b.shape and rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["leaky_inplace", "relu_fused", "relu_fused_residual", "none_inplace"])
+def test_channels_last_training_abn_vs_nchw(kind):
+    """Channels-last training ABN (skd_abn_*_nhwc through the C double) == the NCHW path on the same numbers."""
+    from structure_knowledge_distillation_amd import libs
+    torch.manual_seed(21)
+    act = {"leaky_inplace": "leaky_relu", "none_inplace": "none"}.get(kind, "none")
+    x, r, g = torch.randn(3, 8, 6, 5) * 2 + 0.3, torch.randn(3, 8, 6, 5), torch.randn(3, 8, 6, 5)
+    res = {}
+    for fmt in ("nchw", "nhwc"):
+        mod = libs.InPlaceABNSync(8, activation=act).train()
+        with torch.no_grad():
+            mod.weight.copy_(torch.linspace(-1, 1.5, 8)); mod.bias.copy_(torch.linspace(0.5, -0.5, 8))
+        mf = torch.channels_last if fmt == "nhwc" else torch.contiguous_format
+        xg = x.clone().contiguous(memory_format=mf).requires_grad_(True)
+        rg = r.clone().contiguous(memory_format=mf).requires_grad_(True)
+        xin = (xg * 1.0).contiguous(memory_format=mf)
+        if kind.startswith("relu"):
+            out = mod.forward_relu(xin, rg if kind.endswith("residual") else None)
+        else:
+            out = mod(xin)
+            assert out.data_ptr() == xin.data_ptr()
+        assert out.is_contiguous(memory_format=mf)
+        out.backward(g.contiguous(memory_format=mf))
+        res[fmt] = (out.detach(), xg.grad, mod.weight.grad, mod.bias.grad, mod.running_mean.clone(), mod.running_var.clone(),
+                    rg.grad if kind.endswith("residual") else torch.zeros(1))
+    for a, b in zip(res["nhwc"], res["nchw"]):
+        assert rel(a, b) < 1e-5
+    with pytest.raises(ValueError):   # 6 channels: not a power of two -> no channels-last training kernels
+        libs.InPlaceABN(6).train()(torch.randn(2, 6, 4, 4).contiguous(memory_format=torch.channels_last))
+
+
+def test_student_channels_last_training_graph():
+    """The student network in channels-last (every ABN through the NHWC training entries, PPM / criteria fed NCHW
+    copies) gives the same outputs and parameter gradients as the NCHW network."""
+    from structure_knowledge_distillation_amd.networks import pspnet_combine as PC
+    torch.manual_seed(31)
+    net = PC.Res_pspnet(PC.BasicBlock, [2, 2, 2, 2], 19).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    import copy
+    net2 = copy.deepcopy(net).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 97, 65) * 57
+    outs1 = net(x)
+    outs2 = net2(x.contiguous(memory_format=torch.channels_last))
+    g = [torch.randn_like(o) for o in outs1[:3]]
+    sum((o * gg).sum() for o, gg in zip(outs1[:3], g)).backward()
+    sum((o * gg).sum() for o, gg in zip(outs2[:3], g)).backward()
+    for a, b in zip(outs2, outs1):
+        assert a.shape == b.shape and rel(a, b) < 2e-5
+    p1, p2 = dict(net.named_parameters()), dict(net2.named_parameters())
+    for k in p1:
+        # fp32 reassociation through the BN chains; a conv bias that feeds a BN has a zero true gradient (noise only)
+        assert float((p2[k].grad - p1[k].grad).norm()) <= 5e-3 * float(p1[k].grad.norm()) + 1e-4, k
+    b1, b2 = dict(net.named_buffers()), dict(net2.named_buffers())
+    for k in b1:
+        assert rel(b2[k], b1[k]) < 1e-5, k

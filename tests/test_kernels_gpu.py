@@ -221,6 +221,66 @@ def test_abn_apply_nhwc(hip, ref, rows, C, act):
     assert hip.skd_abn_apply_nhwc(rows, 6, P(gpu(x)), None, P(gpu(rm)), P(gpu(rv)), None, None, 1e-5, 0, 0.01, None) == 0   # C % 4
 
 
+@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 128), (8 * 129 * 129, 64), (2 * 33 * 33, 512), (8 * 36, 128), (50, 4), (1000, 1024)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_abn_nhwc_training(hip, ref, rows, C, act):
+    """Channels-last training entries vs the C oracle: in-place ABN (act none / leaky) and the fused BN+ReLU form."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + torch.randn(1, C, generator=g) * 5
+    r = torch.randn(rows, C, generator=g)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w[0], w[1] = 0.0, -abs(float(w[1]))
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    ws_r = torch.empty(max(1, ref.skd_abn_nhwc_workspace_floats(rows, C)))
+    ws_g = torch.empty(max(1, hip.skd_abn_nhwc_workspace_floats(rows, C)), device=DEV)
+    # in place, activation `act`
+    zr, mr, vr, rmr, rvr = x.clone(), torch.empty(C), torch.empty(C), rm.clone(), rv.clone()
+    assert ref.skd_abn_forward_train_nhwc(rows, C, P(zr), None, P(zr), P(w), P(b), P(rmr), P(rvr), P(mr), P(vr), 0.1, 1e-5, act, 0.01, P(ws_r), None)
+    zg, mg, vg, rmg, rvg = gpu(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV), gpu(rm), gpu(rv)
+    assert hip.skd_abn_forward_train_nhwc(rows, C, P(zg), None, P(zg), P(gpu(w)), P(gpu(b)), P(rmg), P(rvg), P(mg), P(vg), 0.1, 1e-5, act, 0.01, P(ws_g), None)
+    close(mg, mr, 2e-5, "mean"); close(vg, vr, 5e-5, "var"); close(rmg, rmr, 2e-6, "running_mean"); close(rvg, rvr, 1e-5, "running_var")
+    close(zg, zr, 3e-5, "z")
+    m2, v2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    assert hip.skd_abn_stats_nhwc(rows, C, P(gpu(x)), P(m2), P(v2), P(ws_g), None)
+    close(m2, mr, 2e-5, "stats mean"); close(v2, vr, 5e-5, "stats var")
+    dz = torch.randn(rows, C, generator=g)
+    er, eyr, eg, eyg = torch.empty(C), torch.empty(C), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    assert ref.skd_abn_backward_reduce_nhwc(rows, C, P(zr), P(dz), P(w), P(b), P(er), P(eyr), 1e-5, act, 0.01, P(ws_r), None)
+    assert hip.skd_abn_backward_reduce_nhwc(rows, C, P(gpu(zr)), P(gpu(dz)), P(gpu(w)), P(gpu(b)), P(eg), P(eyg), 1e-5, act, 0.01, P(ws_g), None)
+    close(eg, er, 5e-5, "edz"); close(eyg, eyr, 5e-5, "eydz", floor=float(eyr.abs().max()) * 1e-1)
+    dxr, dwr, dbr = torch.empty_like(x), torch.zeros(C), torch.zeros(C)
+    assert ref.skd_abn_backward_dx_nhwc(rows, C, P(zr), P(dz), P(vr), P(w), P(b), P(er), P(eyr), P(dxr), P(dwr), P(dbr), 1e-5, act, 0.01, None)
+    dxg, dwg, dbg = torch.empty(rows, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    assert hip.skd_abn_backward_dx_nhwc(rows, C, P(gpu(zr)), P(gpu(dz)), P(gpu(vr)), P(gpu(w)), P(gpu(b)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(dwg), P(dbg), 1e-5, act, 0.01, None)
+    mul = float(((w.abs() + 1e-5) / torch.sqrt(vr + 1e-5)).max())
+    close(dxg, dxr, 1e-4, "dx", floor=float(dz.abs().max()) * mul)
+    close(dwg, dwr, 5e-5, "dweight", floor=1e-6); close(dbg, dbr, 5e-5, "dbias", floor=1e-6)
+    # fused BN -> (+ residual) -> ReLU, out of place
+    for res in (None, r):
+        outr, outg = torch.empty_like(x), torch.empty(rows, C, device=DEV)
+        assert ref.skd_abn_forward_train_nhwc(rows, C, P(x), P(res), P(outr), P(w), P(b), None, None, P(mr), P(vr), 0.1, 1e-5, 3, 0.0, P(ws_r), None)
+        xg = gpu(x)
+        assert hip.skd_abn_forward_train_nhwc(rows, C, P(xg), P(gpu(res)), P(outg), P(gpu(w)), P(gpu(b)), None, None, P(mg), P(vg), 0.1, 1e-5, 3, 0.0, P(ws_g), None)
+        close(outg, outr, 3e-5, "relu out")
+        assert torch.equal(xg.cpu(), x)
+        out2 = torch.empty(rows, C, device=DEV)
+        assert hip.skd_abn_apply_nhwc_to(rows, C, P(xg), P(gpu(res)), P(out2), P(gpu(mr)), P(gpu(vr)), P(gpu(w)), P(gpu(b)), 1e-5, 3, 0.0, None)
+        close(out2, outr, 3e-5, "apply_to")
+        assert ref.skd_abn_relu_backward_reduce_nhwc(rows, C, P(x), P(outr), P(dz), P(mr), P(vr), P(er), P(eyr), 1e-5, P(ws_r), None)
+        assert hip.skd_abn_relu_backward_reduce_nhwc(rows, C, P(xg), P(gpu(outr)), P(gpu(dz)), P(gpu(mr)), P(gpu(vr)), P(eg), P(eyg), 1e-5, P(ws_g), None)
+        close(eg, er, 5e-5, "relu edz"); close(eyg, eyr, 5e-5, "relu eydz")
+        drr = torch.empty_like(x) if res is not None else None
+        drg = torch.empty(rows, C, device=DEV) if res is not None else None
+        dwr.zero_(); dbr.zero_(); dwg.zero_(); dbg.zero_()
+        assert ref.skd_abn_relu_backward_dx_nhwc(rows, C, P(x), P(outr), P(dz), P(mr), P(vr), P(w), P(er), P(eyr), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, None)
+        assert hip.skd_abn_relu_backward_dx_nhwc(rows, C, P(xg), P(gpu(outr)), P(gpu(dz)), P(gpu(mr)), P(gpu(vr)), P(gpu(w)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, None)
+        close(dxg, dxr, 1e-4, "relu dx", floor=float(dz.abs().max()) * mul)
+        close(dwg, dwr, 5e-5, "relu dweight", floor=1e-6); close(dbg, dbr, 5e-5, "relu dbias", floor=1e-6)
+        if res is not None:
+            assert torch.equal(drg.cpu(), drr)
+    assert hip.skd_abn_nhwc_workspace_floats(100, 48) == 0     # not a power of two: caller must use NCHW
+
+
 def test_abn_legacy_entries(hip, ref):
     """The nine reference exports (libs/src/bn.h:7-19) with their original argument lists."""
     N, C, S = 3, 6, 257

@@ -20,6 +20,8 @@ PHASES = {  # name: (batch, find, what, timeout_s)
     "teacher8_nhwc": (8, True, "teacher_nhwc", 500),
     "student8": (8, True, "student", 900),
     "full8": (8, True, "full", 400),
+    "full8_nhwc": (8, True, "full_nhwc", 900),
+    "full2_nhwc": (2, False, "full_nhwc", 400),
     "full2": (2, False, "full", 400),
 }
 
@@ -28,13 +30,14 @@ def child(phase):
     sys.path.insert(0, ROOT)
     batch, find, what, _ = PHASES[phase]
     os.environ["SKD_MIOPEN_FIND"] = "1" if find else "0"
-    os.environ["SKD_TEACHER_NHWC"] = "1" if what == "teacher_nhwc" else os.environ.get("SKD_TEACHER_NHWC", "0")
+    os.environ["SKD_TEACHER_NHWC"] = "1" if what in ("teacher_nhwc", "full_nhwc") else os.environ.get("SKD_TEACHER_NHWC", "0")
+    os.environ["SKD_STUDENT_NHWC"] = "1" if what == "full_nhwc" else "0"
     import torch
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     t0 = time.time()
-    args = default_args(batch_size=batch, device=dev, ho=(what == "full"), weight_decay=5e-4, lambda_pa=0.5)
+    args = default_args(batch_size=batch, device=dev, ho=(what in ("full", "full_nhwc")), weight_decay=5e-4, lambda_pa=0.5)
     model = NetModel(args)
     x = torch.randn(batch, 3, 512, 512, device=dev) * 57
     y = torch.randint(0, 19, (batch, 512, 512), device=dev)
