@@ -98,7 +98,7 @@ class NetModel():
         self.student = student
         # Channels-last student (SKD_STUDENT_NHWC=1): every convolution NHWC-native in MIOpen, InPlace-ABN through the
         # skd_abn_*_nhwc training kernels.  Needs the find-db tuned for the NHWC problems (tools/miopen_tune.py).
-        self.student_nhwc = (os.environ.get("SKD_STUDENT_NHWC", "0") == "1" and torch.device(device).type == "cuda")
+        self.student_nhwc = (os.environ.get("SKD_STUDENT_NHWC", "1") == "1" and torch.device(device).type == "cuda")
         if self.student_nhwc:
             os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
             student.to(memory_format=torch.channels_last)
