@@ -96,6 +96,7 @@ class NetModel():
         print_model_parm_nums(student, "student_model")
         self.parallel_student = self.DataParallelModelProcess(student, 2, "train", device)
         self.student = student
+        parallel_old.broadcast_module(student)      # every replica starts from rank 0's weights
         # Channels-last student (SKD_STUDENT_NHWC=1): every convolution NHWC-native in MIOpen, InPlace-ABN through the
         # skd_abn_*_nhwc training kernels.  Needs the find-db tuned for the NHWC problems (tools/miopen_tune.py).
         self.student_nhwc = (os.environ.get("SKD_STUDENT_NHWC", "1") == "1" and torch.device(device).type == "cuda")
@@ -108,15 +109,16 @@ class NetModel():
         print_model_parm_nums(teacher, "teacher_model")
         for p in teacher.parameters():
             p.requires_grad_(False)
+        self.parallel_teacher = self.DataParallelModelProcess(teacher, 2, "eval", device)
+        self.teacher = teacher
+        parallel_old.broadcast_module(teacher)
         # The frozen teacher runs channels-last: MIOpen's fastest fp32 kernels on gfx950 are NHWC igemm kernels, and
         # with NCHW tensors MIOpen wraps each of them in NCHW<->NHWC transposes (5.6 ms per step, profiles/).  Its
-        # eval-mode BN (+ReLU, +residual) has an NHWC kernel (skd_abn_apply_nhwc); the student stays NCHW.
+        # eval-mode BN (+ReLU, +residual) has an NHWC kernel (skd_abn_apply_nhwc).
         self.teacher_nhwc = (os.environ.get("SKD_TEACHER_NHWC", "1") == "1" and torch.device(device).type == "cuda")
         if self.teacher_nhwc:
             os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
             teacher.to(memory_format=torch.channels_last)
-        self.parallel_teacher = self.DataParallelModelProcess(teacher, 2, "eval", device)
-        self.teacher = teacher
 
         D_model = Discriminator(args.preprocess_GAN_mode, args.classes_num, args.batch_size,
                                 args.imsize_for_adv, args.adv_conv_dim)
@@ -124,9 +126,7 @@ class NetModel():
         self.parallel_D = self.DataParallelModelProcess(D_model, 2, "train", device)
         self.D_model = D_model
 
-        # every replica starts from rank 0's weights (the reference re-broadcasts them every forward)
-        for m in (student, teacher, D_model):
-            parallel_old.broadcast_module(m)
+        parallel_old.broadcast_module(D_model)      # (the reference re-broadcasts all three every forward)
 
         self._s_params = [p for p in self.student.parameters() if p.requires_grad]
         self._d_params = [p for p in D_model.parameters() if p.requires_grad]
