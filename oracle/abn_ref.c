@@ -467,3 +467,22 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
   free(px); free(po); free(pd); free(pdx); free(pdr);
   return r;
 }
+
+/* ---- cross-replica combine, libs/functions.py:196-197 + 208-209 ---- */
+int skd_abn_combine_stats(int G, int C, const float *gathered, float *mean, float *var, float *rm, float *rv,
+                          float momentum, double n, stream_t st) {
+  if (G <= 0 || C <= 0 || !gathered || !mean || !var) return 0;
+  for (int c = 0; c < C; ++c) {
+    double m = 0.0, v = 0.0;
+    for (int g = 0; g < G; ++g) m += gathered[((int64_t)g * 2) * C + c];
+    m /= G;                                                        /* means.mean(0) */
+    for (int g = 0; g < G; ++g) {
+      const double d = m - gathered[((int64_t)g * 2) * C + c];
+      v += gathered[((int64_t)g * 2 + 1) * C + c] + d * d;         /* (vars + (mean - means)**2).mean(0) */
+    }
+    mean[c] = (float)m;
+    var[c] = (float)(v / G);
+  }
+  if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, n, st);
+  return 1;
+}

@@ -224,6 +224,28 @@ __global__ __launch_bounds__(kThreads) void abn_stats_finalize_kernel(
   }
 }
 
+// Cross-replica combine (libs/functions.py:196-197, 208-209) in one launch: gathered is (G, 2, C) = per-rank
+// [mean, var]; mean = means.mean(0); var = (vars + (mean - means)^2).mean(0); running stats with n = count * G.
+__global__ void abn_combine_stats_kernel(int G, int C, const float *__restrict__ gathered, float *__restrict__ mean,
+                                         float *__restrict__ var, float *running_mean, float *running_var,
+                                         float momentum, float nf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m = 0.f;
+  for (int g = 0; g < G; ++g) m += gathered[((int64_t)g * 2) * C + c];
+  m /= (float)G;
+  float v = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float d = m - gathered[((int64_t)g * 2) * C + c];
+    v += gathered[((int64_t)g * 2 + 1) * C + c] + d * d;
+  }
+  v /= (float)G;
+  mean[c] = m;
+  var[c] = v;
+  if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m;
+  if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * v * nf / (nf - 1.f);
+}
+
 __global__ void abn_update_running_kernel(int C, float *running_mean, float *running_var,
                                           const float *mean, const float *var, float momentum,
                                           float nf) {
@@ -1188,6 +1210,14 @@ int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, 
   abn_stats_partial_kernel<<<dim3((unsigned)pl.items), dim3(kThreads), 0, st>>>(x, workspace, N, C, S, pl);
   abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
       x, workspace, mean, var, nullptr, nullptr, N, C, S, pl.P, 0.f, 0.0);
+  return ok();
+}
+
+int skd_abn_combine_stats(int G, int C, const float *gathered, float *mean, float *var, float *running_mean,
+                          float *running_var, float momentum, double n, skd_stream_t stream) {
+  if (G <= 0 || C <= 0 || !gathered || !mean || !var) return 0;
+  abn_combine_stats_kernel<<<dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream)>>>(
+      G, C, gathered, mean, var, running_mean, running_var, momentum, (float)n);
   return ok();
 }
 

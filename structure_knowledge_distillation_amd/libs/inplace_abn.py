@@ -175,13 +175,11 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
     g = _group_size(group)
     gathered = stat.new_empty((g, 2, c))
     dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=group)
-    mean, var = combine_replica_stats(gathered)
-    mean, var = mean.contiguous(), var.contiguous()
-    if running_mean is not None:
-        _lib.check(lib.skd_abn_update_running(c, running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
-                                              var.data_ptr(), float(momentum), float(count * g), st),
-                   "skd_abn_update_running")
-    return mean, var
+    out = stat.new_empty((2, c))
+    _lib.check(lib.skd_abn_combine_stats(g, c, gathered.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                         _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
+                                         float(count * g), st), "skd_abn_combine_stats")
+    return out[0], out[1]
 
 
 class _InPlaceABN(autograd.Function):

@@ -281,6 +281,23 @@ def test_abn_nhwc_training(hip, ref, rows, C, act):
     assert hip.skd_abn_nhwc_workspace_floats(100, 48) == 0     # not a power of two: caller must use NCHW
 
 
+@pytest.mark.parametrize("G,C", [(2, 6), (8, 512), (1, 64), (3, 1000)])
+def test_abn_combine_stats(hip, ref, G, C):
+    """Cross-replica statistics combine (functions.py:196-197) + running update with n = count * G."""
+    g = torch.Generator().manual_seed(G * C)
+    gathered = torch.cat([torch.randn(G, 1, C, generator=g), torch.rand(G, 1, C, generator=g) + 0.1], 1).contiguous()
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    mr, vr, rmr, rvr = torch.empty(C), torch.empty(C), rm.clone(), rv.clone()
+    assert ref.skd_abn_combine_stats(G, C, P(gathered), P(mr), P(vr), P(rmr), P(rvr), 0.1, float(4225 * 8 * G), None)
+    mg, vg, rmg, rvg = torch.empty(C, device=DEV), torch.empty(C, device=DEV), gpu(rm), gpu(rv)
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(mg), P(vg), P(rmg), P(rvg), 0.1, float(4225 * 8 * G), None)
+    close(mg, mr, 1e-6, "mean"); close(vg, vr, 1e-6, "var"); close(rmg, rmr, 1e-6, "running_mean"); close(rvg, rvr, 1e-6, "running_var")
+    want_m = gathered[:, 0].double().mean(0)
+    want_v = (gathered[:, 1].double() + (want_m - gathered[:, 0].double()) ** 2).mean(0)
+    close(mg, want_m.float(), 1e-6, "mean vs formula"); close(vg, want_v.float(), 1e-6, "var vs formula")
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(mg), P(vg), None, None, 0.1, 100.0, None)   # no running buffers
+
+
 def test_abn_legacy_entries(hip, ref):
     """The nine reference exports (libs/src/bn.h:7-19) with their original argument lists."""
     N, C, S = 3, 6, 257
