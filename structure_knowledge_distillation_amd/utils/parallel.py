@@ -132,12 +132,16 @@ class GradientAllReducer:
 
     def _launch(self, b):
         with torch.no_grad():
+            dsts, srcs = [], []
             for p, o in zip(b.params, b.offsets):
                 seg = b.flat[o:o + p.numel()]
                 if p.grad is None:
                     seg.zero_()
                 else:
-                    seg.copy_(p.grad.reshape(-1))
+                    dsts.append(seg.view(p.shape))      # logical (N, C, H, W) order whatever the grad's strides
+                    srcs.append(p.grad)
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)         # one multi-tensor launch per bucket, not one per parameter
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
@@ -154,12 +158,16 @@ class GradientAllReducer:
             for b in self.buckets:
                 b.work.wait()
                 b.flat.mul_(inv)
+                dsts, srcs = [], []
                 for p, o in zip(b.params, b.offsets):
-                    seg = b.flat[o:o + p.numel()].view_as(p)
+                    seg = b.flat[o:o + p.numel()].view(p.shape)
                     if p.grad is None:
                         p.grad = seg.clone()
                     else:
-                        p.grad.copy_(seg)
+                        dsts.append(p.grad)
+                        srcs.append(seg)
+                if dsts:
+                    torch._foreach_copy_(dsts, srcs)
                 b.work = None
         self.armed = False
 
