@@ -298,6 +298,39 @@ def test_abn_combine_stats(hip, ref, G, C):
     assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(mg), P(vg), None, None, 0.1, 100.0, None)   # no running buffers
 
 
+def test_abn_reference_corner_semantics(hip, ref):
+    """bn.cu:148-151: invStd = 0 when var == 0 and eps == 0;  bn.cu:153: gamma = 1 / beta = 0 without affine
+    parameters (NULL pointers), forward and backward;  constant input (var == 0) with the default eps."""
+    N, C, S = 2, 4, 33
+    x = torch.randn(N, C, S)
+    mean, var = torch.zeros(C), torch.tensor([0.0, 1.0, 0.0, 2.0])
+    zr, zg = x.clone(), gpu(x)
+    assert ref.skd_abn_apply(N, C, S, P(zr), P(mean), P(var), None, None, 0.0, 0, 0.01, None)
+    assert hip.skd_abn_apply(N, C, S, P(zg), P(gpu(mean)), P(gpu(var)), None, None, 0.0, 0, 0.01, None)
+    close(zg, zr, 1e-6, "eps = 0")
+    assert float(zg[:, 0].abs().max()) == 0.0 and float(zg[:, 2].abs().max()) == 0.0     # invStd = 0 -> y = 0
+    # non-affine training forward + backward through the fused entries
+    xr, xg = x.clone(), gpu(x)
+    mr, vr, mg, vg = torch.empty(C), torch.empty(C), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws = torch.empty(max(1, hip.skd_abn_workspace_floats(N, C, S)), device=DEV)
+    assert ref.skd_abn_forward_train(N, C, S, P(xr), None, None, None, None, P(mr), P(vr), 0.1, 1e-5, 1, 0.01, P(torch.empty(2 * C)), None)
+    assert hip.skd_abn_forward_train(N, C, S, P(xg), None, None, None, None, P(mg), P(vg), 0.1, 1e-5, 1, 0.01, P(ws), None)
+    close(xg, xr, 3e-5, "non-affine z")
+    dz = torch.randn(N, C, S)
+    dxr, er, eyr = torch.empty_like(x), torch.empty(C), torch.empty(C)
+    assert ref.skd_abn_backward(N, C, S, P(xr), P(dz), P(vr), None, None, P(er), P(eyr), P(dxr), None, None, 1e-5, 1, 0.01, 1, P(torch.empty(2 * C)), None)
+    dxg, eg, eyg = torch.empty(N, C, S, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    assert hip.skd_abn_backward(N, C, S, P(gpu(xr)), P(gpu(dz)), P(gpu(vr)), None, None, P(eg), P(eyg), P(dxg), None, None, 1e-5, 1, 0.01, 1, P(ws), None)
+    close(dxg, dxr, 1e-4, "non-affine dx", floor=float(dz.abs().max()))
+    # constant channel: var == 0 exactly (the shifted one-pass sums are exact zeros), z = beta
+    xc = torch.full((N, C, S), 3.25)
+    w, b = torch.ones(C), torch.tensor([0.5, -1.0, 2.0, 0.0])
+    xcg = gpu(xc)
+    assert hip.skd_abn_forward_train(N, C, S, P(xcg), P(gpu(w)), P(gpu(b)), None, None, P(mg), P(vg), 0.1, 1e-5, 0, 0.01, P(ws), None)
+    assert float(vg.abs().max()) == 0.0 and torch.allclose(mg.cpu(), torch.full((C,), 3.25))
+    assert torch.allclose(xcg.cpu(), b.view(1, C, 1).expand(N, C, S))
+
+
 def test_abn_legacy_entries(hip, ref):
     """The nine reference exports (libs/src/bn.h:7-19) with their original argument lists."""
     N, C, S = 3, 6, 257
