@@ -138,8 +138,10 @@ def summarise(recs, bytes_per_elem, nhwc=False):
     a residual."""
     if not recs:
         return None
-    if nhwc:
+    if nhwc == "apply":
         recs = [(ms, (d[0], d[1], 1.5 if d[3] else 1.0)) for ms, d in recs]      # third factor scales 8 -> 12 B
+    elif nhwc:
+        recs = [(ms, (d[0], d[1], 1.0)) for ms, d in recs]
     else:
         recs = [(ms, (d[0], d[1], d[2])) for ms, d in recs]
     tot_ms = sum(ms for ms, _ in recs)
@@ -197,7 +199,9 @@ def main():
     for i in range(a.warmup):
         step(i)
     timed = ["skd_abn_apply_nhwc", "skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
-             "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx"]
+             "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx",
+             "skd_abn_forward_train_nhwc", "skd_abn_backward_reduce_nhwc", "skd_abn_backward_dx_nhwc",
+             "skd_abn_relu_backward_reduce_nhwc", "skd_abn_relu_backward_dx_nhwc"]
     if not a.no_kernel_timing and rank == 0:
         _lib.enable_kernel_timing(timed)
     fence()
@@ -231,7 +235,7 @@ def main():
     }
     nhwc_recs = recs.get("skd_abn_apply_nhwc", [])
     if len(nhwc_recs) > len(recs.get("skd_abn_apply", [])):
-        ap = summarise(nhwc_recs, 8, nhwc=True)
+        ap = summarise(nhwc_recs, 8, nhwc="apply")
         pmc_kernel = "abn_apply_nhwc_kernel<3, false, 1>"
         kname = ("abn_apply_nhwc_kernel (skd_abn_apply_nhwc: the frozen teacher's eval-mode InPlace-ABN + ReLU [+ residual], "
                  "channels-last, in place; 8 algorithmic bytes per element, 12 with the residual read)")
@@ -257,7 +261,13 @@ def main():
             "skd_abn_forward_train_to (BN+ReLU[+res] fused: stats+finalize+apply, >=12 B/elem)": summarise(recs.get("skd_abn_forward_train_to", []), 12),
             "skd_abn_relu_backward_reduce (12 B/elem)": summarise(recs.get("skd_abn_relu_backward_reduce", []), 12),
             "skd_abn_relu_backward_dx (>=16 B/elem)": summarise(recs.get("skd_abn_relu_backward_dx", []), 16),
+            "skd_abn_forward_train_nhwc (channels-last student: stats+finalize+apply, >=12 B/elem)": summarise(recs.get("skd_abn_forward_train_nhwc", []), 12, nhwc="train"),
+            "skd_abn_relu_backward_reduce_nhwc (12 B/elem)": summarise(recs.get("skd_abn_relu_backward_reduce_nhwc", []), 12, nhwc="train"),
+            "skd_abn_relu_backward_dx_nhwc (>=16 B/elem)": summarise(recs.get("skd_abn_relu_backward_dx_nhwc", []), 16, nhwc="train"),
+            "skd_abn_backward_reduce_nhwc (leaky ABN, 8 B/elem)": summarise(recs.get("skd_abn_backward_reduce_nhwc", []), 8, nhwc="train"),
+            "skd_abn_backward_dx_nhwc (leaky ABN, 12 B/elem)": summarise(recs.get("skd_abn_backward_dx_nhwc", []), 12, nhwc="train"),
         }
+        line["kernels"] = {k: v for k, v in line["kernels"].items() if v}
     if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:
