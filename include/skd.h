@@ -280,6 +280,17 @@ int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes
                             const float *gcat, float *const *gpriors, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * 9. Whole-image evaluation tail, networks/evaluate.py:106-113, 186-206:
+ *      up = bilinear upsample (h,w) -> (H,W), align_corners=True;  pred = argmax_c up (first maximum, uint8);
+ *      confusion[gt * C + pred] += 1 for every pixel whose label is not ignore_index (int64 counts, ACCUMULATED
+ *      into -- the caller zero-fills once per evaluation run, like evaluate.py:166).
+ *    logits (B, C, h, w) fp32; target (B, H, W) int64 or NULL (prediction only); pred (B, H, W) uint8 or NULL.
+ *    Integer outputs are bit-exact with the plain-C oracle (fp contraction is disabled in the kernel).  C <= 64.
+ * ---------------------------------------------------------------------------------- */
+int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *logits, const int64_t *target,
+                      int ignore_index, uint8_t *pred, int64_t *confusion, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * 6. Deterministic two-stage sum (used by the loss kernels; exposed for tests).
  * ---------------------------------------------------------------------------------- */
 int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, float *workspace,

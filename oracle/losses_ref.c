@@ -421,3 +421,38 @@ int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes
   }
   return 1;
 }
+
+/* ---- evaluation tail: upsample + argmax + confusion matrix, networks/evaluate.py:106-113, 136-154, 186-198 ---- */
+int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *logits, const int64_t *target,
+                      int ignore_index, uint8_t *pred, int64_t *confusion, stream_t st) {
+  (void)st;
+  if (B <= 0 || C <= 0 || C > 64 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !logits) return 0;
+  if (target && !confusion) return 0;
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const int hw = h * w;
+  for (int b = 0; b < B; ++b)
+    for (int Y = 0; Y < H; ++Y) {
+      int y0, y1; float ly0, ly1;
+      tap_of(Y, sy, h, &y0, &y1, &ly0, &ly1);
+      for (int X = 0; X < W; ++X) {
+        int x0, x1; float lx0, lx1;
+        tap_of(X, sx, w, &x0, &x1, &lx0, &lx1);
+        const float *p = logits + (int64_t)b * C * hw;
+        float best = 0.f;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) {
+          const float *q = p + (int64_t)c * hw;
+          /* upsample_bilinear2d: h0l*(w0l*v00 + w1l*v01) + h1l*(w0l*v10 + w1l*v11), every op rounded to float */
+          const float v = ly0 * (lx0 * q[y0 * w + x0] + lx1 * q[y0 * w + x1]) + ly1 * (lx0 * q[y1 * w + x0] + lx1 * q[y1 * w + x1]);
+          if (c == 0 || v > best) { best = v; arg = c; }               /* np.argmax: first maximum */
+        }
+        const int64_t pix = ((int64_t)b * H + Y) * W + X;
+        if (pred) pred[pix] = (uint8_t)arg;
+        if (target) {
+          const int64_t t = target[pix];
+          if (t != (int64_t)ignore_index && t >= 0 && t < C) confusion[t * C + arg] += 1;   /* evaluate.py:144-152 */
+        }
+      }
+    }
+  return 1;
+}

@@ -6,6 +6,7 @@ raise, see _lib.require_device):
 
     cross_entropy_dsn(m, d, y)   utils/criterion.py:179-188   csrc/ce_dsn.hip
     ppm_pool / ppm_concat        networks/pspnet_combine.py:102-111   csrc/ppm.hip
+    seg_confusion(logits, y)     networks/evaluate.py:106-113,186-198 csrc/evaluate.hip  (no autograd)
     pixel_wise_loss(S, T)        utils/criterion.py:219-226   csrc/pixelwise.hip
     max_pool_argmax(x, kh, kw)   nn.MaxPool2d(k=s, ceil_mode=True) of criterion.py:243   csrc/pairwise.hip
     sim_dis(f_S, f_T)            utils/utils.py:170-183 (L2, similarity, sim_dis_compute)  csrc/pairwise.hip
@@ -185,6 +186,30 @@ def ppm_concat(priors, feats):
     """The concatenated input of the PSP bottleneck (pspnet_combine.py:110-111): up-sampled priors followed by
     the feature map, written directly into one (B, L*Cout + Cfeat, H, W) tensor."""
     return _PPMConcat.apply(feats, *priors)
+
+
+def seg_confusion(logits, target=None, ignore_index=255, confusion=None, want_pred=True):
+    """Evaluation tail (networks/evaluate.py:106-113, 186-198): bilinear (align_corners) upsample of ``logits``
+    (B, C, h, w) to the size of ``target`` (B, H, W) [or of ``want_pred`` = (H, W) when no target], argmax over the
+    classes (first maximum, uint8) and accumulation of the (C, C) int64 ``confusion`` matrix over the pixels whose
+    label is not ``ignore_index`` -- one fused kernel, bit-exact integer results.  Returns (pred or None, confusion)."""
+    _lib.require_device(logits, target, confusion)
+    lg = _f32c(logits.detach(), "seg_confusion")
+    b, c, h, w = lg.shape
+    if target is not None:
+        if target.dtype != torch.int64:
+            raise TypeError("seg_confusion: int64 target expected (got %s)" % target.dtype)
+        tg = target if target.is_contiguous() else target.contiguous()
+        H, W = tg.shape[1], tg.shape[2]
+        if confusion is None:
+            confusion = torch.zeros((c, c), dtype=torch.int64, device=lg.device)
+    else:
+        tg = None
+        H, W = want_pred
+    pred = torch.empty((b, H, W), dtype=torch.uint8, device=lg.device) if want_pred else None
+    _lib.check(_lib.get().skd_seg_confusion(b, c, h, w, H, W, lg.data_ptr(), _lib.ptr(tg), int(ignore_index), _lib.ptr(pred),
+                                            _lib.ptr(confusion), _lib.stream_of(lg)), "skd_seg_confusion")
+    return pred, confusion
 
 
 def pool_out_size(n, k):

@@ -1,0 +1,66 @@
+"""Whole-image evaluation (mIoU) on MI355X -- the ``evaluate_main`` that ``train_and_eval.py:28`` reaches through
+``NetModel.evalute_model``.
+
+Reference: networks/evaluate.py:156-206 with ``whole=True`` (the only mode train_and_eval.py uses): per validation
+image, student forward on the full 1024x2048 image, bilinear (align_corners) upsample of the 129x257 logits back to
+1024x2048, argmax, confusion matrix over the non-ignored pixels, IoU = tp / max(1, pos + res - tp), mean over classes.
+The reference materialises the up-sampled logits (159 MB), copies them to the host and runs numpy argmax/bincount;
+here the upsample + argmax + confusion accumulation is one HIP kernel (csrc/evaluate.hip) and only the 19x19 int64
+matrix ever leaves the GPU.  Sliding-window inference, multi-scale / flip averaging, the test-set id remap and the
+palette PNG dump (evaluate.py:62-104, 115-134, 187-191) are host-side tooling around cv2 / scipy / PIL and are not
+provided.
+"""
+import numpy as np
+import torch
+
+from .. import functional as SF
+
+ignore_label = 255
+
+
+def get_confusion_matrix(gt_label, pred_label, class_num):
+    """evaluate.py:136-154 on host arrays (kept for API parity; evaluate_main uses the fused kernel)."""
+    index = (np.asarray(gt_label).astype(np.int64) * class_num + np.asarray(pred_label).astype(np.int64))
+    count = np.bincount(index.ravel(), minlength=class_num * class_num)[: class_num * class_num]
+    return count.reshape(class_num, class_num).astype(np.float64)
+
+
+def iou_from_confusion(confusion_matrix):
+    """evaluate.py:200-206."""
+    cm = np.asarray(confusion_matrix, dtype=np.float64)
+    pos, res, tp = cm.sum(1), cm.sum(0), np.diag(cm)
+    iu = tp / np.maximum(1.0, pos + res - tp)
+    return float(iu.mean()), iu
+
+
+def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, recurrence=1, type="val"):
+    """Returns (mean_IU, IU_array) like evaluate.py:156-206.  ``loader`` yields (image (1,3,H,W) float, label (1,H,W),
+    size, name) like CSDataSet (dataset/datasets.py:121-210); ``size[0][:2]`` is the valid (h, w) of the label."""
+    if not whole:
+        raise NotImplementedError("sliding-window evaluation (evaluate.py:62-104) is not part of the MI355X path; "
+                                  "train_and_eval.py evaluates with whole=True")
+    if type != "val":
+        raise NotImplementedError("test-split prediction dump (evaluate.py:187-191) is host-side tooling")
+    device = torch.device("cuda", int(gpu_id) if str(gpu_id).isdigit() else 0) if torch.cuda.is_available() \
+        else next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    model.to(device)
+    confusion = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=device)
+    with torch.no_grad():
+        for batch in loader:
+            image, label, size = batch[0], batch[1], batch[2]
+            image = torch.as_tensor(np.asarray(image) if not torch.is_tensor(image) else image).float().to(device)
+            label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).long().to(device)
+            sz = np.asarray(size[0] if (torch.is_tensor(size) or isinstance(size, (list, tuple))) else size).reshape(-1)
+            hh, ww = int(sz[0]), int(sz[1])
+            logits = model(image)
+            if isinstance(logits, (list, tuple)):
+                logits = logits[0]
+            # predict_whole upsamples to the tile size (1024, 2048); only [:h, :w] of the label is scored (evaluate.py:194)
+            full = label.new_full(label.shape, ignore_label)
+            full[:, :hh, :ww] = label[:, :hh, :ww]
+            SF.seg_confusion(logits.float(), full, ignore_label, confusion, want_pred=False)
+    if was_training:
+        model.train()
+    return iou_from_confusion(confusion.cpu().numpy())

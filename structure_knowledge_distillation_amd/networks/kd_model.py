@@ -281,15 +281,10 @@ class NetModel():
             self.discriminator_backward()
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
-        """Evaluation (networks/evaluate.py) is outside this hot path: use the
-        reference's evaluate_main when it is importable in the caller's environment."""
-        try:
-            from networks.evaluate import evaluate_main
-        except Exception as e:  # pragma: no cover
-            raise NotImplementedError("evaluation is not part of the MI355X distillation hot path; "
-                                      "networks.evaluate.evaluate_main is not importable: %s" % (e,))
-        return evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
-                             num_classes=num_classes, whole=whole)
+        from .evaluate import evaluate_main
+        mean_IU, IU_array = evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
+                                          num_classes=num_classes, whole=whole)
+        return mean_IU, IU_array
 
     def print_info(self, epoch, step):
         logging.info("step:{:5d} G_lr:{:.6f} G_loss:{:.5f}(mc:{:.5f} pixelwise:{:.5f} pairwise:{:.5f}) "

@@ -299,3 +299,42 @@ def test_student_channels_last_training_graph():
     b1, b2 = dict(net.named_buffers()), dict(net2.named_buffers())
     for k in b1:
         assert rel(b2[k], b1[k]) < 1e-5, k
+
+
+def test_evaluate_main_whole_image_miou():
+    """networks/evaluate.py:156-206 (whole=True) through the fused kernel (C double) vs the reference's numpy recipe."""
+    import numpy as np
+    from structure_knowledge_distillation_amd.networks import evaluate as E
+    torch.manual_seed(41)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 7, 3, 2, 1)
+
+        def forward(self, x):
+            return [self.conv(x), None]
+
+    net = Tiny()
+    H, W = 24, 40
+    batches = []
+    for i in range(3):
+        img = torch.randn(1, 3, H, W) * 10
+        lab = torch.randint(0, 7, (1, H, W))
+        lab[0, :3] = 255
+        size = torch.tensor([[H - 2 * i, W - i, 3]])
+        batches.append((img, lab, size, ["im%d" % i]))
+    mean_iu, iu = E.evaluate_main(net, batches, "0", "512,512", 7, whole=True)
+    cm = np.zeros((7, 7))
+    for img, lab, size, _ in batches:
+        with torch.no_grad():
+            up = torch.nn.functional.interpolate(net(img)[0], size=(H, W), mode="bilinear", align_corners=True)
+        pred = up[0].permute(1, 2, 0).numpy().argmax(2).astype(np.uint8)          # evaluate.py:112, 186
+        hh, ww = int(size[0][0]), int(size[0][1])
+        gt = lab[0].numpy()[:hh, :ww]
+        keep = gt != 255
+        cm += E.get_confusion_matrix(gt[keep], pred[:hh, :ww][keep], 7)           # evaluate.py:193-198
+    want_mean, want_iu = E.iou_from_confusion(cm)
+    assert np.allclose(iu, want_iu) and abs(mean_iu - want_mean) < 1e-12
+    with pytest.raises(NotImplementedError):
+        E.evaluate_main(net, batches, "0", "512,512", 7, whole=False)

@@ -550,6 +550,36 @@ def test_ppm(hip, ref, geom):
     close(pg[off:off + B * C * 9].view(B, C, 3, 3), tp.float(), 1e-5, "pool vs torch")
 
 
+@pytest.mark.parametrize("geom", [(1, 19, 129, 257, 1024, 2048), (2, 19, 65, 65, 512, 512), (2, 11, 46, 61, 360, 480), (1, 3, 1, 1, 4, 4),
+                                  (3, 64, 5, 7, 33, 20), (1, 2, 9, 9, 9, 9)])
+def test_seg_confusion_bit_exact(hip, ref, geom):
+    """Evaluation tail: prediction (uint8 argmax) and int64 confusion counts are bit-exact with the C oracle."""
+    B, C, h, w, H, W = geom
+    g = torch.Generator().manual_seed(H + W + C)
+    lg = torch.randn(B, C, h, w, generator=g) * 4
+    lg[0, :, 0, 0] = 1.5                                   # an exact tie across all classes: first index must win
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[0, : max(1, H // 16)] = 255
+    pr, cr = torch.empty(B, H, W, dtype=torch.uint8), torch.zeros(C, C, dtype=torch.int64)
+    assert ref.skd_seg_confusion(B, C, h, w, H, W, P(lg), P(y), 255, P(pr), P(cr), None)
+    pg, cg = torch.empty(B, H, W, dtype=torch.uint8, device=DEV), torch.zeros(C, C, dtype=torch.int64, device=DEV)
+    assert hip.skd_seg_confusion(B, C, h, w, H, W, P(gpu(lg)), P(y.to(DEV)), 255, P(pg), P(cg), None)
+    assert torch.equal(pg.cpu(), pr), "predictions must be bit-exact"
+    assert torch.equal(cg.cpu(), cr), "confusion counts must be bit-exact"
+    assert int(pg[0, 0, 0]) == 0 and int(cg.sum()) == int((y != 255).sum())
+    # accumulation + prediction-only form
+    assert hip.skd_seg_confusion(B, C, h, w, H, W, P(gpu(lg)), P(y.to(DEV)), 255, None, P(cg), None)
+    assert torch.equal(cg.cpu(), 2 * cr)
+    pg2 = torch.empty_like(pg)
+    assert hip.skd_seg_confusion(B, C, h, w, H, W, P(gpu(lg)), None, 255, P(pg2), None, None)
+    assert torch.equal(pg2, pg)
+    # mIoU from the counts (evaluate.py:200-206)
+    from structure_knowledge_distillation_amd.networks.evaluate import iou_from_confusion
+    m1, _ = iou_from_confusion(cg.cpu().numpy())
+    m2, _ = iou_from_confusion((2 * cr).numpy())
+    assert m1 == m2
+
+
 def test_sum_f32(hip):
     for n in (0, 1, 255, 4097, 1 << 20):
         x = torch.randn(max(n, 1), device=DEV)[:n]

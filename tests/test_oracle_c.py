@@ -177,3 +177,31 @@ def test_ppm_c_vs_torch(ref, geom):
     for a, b in zip(gp, po):
         assert rel(a, b.grad) < 1e-5
     assert rel(gc[:, 4 * Cout:], fo.grad) == 0.0
+
+
+@pytest.mark.parametrize("geom", [(2, 19, 9, 17, 65, 129), (1, 5, 7, 4, 20, 33), (1, 3, 1, 1, 4, 4), (2, 11, 6, 6, 6, 6)])
+def test_seg_confusion_c_vs_torch(ref, geom):
+    """upsample (align_corners) + argmax + confusion matrix, networks/evaluate.py:106-113, 136-154, 186-198."""
+    B, C, h, w, H, W = geom
+    g = torch.Generator().manual_seed(H * W)
+    lg = torch.randn(B, C, h, w, generator=g) * 5
+    y = torch.randint(0, C, (B, H, W), generator=g)
+    y[0, : max(1, H // 8)] = 255
+    pred = torch.empty(B, H, W, dtype=torch.uint8)
+    conf = torch.zeros(C, C, dtype=torch.int64)
+    assert ref.skd_seg_confusion(B, C, h, w, H, W, P(lg), P(y), 255, P(pred), P(conf), None)
+    up = F.interpolate(lg.double(), size=(H, W), mode="bilinear", align_corners=True)
+    want_pred = up.argmax(1)
+    flips = int((want_pred != pred.long()).sum())
+    assert flips <= max(1, B * H * W // 100000), flips          # fp32 vs fp64 interpolation: near-ties only
+    valid = y != 255
+    idx = (y[valid] * C + pred.long()[valid])
+    want_conf = torch.bincount(idx, minlength=C * C).reshape(C, C)      # get_confusion_matrix, evaluate.py:144-152
+    assert torch.equal(conf, want_conf)
+    assert int(conf.sum()) == int(valid.sum())
+    # accumulates (+=) and supports prediction-only calls
+    assert ref.skd_seg_confusion(B, C, h, w, H, W, P(lg), P(y), 255, None, P(conf), None)
+    assert torch.equal(conf, 2 * want_conf)
+    pred2 = torch.empty_like(pred)
+    assert ref.skd_seg_confusion(B, C, h, w, H, W, P(lg), None, 255, P(pred2), None, None)
+    assert torch.equal(pred2, pred)
