@@ -123,7 +123,8 @@ int skd_abn_apply_nhwc(int64_t rows, int C, float *x, const float *residual, con
                        float slope, skd_stream_t stream);
 /* Channels-last (NHWC) TRAINING forms: x is (rows = N*H*W, C) row-major, C a power of two in [4, 1024].
  * Same maths and conventions as the NCHW entries above (statistics over the rows of each channel, running-stat
- * update with n = rows, dweight / dbias accumulated); `out` may equal `x` (the in-place InPlace-ABN) or be a
+ * update with n = rows); the two dx entries take `accumulate`: nonzero = dweight / dbias are accumulated into like
+ * bn.cu:217-229, zero = they are written, so the caller needs no zero-fill; `out` may equal `x` (the in-place InPlace-ABN) or be a
  * separate tensor (the BN -> [+ residual] -> ReLU fusion, which keeps x for backward).  They let MIOpen run its
  * NHWC-native fp32 kernels without NCHW<->NHWC transposes.  workspace: skd_abn_nhwc_workspace_floats(rows, C). */
 int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C);
@@ -142,14 +143,14 @@ int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const floa
 int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
                              const float *weight, const float *bias, const float *edz, const float *eydz,
                              float *dx, float *dweight, float *dbias, float eps, int activation, float slope,
-                             skd_stream_t stream);
+                             int accumulate, skd_stream_t stream);
 int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
                                       const float *mean, const float *var, float *edz, float *eydz, float eps,
                                       float *workspace, skd_stream_t stream);
 int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
                                   const float *mean, const float *var, const float *weight, const float *edz,
                                   const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
-                                  float eps, skd_stream_t stream);
+                                  float eps, int accumulate, skd_stream_t stream);
 /* cross-replica combine in one launch (functions.py:196-197, 208-209): gathered is (G, 2, C) = every rank's
  * [mean, var] (equal per-rank sample counts, as the reference assumes); writes the combined mean / var and, when
  * the running buffers are given, updates them with n = per-rank count * G. */

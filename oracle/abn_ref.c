@@ -427,10 +427,15 @@ int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const floa
 
 int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
                              const float *weight, const float *bias, const float *edz, const float *eydz, float *dx,
-                             float *dweight, float *dbias, float eps, int act, float slope, stream_t st) {
+                             float *dweight, float *dbias, float eps, int act, float slope, int accumulate,
+                             stream_t st) {
   if (!nhwc_ok(rows, C) || !dx) return 0;
   float *pz = to_planes(rows, C, z), *pd = to_planes(rows, C, dz), *px = to_planes(rows, C, NULL);
   int r = 0;
+  if (!accumulate) {                       /* accumulate == 0: dweight / dbias are written, not added to */
+    if (dweight) memset(dweight, 0, sizeof(float) * (size_t)C);
+    if (dbias) memset(dbias, 0, sizeof(float) * (size_t)C);
+  }
   if (pz && pd && px) {
     r = skd_abn_backward_dx(1, C, (int)rows, pz, pd, var, weight, bias, edz, eydz, px, dweight, dbias, eps, act, slope, st);
     if (r) from_planes(rows, C, px, dx);
@@ -452,8 +457,12 @@ int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const
 int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
                                   const float *mean, const float *var, const float *weight, const float *edz,
                                   const float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
-                                  stream_t st) {
+                                  int accumulate, stream_t st) {
   if (!nhwc_ok(rows, C) || !dx) return 0;
+  if (!accumulate) {
+    if (dweight) memset(dweight, 0, sizeof(float) * (size_t)C);
+    if (dbias) memset(dbias, 0, sizeof(float) * (size_t)C);
+  }
   float *px = to_planes(rows, C, x), *po = to_planes(rows, C, out), *pd = to_planes(rows, C, dout);
   float *pdx = to_planes(rows, C, NULL), *pdr = dres ? to_planes(rows, C, NULL) : NULL;
   int r = 0;

@@ -147,16 +147,32 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   if (ldm != skd_pairwise_ldm(M)) return 0;
   double total = 0.0;
   if (G) memset(G, 0, sizeof(float) * (size_t)B * ldm * ldm);
-  for (int b = 0; b < B; ++b)
-    for (int i = 0; i < M; ++i)
+  /* node-major double copies so the channel contraction walks contiguous memory (M = 4225 is 11 GMAC per image);
+     rows are independent -> OpenMP over i, per-row sums added in row order (deterministic). */
+  double *ns = (double *)malloc(sizeof(double) * (size_t)M * Cs), *nt = (double *)malloc(sizeof(double) * (size_t)M * Ct);
+  double *rows = (double *)malloc(sizeof(double) * (size_t)M);
+  if (!ns || !nt || !rows) { free(ns); free(nt); free(rows); return 0; }
+  for (int b = 0; b < B; ++b) {
+    for (int c = 0; c < Cs; ++c)
+      for (int m = 0; m < M; ++m) ns[(size_t)m * Cs + c] = (double)fs[((int64_t)b * Cs + c) * ldm + m];
+    for (int c = 0; c < Ct; ++c)
+      for (int m = 0; m < M; ++m) nt[(size_t)m * Ct + c] = (double)ft[((int64_t)b * Ct + c) * ldm + m];
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; ++i) {
+      double row = 0.0;
       for (int j = 0; j < M; ++j) {
         double at = 0.0, as = 0.0;                                   /* einsum('icm,icn->imn'), utils.py:178 */
-        for (int c = 0; c < Ct; ++c) at += (double)ft[((int64_t)b * Ct + c) * ldm + i] * ft[((int64_t)b * Ct + c) * ldm + j];
-        for (int c = 0; c < Cs; ++c) as += (double)fs[((int64_t)b * Cs + c) * ldm + i] * fs[((int64_t)b * Cs + c) * ldm + j];
+        for (int c = 0; c < Ct; ++c) at += nt[(size_t)i * Ct + c] * nt[(size_t)j * Ct + c];
+        for (int c = 0; c < Cs; ++c) as += ns[(size_t)i * Cs + c] * ns[(size_t)j * Cs + c];
         const double g = at - as;
-        total += g * g;
+        row += g * g;
         if (G) G[((int64_t)b * ldm + i) * ldm + j] = (float)g;
       }
+      rows[i] = row;
+    }
+    for (int i = 0; i < M; ++i) total += rows[i];
+  }
+  free(ns); free(nt); free(rows);
   loss[0] = (float)(total / ((double)M * (double)M) / (double)B);    /* utils.py:181 */
   return 1;
 }
@@ -167,17 +183,21 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *f
   if (B <= 0 || Cs <= 0 || M <= 0 || !fst || !G || !norm_s || !grad_loss || !dpooled) return 0;
   /* L = sum G^2/(M^2 B), G = A_T - A_S, A_S = Fh^T Fh  =>  dL/dFh = -4/(M^2 B) Fh G ; dP = dFh / norm */
   const double coef = -4.0 / ((double)M * (double)M * (double)B) * (double)grad_loss[0];
-  for (int b = 0; b < B; ++b)
-    for (int c = 0; c < Cs; ++c)
-      for (int m = 0; m < ldm; ++m) {
-        double acc = 0.0;
-        if (m < M) {
-          for (int n = 0; n < M; ++n)
-            acc += (double)fst[((int64_t)b * ldm + n) * ldc + c] * (double)G[((int64_t)b * ldm + n) * ldm + m];
-          acc = acc * coef / (double)norm_s[(int64_t)b * M + m];
+  for (int b = 0; b < B; ++b) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < ldm; ++m) {
+      double *acc = (double *)calloc((size_t)Cs, sizeof(double));
+      if (m < M)
+        for (int n = 0; n < M; ++n) {                                /* G is symmetric in exact arithmetic; index as written */
+          const double g = (double)G[((int64_t)b * ldm + n) * ldm + m];
+          const float *frow = fst + ((int64_t)b * ldm + n) * ldc;
+          for (int c = 0; c < Cs; ++c) acc[c] += (double)frow[c] * g;
         }
-        dpooled[((int64_t)b * Cs + c) * ldm + m] = (float)acc;
-      }
+      for (int c = 0; c < Cs; ++c)
+        dpooled[((int64_t)b * Cs + c) * ldm + m] = m < M ? (float)(acc[c] * coef / (double)norm_s[(int64_t)b * M + m]) : 0.f;
+      free(acc);
+    }
+  }
   return 1;
 }
 

@@ -124,6 +124,11 @@ __device__ __forceinline__ float inv_std_of(float var, float eps) {
   return (var != 0.f || eps != 0.f) ? 1.f / sqrtf(var + eps) : 0.f;  // bn.cu:148-151
 }
 
+// functions.py:91,209: running_var takes var * n / (n - 1).  With ONE sample per channel (the PSP 1x1 stage at
+// batch 1 on a single replica) the reference divides by zero and poisons the buffer with
+// NaN / inf; here n == 1 keeps the (zero) biased variance instead -- the one deliberate deviation, see DESIGN.md.
+__device__ __forceinline__ float unbiased_of(float var, float n) { return n > 1.f ? var * n / (n - 1.f) : var; }
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, float slope) {
   if (ACT == SKD_ACT_LEAKY_RELU) return z < 0.f ? z * slope : z;        // bn.cu:302-315
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void abn_stats_finalize_kernel(
     if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
     if (running_var != nullptr) {
       const float nf = (float)n_total;
-      running_var[c] = running_var[c] * (1.f - momentum) + momentum * v_f * nf / (nf - 1.f);
+      running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v_f, nf);
     }
   }
 }
@@ -243,7 +248,7 @@ __global__ void abn_combine_stats_kernel(int G, int C, const float *__restrict__
   mean[c] = m;
   var[c] = v;
   if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m;
-  if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * v * nf / (nf - 1.f);
+  if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v, nf);
 }
 
 __global__ void abn_update_running_kernel(int C, float *running_mean, float *running_var,
@@ -252,7 +257,7 @@ __global__ void abn_update_running_kernel(int C, float *running_mean, float *run
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mean[c];
-  running_var[c] = running_var[c] * (1.f - momentum) + momentum * var[c] * nf / (nf - 1.f);
+  running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(var[c], nf);
 }
 
 struct F4x2 {
@@ -889,9 +894,8 @@ static int launch_apply_nhwc(int64_t rows, int C, float *x, const float *res, co
 // With the channel as the fastest dimension a thread owns ONE channel quad (its statistics accumulate in
 // registers, its parameters live in registers) and a workgroup walks a contiguous slab of rows:
 //   256 threads = (256 / C4) rows x C4 channel quads per pass, 8 passes in flight per loop trip.
-// Per-workgroup partials use the same [c][P][2] layout as the NCHW path, so the finalize kernels (double
-// accumulation, fixed order, running-stat update) are shared: they are called with (N, S) = (rows, 1), which makes
-// the pivot x[c * S] the first row's element of channel c.
+// The two apply-type passes (normalise, dx) below give every 32 KiB slab its own 256-thread workgroup; the reductions
+// (statistics, edz / eydz) are the one-launch kernels of the "second design" section further down.
 // Power-of-two C with 4 <= C <= 1024 (every training layer of this path: 64 ... 512).
 // =============================================================================================
 constexpr int kNhwcRowsPerThread = 8;
@@ -913,64 +917,6 @@ static bool make_nhwc_geom(int64_t rows, int C, NhwcGeom &g) {
   if (P > (1 << 24)) return false;
   g.P = (int)P;
   return true;
-}
-
-// combine the partial sums of the rpp threads that share a channel quad, write [c][P][2] partials
-__device__ __forceinline__ void nhwc_store_partials(float (&s1)[4], float (&s2)[4], float *__restrict__ part,
-                                                    const NhwcGeom &g, float *lds) {
-  const int t = threadIdx.x;
-  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
-  float *mine = lds + (int64_t)t * 8;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    mine[k] = s1[k];
-    mine[4 + k] = s2[k];
-  }
-  __syncthreads();
-  if (rsub == 0) {
-    float a[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = 0.f;
-    for (int r = 0; r < g.rpp; ++r) {
-      const float *o = lds + ((int64_t)(r << g.log2C4) + cq) * 8;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] += o[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float *dst = part + ((int64_t)(cq * 4 + k) * g.P + blockIdx.x) * 2;
-      dst[0] = a[k];
-      dst[1] = a[4 + k];
-    }
-  }
-}
-
-// K1 (NHWC): shifted sums of (x - K), (x - K)^2 with K = x[0][c]
-__global__ __launch_bounds__(kThreads) void abn_stats_nhwc_kernel(const float *__restrict__ x,
-                                                                 float *__restrict__ part, int64_t rows,
-                                                                 NhwcGeom g) {
-  __shared__ float lds[kThreads * 8];
-  const int t = threadIdx.x;
-  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
-  const float4 K = *reinterpret_cast<const float4 *>(x + cq * 4);
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
-  float4 v[kNhwcRowsPerThread];
-#pragma unroll
-  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
-    const int64_t r = r0 + (int64_t)u * g.rpp;
-    if (r < rows) v[u] = *reinterpret_cast<const float4 *>(x + (r << (g.log2C4 + 2)) + cq * 4);
-  }
-#pragma unroll
-  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
-    const int64_t r = r0 + (int64_t)u * g.rpp;
-    if (r < rows) {
-      const float d0 = v[u].x - K.x, d1 = v[u].y - K.y, d2 = v[u].z - K.z, d3 = v[u].w - K.w;
-      s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
-      s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
-    }
-  }
-  nhwc_store_partials(s1, s2, part, g, lds);
 }
 
 // K2 (NHWC), out of place or in place: out = act(bn(x) [+ residual]) with given mean / var
@@ -1016,76 +962,13 @@ __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_train_kernel(const fl
   }
 }
 
-// K3 (NHWC): edz / eydz partials.  MODE 0: y from the saved OUTPUT z (activation ACT undone in registers, the
-// in-place ABN);  MODE 1: fused BN+ReLU: inputs (x, out, dout), y from x, mask = out > 0.
-template <int ACT, int MODE>
-__global__ __launch_bounds__(kThreads) void abn_grad_partial_nhwc_kernel(
-    const float *__restrict__ a_, const float *__restrict__ b_, const float *__restrict__ c_,
-    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
-    const float *__restrict__ bias, float *__restrict__ part, float eps, float slope, int64_t rows, NhwcGeom g) {
-  __shared__ float lds[kThreads * 8];
-  const int t = threadIdx.x;
-  const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
-  float p0[4], p1[4];  // MODE 0: beta, gamma   MODE 1: mean, inv_std
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (MODE == 0) {
-      p0[k] = beta_of(bias, cq * 4 + k);
-      p1[k] = gamma_of(weight, cq * 4 + k, eps);
-    } else {
-      p0[k] = mean[cq * 4 + k];
-      p1[k] = inv_std_of(var[cq * 4 + k], eps);
-    }
-  }
-  const float inv_slope = 1.f / slope;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  const int64_t r0 = (int64_t)blockIdx.x * g.rows_per_wg + rsub;
-  float4 va[kNhwcRowsPerThread], vb[kNhwcRowsPerThread], vc[kNhwcRowsPerThread];
-#pragma unroll
-  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
-    const int64_t r = r0 + (int64_t)u * g.rpp;
-    if (r < rows) {
-      const int64_t o = (r << (g.log2C4 + 2)) + cq * 4;
-      va[u] = *reinterpret_cast<const float4 *>(a_ + o);
-      vb[u] = *reinterpret_cast<const float4 *>(b_ + o);
-      if (MODE == 1) vc[u] = *reinterpret_cast<const float4 *>(c_ + o);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kNhwcRowsPerThread; ++u) {
-    const int64_t r = r0 + (int64_t)u * g.rpp;
-    if (r < rows) {
-      const float A[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
-      const float B[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-      const float Cc[4] = {MODE == 1 ? vc[u].x : 0.f, MODE == 1 ? vc[u].y : 0.f, MODE == 1 ? vc[u].z : 0.f,
-                           MODE == 1 ? vc[u].w : 0.f};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float y, dz;
-        if (MODE == 0) {
-          float zv = A[k];
-          dz = B[k];
-          act_undo<ACT>(zv, dz, slope, inv_slope);
-          y = (zv - p0[k]) / p1[k];
-        } else {
-          dz = B[k] > 0.f ? Cc[k] : 0.f;          // (x, out, dout)
-          y = (A[k] - p0[k]) * p1[k];
-        }
-        s1[k] += dz;
-        s2[k] += y * dz;
-      }
-    }
-  }
-  nhwc_store_partials(s1, s2, part, g, lds);
-}
-
 // K4 (NHWC): dx (and dres for MODE 1), dweight / dbias by workgroup 0
 template <int ACT, int MODE, bool WRITE_RES>
 __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
     const float *a_, const float *b_, const float *c_, const float *__restrict__ mean,
     const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ bias,
     const float *__restrict__ edz, const float *__restrict__ eydz, float *dx, float *dres, float *dweight,
-    float *dbias, float eps, float slope, int64_t rows, NhwcGeom g) {
+    float *dbias, float eps, float slope, int64_t rows, NhwcGeom g, int accumulate) {
   const int t = threadIdx.x;
   const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
   float p0[4], p1[4], e[4], ey[4], mul[4];
@@ -1151,16 +1034,313 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = cq * 4 + k;
-      if (dweight != nullptr) {
+      if (dweight != nullptr) {   // bn.cu:217-229 accumulates; accumulate == 0 writes (no zero-fill needed before the call)
         const float wv = weight[c];
-        if (wv > 0.f)
-          dweight[c] += ey[k] * norm;
-        else if (wv < 0.f)
-          dweight[c] -= ey[k] * norm;
+        const float gwt = wv > 0.f ? ey[k] * norm : (wv < 0.f ? -ey[k] * norm : 0.f);
+        dweight[c] = accumulate ? dweight[c] + gwt : gwt;
       }
-      if (dbias != nullptr) dbias[c] += e[k] * norm;
+      if (dbias != nullptr) dbias[c] = accumulate ? dbias[c] + e[k] * norm : e[k] * norm;
     }
   }
+}
+
+
+// =============================================================================================
+// Channels-last reductions, second design (round 2): ONE launch per reduction, finalize included.
+//
+// Round 1 gave every 32 KiB slab its own workgroup (2113 workgroups for an (8,512,65,65) tensor), each scattering
+// 2*C floats as 8-byte stores with a stride of 8*P bytes, followed by a one-wave-per-channel finalize launch over the
+// strided partials: the partial traffic rivalled the tensor itself and the finalize launch plus its two kernel
+// boundaries cost ~14 us of every ~50 us call (0.24-0.43 of HBM peak).  Now:
+//   * at most 256 workgroups of 1024 threads (16 waves, one workgroup per CU), each looping over row slabs with a
+//     grid stride; a thread owns one channel quad and keeps its two sums in registers for the whole launch;
+//   * wide tensors are cut into CB <= 4 channel blocks of >= 64 channels (256-byte row segments), so a workgroup's
+//     partial is 2*CW floats and a channel block's partials total <= 128 KiB;
+//   * partials are workgroup-major and contiguous: part[cb][rg][CW4][8] (per quad: four first sums, four second sums);
+//   * the LAST workgroup of a channel block to arrive (agent-scope release -> ticket -> acquire,
+//     MI355X_MICROARCH.md "inter-workgroup visibility") sums the RG partial rows in double precision in a fixed
+//     order -- bit-identical whichever workgroup happens to be last -- and finishes the statistics in place
+//     (mean / var + running update, or edz / eydz).  No finalize launch, no atomically accumulated floats.
+// Tickets live in a library-owned, zero-initialised counter pool (one slot per launch, round robin; the last arriver
+// re-arms its counter), so the caller's workspace needs no initialisation.
+// =============================================================================================
+constexpr int kRedThreads = 1024;
+constexpr int kRedMaxWG = 256;
+constexpr int kRedMaxCB = 4;
+constexpr int kRedSlots = 4096;
+
+struct RedGeom {
+  int C4, log2C4;     // channel quads per row
+  int CB;             // channel blocks
+  int CW4, log2CW4;   // quads per channel block
+  int rpp;            // rows per pass of one workgroup (1024 / CW4)
+  int RG;             // row groups = workgroups per channel block = partial rows per channel block
+  int L;              // floats per partial row (CW4 * 8)
+};
+
+static bool make_red_geom(int64_t rows, int C, int U, RedGeom &g) {
+  if (rows <= 0 || rows > 2147483647 || C < 4 || C > 4 * kThreads || (C & (C - 1))) return false;
+  g.C4 = C / 4;
+  g.log2C4 = 0;
+  while ((1 << g.log2C4) < g.C4) ++g.log2C4;
+  g.CB = C >= 256 ? 4 : (C >= 128 ? 2 : 1);
+  g.CW4 = g.C4 / g.CB;
+  g.log2CW4 = 0;
+  while ((1 << g.log2CW4) < g.CW4) ++g.log2CW4;
+  g.rpp = kRedThreads / g.CW4;
+  const int64_t want = cdiv(rows, (int64_t)g.rpp * U);
+  const int64_t cap = kRedMaxWG / g.CB;
+  g.RG = (int)(want < cap ? want : cap);
+  g.L = g.CW4 * 8;
+  return true;
+}
+
+struct RedPool {
+  unsigned *ptr = nullptr;
+};
+static RedPool g_red_pool[64];
+static unsigned g_red_next = 0;
+
+// one ticket counter per channel block for this launch (zero on entry, zero again when the launch retires)
+static unsigned *red_counters() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  RedPool &p = g_red_pool[dev];
+  if (p.ptr == nullptr) {
+    unsigned *q = nullptr;
+    const size_t bytes = sizeof(unsigned) * kRedSlots * kRedMaxCB;
+    if (hipMalloc(reinterpret_cast<void **>(&q), bytes) != hipSuccess) return nullptr;
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipFree(q);
+      return nullptr;
+    }
+    p.ptr = q;
+  }
+  const unsigned slot = __atomic_fetch_add(&g_red_next, 1u, __ATOMIC_RELAXED) % kRedSlots;
+  return p.ptr + (size_t)slot * kRedMaxCB;
+}
+
+// Workgroup epilogue of a channels-last reduction.  In: every thread's eight running sums.  Out: `true` in all
+// threads of the channel block's last-arriving workgroup, with the block's totals in fin[cq * 8 + k] (double).
+// lds: kRedThreads * 4 doubles; fin: L doubles.
+__device__ __forceinline__ bool red_finish(float (&s1)[4], float (&s2)[4], float *__restrict__ part,
+                                           unsigned *counter, const RedGeom &g, int cb, int rg, double *lds,
+                                           double *fin, unsigned *ticket_s) {
+  const int t = threadIdx.x, lane = t & (kWave - 1);
+  float a[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+  // lanes of a wave that share a channel quad differ only in the row bits of the lane index: butterfly over those
+  for (int m = kWave / 2; m >= g.CW4; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += __shfl_xor(a[k], m, kWave);
+  }
+  float *ldsf = reinterpret_cast<float *>(lds);
+  const int cq = t & (g.CW4 - 1);
+  int slot, nslots;
+  bool writer;
+  if (g.CW4 < kWave) {
+    slot = t / kWave;
+    nslots = kRedThreads / kWave;
+    writer = lane < g.CW4;
+  } else {
+    slot = t >> g.log2CW4;
+    nslots = kRedThreads >> g.log2CW4;
+    writer = true;
+  }
+  if (writer) {
+    float *o = ldsf + ((int64_t)slot * g.CW4 + cq) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = a[k];
+  }
+  __syncthreads();
+  float *mine = part + ((int64_t)cb * g.RG + rg) * g.L;
+  for (int i = t; i < g.L; i += kRedThreads) {
+    float s = 0.f;
+    for (int sl = 0; sl < nslots; ++sl) s += ldsf[sl * g.L + i];
+    mine[i] = s;
+  }
+  __syncthreads();   // every wave's partial stores are acknowledged before lane 0 releases them
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)g.RG - 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for a later launch
+    }
+    *ticket_s = old;
+  }
+  __syncthreads();
+  if (*ticket_s != (unsigned)g.RG - 1u) return false;
+  // ---- last arriver: fixed-order double-precision sum of the RG partial rows of this channel block ----
+  const int L4 = g.L >> 2;                 // float4 per partial row (a power of two, 2 ... 512)
+  const int NP = kRedThreads / L4;         // row phases
+  const int j4 = t & (L4 - 1), ph = t / L4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float *col = part + (int64_t)cb * g.RG * g.L + j4 * 4;
+  for (int r = ph; r < g.RG; r += 4 * NP) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * NP;
+      v[u] = rr < g.RG ? *reinterpret_cast<const float4 *>(col + (int64_t)rr * g.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += (double)v[u].x;
+      acc[1] += (double)v[u].y;
+      acc[2] += (double)v[u].z;
+      acc[3] += (double)v[u].w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lds[((int64_t)ph * L4 + j4) * 4 + q] = acc[q];
+  __syncthreads();
+  for (int i = t; i < g.L; i += kRedThreads) {
+    double s = 0.0;
+    for (int p = 0; p < NP; ++p) s += lds[(int64_t)p * g.L + i];
+    fin[i] = s;
+  }
+  __syncthreads();
+  return true;
+}
+
+// K1 (NHWC): shifted sums of (x - K), (x - K)^2 with K = x[0][c]; mean / biased var (+ running update) by the last arriver
+template <int U>
+__global__ __launch_bounds__(kRedThreads) void abn_stats_nhwc2_kernel(
+    const float *__restrict__ x, float *__restrict__ part, unsigned *counters, float *__restrict__ mean,
+    float *__restrict__ var, float *running_mean, float *running_var, int64_t rows, RedGeom g, float momentum,
+    float n_total) {
+  __shared__ double lds[kRedThreads * 4];
+  __shared__ double fin[kRedThreads * 2];
+  __shared__ unsigned ticket_s;
+  const int t = threadIdx.x;
+  const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
+  const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
+  const int col = (cb * g.CW4 + cq) * 4;
+  const float4 K = *reinterpret_cast<const float4 *>(x + col);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t slab = (int64_t)g.rpp * U;
+  for (int64_t base = (int64_t)rg * slab + rsub; base < rows; base += (int64_t)g.RG * slab) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + (int64_t)u * g.rpp;
+      if (r < rows) v[u] = *reinterpret_cast<const float4 *>(x + (r << (g.log2C4 + 2)) + col);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + (int64_t)u * g.rpp;
+      if (r < rows) {
+        const float d0 = v[u].x - K.x, d1 = v[u].y - K.y, d2 = v[u].z - K.z, d3 = v[u].w - K.w;
+        s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+        s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
+      }
+    }
+  }
+  if (!red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) return;
+  const int CW = g.CW4 * 4;
+  if (t < CW) {
+    const int c = cb * CW + t;
+    const double cnt = (double)rows;
+    const double d = fin[(t >> 2) * 8 + (t & 3)] / cnt;
+    double v = fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt - d * d;
+    if (v < 0.0) v = 0.0;
+    const float m_f = (float)((double)x[c] + d), v_f = (float)v;
+    mean[c] = m_f;
+    var[c] = v_f;
+    if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
+    if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v_f, n_total);
+  }
+}
+
+// K3 (NHWC): edz / eydz.  MODE 0: y from the saved OUTPUT z (activation ACT undone in registers, the in-place ABN);
+// MODE 1: fused BN+ReLU: inputs (x, out, dout), y from x, mask = out > 0.
+template <int ACT, int MODE, int U>
+__global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
+    const float *__restrict__ a_, const float *__restrict__ b_, const float *__restrict__ c_,
+    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ part, unsigned *counters, float *__restrict__ edz,
+    float *__restrict__ eydz, float eps, float slope, int64_t rows, RedGeom g) {
+  __shared__ double lds[kRedThreads * 4];
+  __shared__ double fin[kRedThreads * 2];
+  __shared__ unsigned ticket_s;
+  const int t = threadIdx.x;
+  const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
+  const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
+  const int col = (cb * g.CW4 + cq) * 4;
+  float p0[4], p1[4];  // MODE 0: beta, gamma   MODE 1: mean, inv_std
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (MODE == 0) {
+      p0[k] = beta_of(bias, col + k);
+      p1[k] = gamma_of(weight, col + k, eps);
+    } else {
+      p0[k] = mean[col + k];
+      p1[k] = inv_std_of(var[col + k], eps);
+    }
+  }
+  const float inv_slope = 1.f / slope;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t slab = (int64_t)g.rpp * U;
+  for (int64_t base = (int64_t)rg * slab + rsub; base < rows; base += (int64_t)g.RG * slab) {
+    float4 va[U], vb[U], vc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + (int64_t)u * g.rpp;
+      if (r < rows) {
+        const int64_t o = (r << (g.log2C4 + 2)) + col;
+        va[u] = *reinterpret_cast<const float4 *>(a_ + o);
+        vb[u] = *reinterpret_cast<const float4 *>(b_ + o);
+        if (MODE == 1) vc[u] = *reinterpret_cast<const float4 *>(c_ + o);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + (int64_t)u * g.rpp;
+      if (r < rows) {
+        const float A[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+        const float B[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+        const float Cc[4] = {MODE == 1 ? vc[u].x : 0.f, MODE == 1 ? vc[u].y : 0.f, MODE == 1 ? vc[u].z : 0.f,
+                             MODE == 1 ? vc[u].w : 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float y, dz;
+          if (MODE == 0) {
+            float zv = A[k];
+            dz = B[k];
+            act_undo<ACT>(zv, dz, slope, inv_slope);
+            y = (zv - p0[k]) / p1[k];
+          } else {
+            dz = B[k] > 0.f ? Cc[k] : 0.f;          // (x, out, dout)
+            y = (A[k] - p0[k]) * p1[k];
+          }
+          s1[k] += dz;
+          s2[k] += y * dz;
+        }
+      }
+    }
+  }
+  if (!red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) return;
+  const int CW = g.CW4 * 4;
+  if (t < CW) {
+    const int c = cb * CW + t;
+    const double cnt = (double)rows;
+    edz[c] = (float)(fin[(t >> 2) * 8 + (t & 3)] / cnt);       // bn.cu:176
+    eydz[c] = (float)(fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt);  // bn.cu:177
+  }
+}
+
+constexpr int kStatsU = 8, kGrad0U = 8, kGrad1U = 4;
+
+static int launch_stats_nhwc2(int64_t rows, int C, const float *x, float *mean, float *var, float *running_mean,
+                              float *running_var, float momentum, float *workspace, hipStream_t st) {
+  RedGeom g;
+  if (!make_red_geom(rows, C, kStatsU, g)) return 0;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  abn_stats_nhwc2_kernel<kStatsU><<<dim3((unsigned)(g.RG * g.CB)), dim3(kRedThreads), 0, st>>>(
+      x, workspace, cnt, mean, var, running_mean, running_var, rows, g, momentum, (float)rows);
+  return ok();
 }
 
 template <bool HAS_RES>
@@ -1445,18 +1625,15 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g)) return 0;
-  return (int64_t)g.P * C * 2;
+  // workgroup-major partial rows of the one-launch reductions: CB * RG <= kRedMaxWG rows of 2 * C / CB floats
+  return (int64_t)kRedMaxWG * 2 * C;
 }
 
 int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *workspace,
                        skd_stream_t stream) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g) || !x || !mean || !var || !workspace || !aligned16(x)) return 0;
-  hipStream_t st = as_stream(stream);
-  abn_stats_nhwc_kernel<<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(x, workspace, rows, g);
-  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
-      x, workspace, mean, var, nullptr, nullptr, (int)(rows > 2147483647 ? 2147483647 : rows), C, 1, g.P, 0.f, 0.0);
-  return rows > 2147483647 ? 0 : ok();
+  return launch_stats_nhwc2(rows, C, x, mean, var, nullptr, nullptr, 0.f, workspace, as_stream(stream));
 }
 
 int skd_abn_apply_nhwc_to(int64_t rows, int C, const float *x, const float *residual, float *out,
@@ -1478,9 +1655,7 @@ int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float 
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !mean || !var || !workspace) return 0;
   if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual))) return 0;
   hipStream_t st = as_stream(stream);
-  abn_stats_nhwc_kernel<<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(x, workspace, rows, g);
-  abn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(
-      x, workspace, mean, var, running_mean, running_var, (int)rows, C, 1, g.P, momentum, (double)rows);
+  if (!launch_stats_nhwc2(rows, C, x, mean, var, running_mean, running_var, momentum, workspace, st)) return 0;
   return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
                   : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
 }
@@ -1492,24 +1667,27 @@ int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const floa
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !z || !dz || !edz || !eydz || !workspace) return 0;
   if (!aligned16(z) || !aligned16(dz) || activation == SKD_ACT_RELU) return 0;
   hipStream_t st = as_stream(stream);
-  const dim3 grid((unsigned)g.P), block(kThreads);
+  RedGeom rg;
+  if (!make_red_geom(rows, C, kGrad0U, rg)) return 0;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  const dim3 grid((unsigned)(rg.RG * rg.CB)), block(kRedThreads);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_grad_partial_nhwc_kernel<SKD_ACT_LEAKY_RELU, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+      abn_grad_nhwc2_kernel<SKD_ACT_LEAKY_RELU, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
       break;
     case SKD_ACT_ELU:
-      abn_grad_partial_nhwc_kernel<SKD_ACT_ELU, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+      abn_grad_nhwc2_kernel<SKD_ACT_ELU, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
       break;
     default:
-      abn_grad_partial_nhwc_kernel<SKD_ACT_NONE, 0><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, eps, slope, rows, g);
+      abn_grad_nhwc2_kernel<SKD_ACT_NONE, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
   }
-  abn_grad_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(workspace, edz, eydz, (int)rows, C, 1, g.P);
   return ok();
 }
 
 int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var,
                              const float *weight, const float *bias, const float *edz, const float *eydz, float *dx,
-                             float *dweight, float *dbias, float eps, int activation, float slope,
+                             float *dweight, float *dbias, float eps, int activation, float slope, int accumulate,
                              skd_stream_t stream) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g) || !z || !dz || !var || !edz || !eydz || !dx) return 0;
@@ -1518,13 +1696,13 @@ int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *d
   const dim3 grid((unsigned)g.P), block(kThreads);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_grad_dx_nhwc_kernel<SKD_ACT_LEAKY_RELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+      abn_grad_dx_nhwc_kernel<SKD_ACT_LEAKY_RELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g, accumulate);
       break;
     case SKD_ACT_ELU:
-      abn_grad_dx_nhwc_kernel<SKD_ACT_ELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+      abn_grad_dx_nhwc_kernel<SKD_ACT_ELU, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g, accumulate);
       break;
     default:
-      abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g);
+      abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 0, false><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, slope, rows, g, accumulate);
   }
   return ok();
 }
@@ -1536,25 +1714,28 @@ int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !dout || !mean || !var || !edz || !eydz || !workspace) return 0;
   if (!aligned16(x) || !aligned16(out) || !aligned16(dout)) return 0;
   hipStream_t st = as_stream(stream);
-  abn_grad_partial_nhwc_kernel<SKD_ACT_NONE, 1><<<dim3((unsigned)g.P), dim3(kThreads), 0, st>>>(
-      x, out, dout, mean, var, nullptr, nullptr, workspace, eps, 0.f, rows, g);
-  abn_grad_finalize_kernel<<<dim3((unsigned)cdiv(C, kWavesPerWG)), dim3(kThreads), 0, st>>>(workspace, edz, eydz, (int)rows, C, 1, g.P);
+  RedGeom rg;
+  if (!make_red_geom(rows, C, kGrad1U, rg)) return 0;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  abn_grad_nhwc2_kernel<SKD_ACT_NONE, 1, kGrad1U><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
+      x, out, dout, mean, var, nullptr, nullptr, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
   return ok();
 }
 
 int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
                                   const float *mean, const float *var, const float *weight, const float *edz,
                                   const float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
-                                  skd_stream_t stream) {
+                                  int accumulate, skd_stream_t stream) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g) || !x || !out || !dout || !mean || !var || !edz || !eydz || !dx) return 0;
   if (!aligned16(x) || !aligned16(out) || !aligned16(dout) || !aligned16(dx) || (dres && !aligned16(dres)) || (dweight && !weight)) return 0;
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)g.P), block(kThreads);
   if (dres != nullptr)
-    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g);
+    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g, accumulate);
   else
-    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g);
+    abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g, accumulate);
   return ok();
 }
 

@@ -151,8 +151,19 @@ class _Geom:
         _lib.check(fn(*self._d(), z.data_ptr(), dz.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(),
                       eydz.data_ptr(), eps, act, slope, ws.data_ptr(), st), "skd_abn_backward_reduce")
 
+    def new_param_grad(self, ref):
+        """Buffer for dweight / dbias: the channels-last dx entries WRITE them (accumulate = 0), the NCHW entries keep
+        the reference's accumulate-into convention (bn.cu:217-229) and need zeros."""
+        return torch.empty_like(ref) if self.nhwc else torch.zeros_like(ref)
+
     def backward_dx(self, lib, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, st):
-        fn = lib.skd_abn_backward_dx_nhwc if self.nhwc else lib.skd_abn_backward_dx
+        if self.nhwc:
+            _lib.check(lib.skd_abn_backward_dx_nhwc(self.rows, self.c, z.data_ptr(), dz.data_ptr(), var.data_ptr(),
+                                                    _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(),
+                                                    _lib.ptr(dx), _lib.ptr(dweight), _lib.ptr(dbias), eps, act, slope, 0, st),
+                       "skd_abn_backward_dx_nhwc")
+            return
+        fn = lib.skd_abn_backward_dx
         _lib.check(fn(*self._d(), z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
                       edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight), _lib.ptr(dbias), eps, act, slope,
                       st), "skd_abn_backward_dx")
@@ -163,7 +174,13 @@ class _Geom:
                       edz.data_ptr(), eydz.data_ptr(), eps, ws.data_ptr(), st), "skd_abn_relu_backward_reduce")
 
     def relu_backward_dx(self, lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, st):
-        fn = lib.skd_abn_relu_backward_dx_nhwc if self.nhwc else lib.skd_abn_relu_backward_dx
+        if self.nhwc:
+            _lib.check(lib.skd_abn_relu_backward_dx_nhwc(self.rows, self.c, x.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                         mean.data_ptr(), var.data_ptr(), _lib.ptr(weight), edz.data_ptr(),
+                                                         eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight),
+                                                         _lib.ptr(dbias), eps, 0, st), "skd_abn_relu_backward_dx_nhwc")
+            return
+        fn = lib.skd_abn_relu_backward_dx
         _lib.check(fn(*self._d(), x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(), var.data_ptr(),
                       _lib.ptr(weight), edz.data_ptr(), eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres),
                       _lib.ptr(dweight), _lib.ptr(dbias), eps, st), "skd_abn_relu_backward_dx")
@@ -249,9 +266,10 @@ class _InPlaceABN(autograd.Function):
         st = _lib.stream_of(z)
 
         dx = torch.empty_like(z) if need_dx else None
-        dweight = torch.zeros_like(weight) if (need_dw and weight is not None) else None
-        dbias = torch.zeros_like(bias) if (need_db and bias is not None) else None
-        stat = z.new_zeros((2, c))          # functions.py:146-147: inference-mode backward uses edz = eydz = 0
+        dweight = geo.new_param_grad(weight) if (need_dw and weight is not None) else None
+        dbias = geo.new_param_grad(bias) if (need_db and bias is not None) else None
+        # functions.py:146-147: inference-mode backward uses edz = eydz = 0 (training overwrites both)
+        stat = z.new_empty((2, c)) if ctx.training else z.new_zeros((2, c))
         edz, eydz = stat[0], stat[1]
         if ctx.training:
             ws = geo.workspace(lib, z)
@@ -321,8 +339,8 @@ class _ABNRelu(autograd.Function):
         lib, st = _lib.get(), _lib.stream_of(x)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if need_res else None
-        dweight = torch.zeros_like(weight) if (need_dw and weight is not None) else None
-        dbias = torch.zeros_like(weight) if (need_db and weight is not None) else None
+        dweight = geo.new_param_grad(weight) if (need_dw and weight is not None) else None
+        dbias = geo.new_param_grad(weight) if (need_db and weight is not None) else None
         stat = x.new_empty((2, c))
         edz, eydz = stat[0], stat[1]
         ws = geo.workspace(lib, x)

@@ -13,8 +13,8 @@ What differs from the reference, none of it changing a number the step produces:
   * one process per GPU (utils/parallel.py here); gradients averaged by bucketed RCCL all-reduce;
   * the four logged scalars are kept as device tensors and read back lazily (one host sync when
     ``print_info`` / the attributes are read, instead of four ``.item()`` stalls inside the step);
-  * the teacher's cross-entropy, which the reference computes and discards (kd_model.py:129), is computed too
-    (forward only, fused kernel) and kept as ``mc_T_loss`` instead of being thrown away;
+  * the teacher's cross-entropy, which the reference computes and discards (kd_model.py:129), is not computed
+    (``SKD_TEACHER_CE=1`` / ``model.log_teacher_ce = True`` computes it, forward only, and keeps it as ``mc_T_loss``);
   * while the student loss is back-propagated through D (kd_model.py:148-150) D's parameters do not
     require grad: the reference computes those weight gradients and then zeroes them (kd_model.py:154).
 """
@@ -153,6 +153,7 @@ class NetModel():
                                                                     and torch.device(device).type == "cuda") else None)
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
+        self.log_teacher_ce = os.environ.get("SKD_TEACHER_CE", "0") == "1"
 
         # MIOpen find mode is opt-in: this ROCm image ships no gfx950 find/kernel database, so "find"
         # JIT-compiles every candidate solver for every convolution shape on a fresh machine.
@@ -232,8 +233,8 @@ class NetModel():
         args = self.args
         temp = self.criterion(self.preds_S, self.labels, is_target_scattered=False)
         self._scalars["mc_G_loss"] = temp.detach()
-        temp_T = self.criterion(self.preds_T, self.labels, is_target_scattered=False)     # kd_model.py:129
-        self._scalars["mc_T_loss"] = temp_T.detach()
+        if self.log_teacher_ce:     # kd_model.py:129 computes the teacher's CE and throws it away; off unless asked for
+            self._scalars["mc_T_loss"] = self.criterion(self.preds_T, self.labels, is_target_scattered=False).detach()
         G_loss = temp
         if args.pi == True:  # noqa: E712  (flags may arrive as 0/1)
             temp = args.lambda_pi * self.criterion_pixel_wise(self.preds_S, self.preds_T, is_target_scattered=True)

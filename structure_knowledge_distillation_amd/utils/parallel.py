@@ -33,12 +33,14 @@ def init_distributed(backend=None):
     rk = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # more ranks than GPUs: ranks share devices
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SKD_DIST_BACKEND=gloo lets N ranks share ONE GPU (tests, bench.py --gpus N on a 1-GPU box): same code
+            # path -- hooks, buckets, SyncABN collectives -- over gloo instead of RCCL
+            backend = os.environ.get("SKD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())

@@ -194,9 +194,9 @@ def test_abn_relu_training_fusion(hip, ref, shape, with_res):
     assert hip.skd_abn_relu_backward_reduce(N, C, S, P(xg), P(og), P(dg), P(mgg), P(vgg), P(eg), P(eyg), 1e-5, P(ws), None)
     close(eg, er, 5e-5, "edz"); close(eyg, eyr, 5e-5, "eydz")
     dxr, drr, dwr, dbr = torch.empty_like(x), (torch.empty_like(x) if with_res else None), torch.zeros(C), torch.zeros(C)
-    assert ref.skd_abn_relu_backward_dx(N, C, S, P(x), P(outr), P(dout), P(mr), P(vr), P(w), P(er), P(eyr), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, None)
+    assert ref.skd_abn_relu_backward_dx(N, C, S, P(x), P(outr), P(dout), P(mr), P(vr), P(w), P(er), P(eyr), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, 1, None)
     dxg, drg, dwg, dbg = torch.empty_like(xg), (torch.empty_like(xg) if with_res else None), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    assert hip.skd_abn_relu_backward_dx(N, C, S, P(xg), P(og), P(dg), P(mgg), P(vgg), P(gpu(w)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, None)
+    assert hip.skd_abn_relu_backward_dx(N, C, S, P(xg), P(og), P(dg), P(mgg), P(vgg), P(gpu(w)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, 1, None)
     mul = float(((w.abs() + 1e-5) / torch.sqrt(vr + 1e-5)).max())
     close(dxg, dxr, 1e-4, "dx", floor=float(dout.abs().max()) * mul)
     close(dwg, dwr, 5e-5, "dweight", floor=1e-6); close(dbg, dbr, 5e-5, "dbias", floor=1e-6)
@@ -221,7 +221,8 @@ def test_abn_apply_nhwc(hip, ref, rows, C, act):
     assert hip.skd_abn_apply_nhwc(rows, 6, P(gpu(x)), None, P(gpu(rm)), P(gpu(rv)), None, None, 1e-5, 0, 0.01, None) == 0   # C % 4
 
 
-@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 128), (8 * 129 * 129, 64), (2 * 33 * 33, 512), (8 * 36, 128), (50, 4), (1000, 1024)])
+@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 128), (8 * 129 * 129, 64), (2 * 33 * 33, 512), (8 * 36, 128), (50, 4), (1000, 1024),
+                                    (8 * 65 * 65, 512), (8 * 65 * 65, 256), (4 * 256 * 256, 64), (2, 128), (8, 128), (300000, 8)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_abn_nhwc_training(hip, ref, rows, C, act):
     """Channels-last training entries vs the C oracle: in-place ABN (act none / leaky) and the fused BN+ReLU form."""
@@ -249,9 +250,9 @@ def test_abn_nhwc_training(hip, ref, rows, C, act):
     assert hip.skd_abn_backward_reduce_nhwc(rows, C, P(gpu(zr)), P(gpu(dz)), P(gpu(w)), P(gpu(b)), P(eg), P(eyg), 1e-5, act, 0.01, P(ws_g), None)
     close(eg, er, 5e-5, "edz"); close(eyg, eyr, 5e-5, "eydz", floor=float(eyr.abs().max()) * 1e-1)
     dxr, dwr, dbr = torch.empty_like(x), torch.zeros(C), torch.zeros(C)
-    assert ref.skd_abn_backward_dx_nhwc(rows, C, P(zr), P(dz), P(vr), P(w), P(b), P(er), P(eyr), P(dxr), P(dwr), P(dbr), 1e-5, act, 0.01, None)
+    assert ref.skd_abn_backward_dx_nhwc(rows, C, P(zr), P(dz), P(vr), P(w), P(b), P(er), P(eyr), P(dxr), P(dwr), P(dbr), 1e-5, act, 0.01, 1, None)
     dxg, dwg, dbg = torch.empty(rows, C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    assert hip.skd_abn_backward_dx_nhwc(rows, C, P(gpu(zr)), P(gpu(dz)), P(gpu(vr)), P(gpu(w)), P(gpu(b)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(dwg), P(dbg), 1e-5, act, 0.01, None)
+    assert hip.skd_abn_backward_dx_nhwc(rows, C, P(gpu(zr)), P(gpu(dz)), P(gpu(vr)), P(gpu(w)), P(gpu(b)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(dwg), P(dbg), 1e-5, act, 0.01, 1, None)
     mul = float(((w.abs() + 1e-5) / torch.sqrt(vr + 1e-5)).max())
     close(dxg, dxr, 1e-4, "dx", floor=float(dz.abs().max()) * mul)
     close(dwg, dwr, 5e-5, "dweight", floor=1e-6); close(dbg, dbr, 5e-5, "dbias", floor=1e-6)
@@ -272,13 +273,68 @@ def test_abn_nhwc_training(hip, ref, rows, C, act):
         drr = torch.empty_like(x) if res is not None else None
         drg = torch.empty(rows, C, device=DEV) if res is not None else None
         dwr.zero_(); dbr.zero_(); dwg.zero_(); dbg.zero_()
-        assert ref.skd_abn_relu_backward_dx_nhwc(rows, C, P(x), P(outr), P(dz), P(mr), P(vr), P(w), P(er), P(eyr), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, None)
-        assert hip.skd_abn_relu_backward_dx_nhwc(rows, C, P(xg), P(gpu(outr)), P(gpu(dz)), P(gpu(mr)), P(gpu(vr)), P(gpu(w)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, None)
+        assert ref.skd_abn_relu_backward_dx_nhwc(rows, C, P(x), P(outr), P(dz), P(mr), P(vr), P(w), P(er), P(eyr), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, 1, None)
+        assert hip.skd_abn_relu_backward_dx_nhwc(rows, C, P(xg), P(gpu(outr)), P(gpu(dz)), P(gpu(mr)), P(gpu(vr)), P(gpu(w)), P(gpu(er)), P(gpu(eyr)), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, 1, None)
         close(dxg, dxr, 1e-4, "relu dx", floor=float(dz.abs().max()) * mul)
         close(dwg, dwr, 5e-5, "relu dweight", floor=1e-6); close(dbg, dbr, 5e-5, "relu dbias", floor=1e-6)
         if res is not None:
             assert torch.equal(drg.cpu(), drr)
     assert hip.skd_abn_nhwc_workspace_floats(100, 48) == 0     # not a power of two: caller must use NCHW
+
+
+def test_abn_single_sample_running_var_is_finite(hip):
+    """One sample per channel (PSP 1x1 stage at batch 1, one replica): the reference's n / (n - 1) poisons
+    running_var with NaN; here the biased variance (0) is kept -- DESIGN.md section 7."""
+    C = 128
+    for nhwc in (True, False):
+        x = torch.randn(1, C, device=DEV)
+        w, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        m, v = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        if nhwc:
+            ws = torch.empty(hip.skd_abn_nhwc_workspace_floats(1, C), device=DEV)
+            assert hip.skd_abn_forward_train_nhwc(1, C, P(x), None, P(x), P(w), P(b), P(rm), P(rv), P(m), P(v), 0.1, 1e-5, 1, 0.01, P(ws), None)
+        else:
+            ws = torch.empty(hip.skd_abn_workspace_floats(1, C, 1), device=DEV)
+            assert hip.skd_abn_forward_train(1, C, 1, P(x), P(w), P(b), P(rm), P(rv), P(m), P(v), 0.1, 1e-5, 1, 0.01, P(ws), None)
+        assert torch.isfinite(rv).all() and torch.allclose(rv.cpu(), torch.full((C,), 0.9)), nhwc
+        assert torch.isfinite(x).all()
+
+
+@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 512), (8 * 129 * 129, 64), (8 * 65 * 65, 128), (3000, 256)])
+def test_abn_nhwc_reduction_handoff_stress(hip, rows, C):
+    """The one-launch reductions hand their workgroup partials to the last-arriving workgroup through global memory
+    (release -> ticket -> acquire).  The summation order is fixed, so results must be BIT-identical from launch to
+    launch; a stale partial (a missed release / acquire, a counter that was not re-armed) would show up as a
+    different value.  Alternate two inputs over ONE workspace, uneven load from a concurrent stream."""
+    g = torch.Generator().manual_seed(C)
+    xs = [gpu(torch.randn(rows, C, generator=g) * (2 + i) + i) for i in range(2)]
+    dz = gpu(torch.randn(rows, C, generator=g))
+    w, b = gpu(torch.randn(C, generator=g)), gpu(torch.randn(C, generator=g))
+    ws = torch.empty(hip.skd_abn_nhwc_workspace_floats(rows, C), device=DEV)
+    side = torch.cuda.Stream()
+    noise = torch.randn(1 << 22, device=DEV)
+    first = {}
+    for it in range(60):
+        i = it & 1
+        if it % 7 == 0:
+            with torch.cuda.stream(side):       # uneven load on the chip while the hand-off happens
+                for _ in range(4):
+                    noise.mul_(1.0001)
+        m, v, e, ey = (torch.empty(C, device=DEV) for _ in range(4))
+        assert hip.skd_abn_stats_nhwc(rows, C, P(xs[i]), P(m), P(v), P(ws), None)
+        assert hip.skd_abn_backward_reduce_nhwc(rows, C, P(xs[i]), P(dz), P(w), P(b), P(e), P(ey), 1e-5, 1, 0.01, P(ws), None)
+        e2, ey2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        assert hip.skd_abn_relu_backward_reduce_nhwc(rows, C, P(xs[i]), P(xs[1 - i]), P(dz), P(m), P(v), P(e2), P(ey2), 1e-5, P(ws), None)
+        got = [t.clone() for t in (m, v, e, ey, e2, ey2)]
+        if i not in first:
+            first[i] = got
+            xd = xs[i].double()
+            close(m, xd.mean(0).float(), 2e-5, "mean"); close(v, xd.var(0, unbiased=False).float(), 5e-5, "var")
+        else:
+            for a, bb in zip(got, first[i]):
+                assert torch.equal(a, bb), "reduction result changed between launches (iteration %d)" % it
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("G,C", [(2, 6), (8, 512), (1, 64), (3, 1000)])
@@ -419,7 +475,8 @@ def test_maxpool_argmax_bit_exact(hip, ref, planes, H, W, kh, kw):
 
 
 @pytest.mark.parametrize("B,Cs,Ct,M", [(2, 16, 40, 9), (8, 128, 512, 9), (2, 128, 512, 81), (1, 5, 3, 1), (2, 130, 70, 289),
-                                        (1, 128, 512, 1089), (3, 8, 8, 128), (2, 12, 20, 129)])
+                                        (1, 128, 512, 1089), (3, 8, 8, 128), (2, 12, 20, 129),
+                                        (1, 128, 512, 4225)])      # M = 4225: the shape the MFMA roofline claim is quoted on (nt = 34)
 def test_pairwise_stages(hip, ref, B, Cs, Ct, M):
     g = torch.Generator().manual_seed(M + Cs)
     ps, pt = torch.randn(B, Cs, M, generator=g), torch.randn(B, Ct, M, generator=g)

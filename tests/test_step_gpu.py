@@ -102,8 +102,9 @@ def _preds(B, cs, ct, hw, gen, classes=19):
     return S, T
 
 
-@pytest.mark.parametrize("hw,scale", [(33, 0.5), (65, 0.5), (65, 0.125), (65, 0.0625), (65, 0.03125)])
+@pytest.mark.parametrize("hw,scale", [(33, 0.5), (65, 0.5), (65, 0.125), (65, 0.0625), (65, 0.03125), (65, 1.0 / 65)])
 def test_criteria_vs_oracle(hw, scale):
+    # scale = 1/65 -> 1x1 pooling window -> M = 4225 nodes: the shape the pair-wise MFMA roofline is quoted on
     gen = torch.Generator().manual_seed(hw)
     S, T = _preds(2, 128, 512, hw, gen)
     y = torch.randint(0, 19, (2, 8 * hw - 8, 8 * hw - 8), generator=gen)
@@ -272,3 +273,182 @@ def test_full_step_vs_oracle(ho):
         base = float((PS32[k].double() - PS64[k]).norm())
         err = float((after[k].detach().cpu().double() - PS64[k]).norm())
         assert err <= 8 * base + 1e-5 * float(PS64[k].norm()) + 1e-7, (k, err, base)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The BENCHMARKED configuration and the reference-generated fixtures, on the GPU
+# ---------------------------------------------------------------------------------------------------------------
+import math
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# ONE gradient bound: the error of a GPU gradient tensor against the fp64 oracle is at most
+# GRAD_BOUND x the error of the CPU-fp32 oracle against the fp64 oracle for the same tensor, plus GRAD_FLOOR of the
+# tensor's norm (tensors the CPU happens to get almost exactly -- biases of 19 channels, BN vectors -- have a base
+# error near zero).  The tests print the worst observed ratio so the bound can be audited from the log.
+GRAD_BOUND = 3.0
+GRAD_FLOOR = 1e-3
+
+
+def _load_oracle_weights(model, PS, PT, PD=None):
+    model.student.load_state_dict({k: v.clone() for k, v in PS.items()})
+    model.teacher.load_state_dict({k: v.clone() for k, v in PT.items()})
+    if PD is not None:
+        model.D_model.load_state_dict({k: v.clone() for k, v in PD.items()})
+
+
+def _rec_err(t, rec):
+    """(estimated L2 error, norm) of tensor ``t`` against a fixture record {step, sample, norm}: exact when the
+    sample is the whole tensor, otherwise the strided sample's error scaled by sqrt(numel / samples)."""
+    f = t.detach().cpu().double().reshape(-1)
+    assert list(t.shape) == rec["shape"], (tuple(t.shape), rec["shape"])
+    s = f[::rec["step"]][:rec["sample"].numel()]
+    return float((s - rec["sample"]).norm()) * math.sqrt(f.numel() / s.numel()), float(f.norm())
+
+
+def _check_grads(got, recs, what, bound=GRAD_BOUND, floor=GRAD_FLOOR):
+    worst_ratio, worst_rel, worst_key = 0.0, 0.0, None
+    for k, rec in recs.items():
+        assert got.get(k) is not None, k
+        err, nrm = _rec_err(got[k], rec)
+        ratio = err / (rec["base"] + floor * rec["norm"] / bound + 1e-12)
+        if ratio > worst_ratio:
+            worst_ratio, worst_key = ratio, k
+        worst_rel = max(worst_rel, err / (rec["norm"] + 1e-12))
+        assert err <= bound * rec["base"] + floor * rec["norm"] + 1e-7, (what, k, err, rec["base"], rec["norm"])
+        assert abs(nrm - rec["norm"]) <= bound * rec["base"] + floor * rec["norm"] + 1e-7, (what, k, nrm, rec["norm"])
+    print("%s: worst err / (base + floor) = %.3f at %s (bound %.1f); worst err / norm = %.2e"
+          % (what, worst_ratio, worst_key, bound, worst_rel))
+
+
+def test_full_step_b8_vs_golden():
+    """BASELINE configs[2] exactly as bench.py runs it -- batch 8, 512x512, Pi + Pa + Ho (wgan-gp) -- one step against
+    tests/golden/step_b8_oracle.pt (CPU oracle in fp64 and fp32; generator tests/golden/make_golden_step_b8.py)."""
+    gold = torch.load(os.path.join(GOLDEN_DIR, "step_b8_oracle.pt"), weights_only=False)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_step_b8", os.path.join(GOLDEN_DIR, "make_golden_step_b8.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                                          # the generator's init() / checksum() / seeds
+    B, H, W = gold["shape"]
+    PS, PT, PD = gen.init(torch.float32)
+    for name, P in (("student", PS), ("teacher", PT), ("D", PD)):      # same seeded weights as the generator saw
+        for k, v in gen.checksum(P).items():
+            assert abs(v - gold["checksums"][name][k]) <= 1e-9 * max(1.0, abs(v)), ("weight RNG drifted", name, k)
+    args = default_args(batch_size=B, device=DEV, weight_decay=gold["cfg"]["weight_decay"], lambda_pa=gold["cfg"]["lambda_pa"])
+    model = NetModel(args)
+    no_dropout(model.student)
+    _load_oracle_weights(model, PS, PT, PD)
+    images, labels = O.synthetic_batch(B, H, W, seed=gold["seeds"]["batch"])
+    alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(gold["seeds"]["alpha"]))
+    model.gp_alpha = alpha.to(DEV)
+    model.set_input((images, labels, None, None))
+    model.forward()
+    model.G_solver.zero_grad()
+    model.student_backward()
+    gS = {k: p.grad.detach().clone() for k, p in model.student.named_parameters()}
+    model.G_solver.step()
+    model.D_solver.zero_grad()
+    d_before = {k: p.detach().clone() for k, p in model.D_model.named_parameters()}
+    model.discriminator_backward()
+    for k, want in gold["losses64"].items():
+        got = getattr(model, k)
+        r = abs(got - want) / max(abs(want), 1e-12)
+        print("B=8 %-10s hip %.7g  oracle64 %.7g  rel %.2e  (cpu fp32 oracle rel %.2e)"
+              % (k, got, want, r, abs(gold["losses32"][k] - want) / max(abs(want), 1e-12)))
+        assert r < 1e-4, (k, got, want)                                    # north_star: 1e-4 relative
+    for i, (a, rec) in enumerate(zip(model.preds_S, gold["preds_S"])):
+        err, _ = _rec_err(a, rec)
+        assert err <= max(1e-4 * rec["norm"], GRAD_BOUND * rec["base"]), ("preds_S", i, err, rec["norm"], rec["base"])
+    for i, (a, rec) in enumerate(zip(model.preds_T[:3], gold["preds_T"])):
+        err, _ = _rec_err(a, rec)
+        assert err <= max(1e-4 * rec["norm"], GRAD_BOUND * rec["base"]), ("preds_T", i, err, rec["norm"], rec["base"])
+    _check_grads(gS, gold["grads_S"], "B=8 student gradients")
+    # D: gradients are recovered from the SGD update (p_after = p - lr * (g + wd * p), first step: buf = d)
+    lr_d, wd = model.D_solver.param_groups[0]["lr"], gold["cfg"]["weight_decay"]
+    gD = {k: (d_before[k] - p.detach()) / lr_d - wd * d_before[k] for k, p in model.D_model.named_parameters() if k in gold["grads_D"]}
+    _check_grads(gD, gold["grads_D"], "B=8 discriminator gradients", floor=5e-3)   # recovered through (p - p')/lr: 1e-7/4e-4 of |p| extra
+    after = model.student.state_dict()
+    for k, rec in gold["running"].items():
+        err, _ = _rec_err(after[k], rec)
+        assert err <= 1e-4 * rec["norm"] + 1e-7, ("running", k, err, rec["norm"])
+    for k, rec in gold["student_after"].items():
+        err, _ = _rec_err(after[k], rec)
+        assert err <= GRAD_BOUND * rec["base"] + 1e-5 * rec["norm"] + 1e-7, ("student_after", k, err, rec["base"])
+
+
+def _config1_step(pa):
+    """BASELINE configs[0] shape (batch 2, 256x256, 33x33 maps; Ho impossible at that size) on the GPU with the
+    weights / inputs of tests/golden/reference_vectors.pt["step_config1_pa"] (seeds 41, 42, 43)."""
+    s1, s2, s3 = 41, 42, 43
+    PS, PT = O.pspnet_init(O.STUDENT, 19, seed=s1, dtype=torch.float64), O.pspnet_init(O.TEACHER, 19, seed=s2, dtype=torch.float64)
+    x, y = O.synthetic_batch(2, 256, 256, seed=s3, dtype=torch.float64)
+    args = default_args(batch_size=2, device=DEV, ho=False, pa=pa, weight_decay=5e-4, lambda_pa=0.5)
+    model = NetModel(args)
+    no_dropout(model.student)
+    _load_oracle_weights(model, {k: v.float() if v.is_floating_point() else v for k, v in PS.items()},
+                         {k: v.float() if v.is_floating_point() else v for k, v in PT.items()})
+    # the fp64 / fp32 CPU oracles start from the fp32-rounded weights the GPU holds
+    P64 = ({k: v.float().double() if v.is_floating_point() else v.clone() for k, v in PS.items()},
+           {k: v.float().double() if v.is_floating_point() else v.clone() for k, v in PT.items()})
+    P32 = ({k: v.float() if v.is_floating_point() else v.clone() for k, v in PS.items()},
+           {k: v.float() if v.is_floating_point() else v.clone() for k, v in PT.items()})
+    cfg = O.StepConfig(pi=True, pa=pa, ho=False, lambda_pa=0.5, weight_decay=5e-4, dropout_p=0.0)
+    o64 = O.distillation_step(P64[0], P64[1], None, x.float().double(), y, cfg)
+    o32 = O.distillation_step(P32[0], P32[1], None, x.float(), y, cfg)
+    model.set_input((x.float(), y, None, None))
+    model.forward()
+    model.G_solver.zero_grad()
+    model.student_backward()
+    gS = {k: p.grad.detach().cpu().double() for k, p in model.student.named_parameters()}
+    model.G_solver.step()
+    return model, gS, o64, o32, P64, P32
+
+
+def _check_vs_live_oracle(model, gS, o64, o32, P64, P32, what):
+    for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
+        assert abs(getattr(model, k) - o64[k]) <= 1e-4 * abs(o64[k]) + 1e-12, (what, k, getattr(model, k), o64[k])
+    worst = 0.0
+    for k, gw in o64["grads_S"].items():
+        base = float((o32["grads_S"][k].double() - gw).norm())
+        err = float((gS[k] - gw).norm())
+        worst = max(worst, err / (base + GRAD_FLOOR * float(gw.norm()) / GRAD_BOUND + 1e-12))
+        assert err <= GRAD_BOUND * base + GRAD_FLOOR * float(gw.norm()) + 1e-7, (what, k, err, base, float(gw.norm()))
+    print("%s: worst gradient err / (base + floor) = %.3f (bound %.1f)" % (what, worst, GRAD_BOUND))
+    after = model.student.state_dict()
+    for k in O.learnable_keys(P64[0]):
+        base = float((P32[0][k].double() - P64[0][k]).norm())
+        err = float((after[k].detach().cpu().double() - P64[0][k]).norm())
+        assert err <= GRAD_BOUND * base + 1e-5 * float(P64[0][k].norm()) + 1e-7, (what, k, err, base)
+
+
+def test_step_config1_vs_reference_golden():
+    """The reference-generated fixture meets the HIP path: tests/golden/reference_vectors.pt["step_config1_pa"] was
+    produced by the reference's OWN modules (tests/golden/make_golden.py) in fp64; NetModel on the GPU starts from
+    the same seeded weights rounded to fp32 (a 6e-8 relative perturbation of every weight, which the tolerance of the
+    loss comparison -- 1e-4, north_star -- absorbs)."""
+    gold = torch.load(os.path.join(GOLDEN_DIR, "reference_vectors.pt"), weights_only=False)["step_config1_pa"]
+    assert tuple(gold["seeds"]) == (41, 42, 43)
+    model, gS, o64, o32, P64, P32 = _config1_step(pa=True)
+    for k, gk in (("mc_G_loss", "mc"), ("pi_G_loss", "pi"), ("pa_G_loss", "pa")):
+        want = float(gold[gk])
+        print("config1 %-10s hip %.7g  reference %.7g  rel %.2e" % (k, getattr(model, k), want, abs(getattr(model, k) - want) / abs(want)))
+        assert abs(getattr(model, k) - want) <= 1e-4 * abs(want), (k, getattr(model, k), want)
+    # gradients against the reference's strided samples; error budget from the live fp32-vs-fp64 CPU oracle
+    for k, rec in gold["grads"].items():
+        if float(rec["norm"]) <= 1e-12:
+            continue
+        base = float((o32["grads_S"][k].double() - o64["grads_S"][k]).norm())
+        f = gS[k].reshape(-1)
+        s = f[::rec["step"]][:rec["sample"].numel()]
+        err = float((s - rec["sample"]).norm()) * math.sqrt(f.numel() / s.numel())
+        # 16 samples per tensor: a coarse estimate, hence the factor 2 on top of the bound
+        assert err <= 2 * (GRAD_BOUND * base + GRAD_FLOOR * float(rec["norm"])) + 1e-7, (k, err, base, float(rec["norm"]))
+        assert abs(float(f.norm()) - float(rec["norm"])) <= GRAD_BOUND * base + GRAD_FLOOR * float(rec["norm"]) + 1e-7, k
+    _check_vs_live_oracle(model, gS, o64, o32, P64, P32, "config1 Pi+Pa")
+
+
+def test_step_config1_pi_only():
+    """BASELINE configs[0]: Pi only, batch 2, 256x256 -- the reference's own CPU-runnable case."""
+    model, gS, o64, o32, P64, P32 = _config1_step(pa=False)
+    assert model.pa_G_loss == 0.0
+    _check_vs_live_oracle(model, gS, o64, o32, P64, P32, "config1 Pi only")

@@ -1,0 +1,82 @@
+#!/bin/bash
+# One GPU-box session (gpurun): every section writes under gpurun_out/<tag>/ and is bounded by its own timeout.
+#   tools/gpu_session.sh <tag> <section> [<section> ...]
+# sections: tests_new | tests_all | smoke | bench | bench_prof | micro | micro_prof | pmc | conv | dist
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
+O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+t0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - t0 )) s] $1" | tee -a $O/session.log; }
+for sec in "$@"; do
+  case $sec in
+    tests_new)
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
+        -k "nhwc or pairwise or b8 or config1 or single_sample or criteria or small_m or ppm" > $O/pytest_new.log 2>&1
+      stamp "tests_new rc=$?"; grep -E "passed|failed|error" $O/pytest_new.log | tail -3 | tee -a $O/session.log
+      grep -E "worst|B=8 |config1 " $O/pytest_new.log | tee -a $O/session.log ;;
+    tests_all)
+      timeout 1500 python -m pytest tests -m gpu -q --tb=short -s > $O/pytest_gpu.log 2>&1
+      stamp "tests_all rc=$?"; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 | tee -a $O/session.log
+      grep -E "worst|B=8 |config1 " $O/pytest_gpu.log | tee -a $O/session.log ;;
+    smoke)
+      (timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1
+      stamp "smoke rc=$?"; tail -7 $O/smoke.log | tee -a $O/session.log ;;
+    bench)
+      (timeout 600 python bench.py) > $O/bench.json 2> $O/bench.err
+      stamp "bench rc=$?"; cut -c1-1500 $O/bench.json | tee -a $O/session.log ;;
+    bench_quick)
+      (timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_quick.json 2> $O/bench_quick.err
+      stamp "bench_quick rc=$?"; cut -c1-1200 $O/bench_quick.json | tee -a $O/session.log ;;
+    bench_prof)
+      (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- \
+        python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-pairwise-sweep > $O/prof_bench.log 2>&1)
+      stamp "bench_prof rc=$?" ;;
+    micro)
+      timeout 300 python tools/kernel_microbench.py time 20 > $O/micro.jsonl 2> $O/micro.err
+      stamp "micro rc=$?"; grep -v manifest $O/micro.jsonl | cut -c1-230 | tee -a $O/session.log ;;
+    micro_prof)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_micro -o micro -- \
+        python $R/tools/kernel_microbench.py time 5 > $O/prof_micro.log 2>&1)
+      stamp "micro_prof rc=$?" ;;
+    pmc)
+      # counters in their own passes, --kernel-trace only (no --stats / sys-trace next to --pmc)
+      i=0
+      for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+                 "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+                 "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"; do
+        i=$((i+1))
+        (cd /tmp && timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o k -- \
+          python $R/tools/kernel_microbench.py pmc > $O/pmc$i.log 2>&1)
+        stamp "pmc pass $i ($set) rc=$?"
+        # keep only what the summariser needs from the (large) counter CSV: drop the long torch kernel names
+        for f in $(find $O/pmc$i -name "*counter_collection.csv"); do
+          python - "$f" <<'EOF'
+import csv, sys
+f = sys.argv[1]
+rows = list(csv.DictReader(open(f, newline="")))
+keep = [r for r in rows if "skd::" in r["Kernel_Name"]]
+for r in keep:
+    r["Kernel_Name"] = r["Kernel_Name"][:200]
+w = csv.DictWriter(open(f, "w", newline=""), fieldnames=list(rows[0].keys()) if rows else [])
+w.writeheader(); w.writerows(keep)
+EOF
+        done
+        find $O/pmc$i -name "*kernel_trace.csv" -delete
+      done
+      python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 $O/pmc5 >> $O/session.log 2>&1
+      stamp "pmc summarised" ;;
+    conv)
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof_conv -o conv -- \
+        python $R/tools/conv_table.py 10 > $O/conv_table.jsonl 2> $O/conv_table.err)
+      stamp "conv rc=$?"; tail -1 $O/conv_table.jsonl | tee -a $O/session.log
+      python tools/summarise_conv_table.py $O/conv_table.jsonl $O/prof_conv $O/conv_shapes.md >> $O/session.log 2>&1 ;;
+    dist)
+      SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
+      stamp "dist rc=$?"; cut -c1-600 $O/bench_dist.json | tee -a $O/session.log ;;
+  esac
+done
+# large raw traces do not travel back (64 MiB cap): keep stats, drop per-dispatch traces except the conv one (names needed)
+find $O -name "*kernel_trace.csv" -size +20M -delete
+du -sh $O | tee -a $O/session.log

@@ -1,0 +1,137 @@
+"""GPU tool: the hand-written kernels alone, at the shapes the batch-8 512x512 step gives them.
+
+    python tools/kernel_microbench.py time [reps]     HIP-event timing per C-ABI call  -> one JSON line per case
+    python tools/kernel_microbench.py pmc             2 calls per case, each case preceded by a MARKER launch
+
+The pmc mode is what rocprofv3 --pmc passes are run over (tools/gpu_session.sh); tools/summarise_pmc.py maps every
+dispatch of the counter CSVs back to its case through the markers (a skd_leaky_relu launch whose grid size encodes
+the case id), so per-case HBM bytes / MFMA counters need no guessing from grid sizes.
+
+Cases = the channels-last TRAINING InPlace-ABN entries on the student's layers, the channels-last inference apply on
+the teacher's layers, and the pair-wise Gram / backward kernels at M in {9, 1089, 4225}.  Each case states its
+ALGORITHMIC bytes or flops per call; the manifest is printed as the first JSON line.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+STUDENT = [(8 * 256 * 256, 64), (8 * 256 * 256, 128), (8 * 129 * 129, 64), (8 * 65 * 65, 128), (8 * 65 * 65, 256),
+           (8 * 65 * 65, 512)]
+TEACHER = [(8 * 65 * 65, 1024), (8 * 65 * 65, 2048), (8 * 65 * 65, 256), (8 * 129 * 129, 256), (8 * 65 * 65, 512)]
+PAIRWISE_M = [9, 1089, 4225]
+
+
+def build_cases(lib, torch, dev, st):
+    p = lambda t: None if t is None else t.data_ptr()
+    cases = []
+
+    def add(name, shape, fn, bytes_=None, flops=None, keep=()):
+        cases.append({"id": len(cases), "name": name, "shape": shape, "algo_bytes": bytes_, "algo_flops": flops,
+                      "fn": fn, "keep": keep})
+
+    for rows, C in STUDENT:
+        n = rows * C
+        x, r, dz, out, dx, dres = (torch.randn(rows, C, device=dev) for _ in range(6))
+        w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        m, v = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        e, ey = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ws = torch.empty(lib.skd_abn_nhwc_workspace_floats(rows, C), device=dev)
+        keep = (x, r, dz, out, dx, dres, w, b, rm, rv, m, v, e, ey, dw, db, ws)
+        sh = [rows, C]
+        add("stats_nhwc", sh, lambda x=x, m=m, v=v, ws=ws, rows=rows, C=C: lib.skd_abn_stats_nhwc(rows, C, p(x), p(m), p(v), p(ws), st), 4 * n, keep=keep)
+        add("forward_train_nhwc(leaky,in place)", sh, lambda x=x, w=w, b=b, rm=rm, rv=rv, m=m, v=v, ws=ws, rows=rows, C=C:
+            lib.skd_abn_forward_train_nhwc(rows, C, p(x), None, p(x), p(w), p(b), p(rm), p(rv), p(m), p(v), 0.1, 1e-5, 1, 0.01, p(ws), st), 12 * n)
+        add("forward_train_nhwc(relu,to out)", sh, lambda x=x, out=out, w=w, b=b, rm=rm, rv=rv, m=m, v=v, ws=ws, rows=rows, C=C:
+            lib.skd_abn_forward_train_nhwc(rows, C, p(x), None, p(out), p(w), p(b), p(rm), p(rv), p(m), p(v), 0.1, 1e-5, 3, 0.0, p(ws), st), 12 * n)
+        add("forward_train_nhwc(relu,+residual)", sh, lambda x=x, r=r, out=out, w=w, b=b, rm=rm, rv=rv, m=m, v=v, ws=ws, rows=rows, C=C:
+            lib.skd_abn_forward_train_nhwc(rows, C, p(x), p(r), p(out), p(w), p(b), p(rm), p(rv), p(m), p(v), 0.1, 1e-5, 3, 0.0, p(ws), st), 16 * n)
+        add("backward_reduce_nhwc(leaky)", sh, lambda x=x, dz=dz, w=w, b=b, e=e, ey=ey, ws=ws, rows=rows, C=C:
+            lib.skd_abn_backward_reduce_nhwc(rows, C, p(x), p(dz), p(w), p(b), p(e), p(ey), 1e-5, 1, 0.01, p(ws), st), 8 * n)
+        add("backward_dx_nhwc(leaky)", sh, lambda x=x, dz=dz, v=rv, w=w, b=b, e=e, ey=ey, dx=dx, dw=dw, db=db, rows=rows, C=C:
+            lib.skd_abn_backward_dx_nhwc(rows, C, p(x), p(dz), p(v), p(w), p(b), p(e), p(ey), p(dx), p(dw), p(db), 1e-5, 1, 0.01, 0, st), 12 * n)
+        add("relu_backward_reduce_nhwc", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, e=e, ey=ey, ws=ws, rows=rows, C=C:
+            lib.skd_abn_relu_backward_reduce_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(e), p(ey), 1e-5, p(ws), st), 12 * n)
+        add("relu_backward_dx_nhwc", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, e=e, ey=ey, dx=dx, dw=dw, db=db, rows=rows, C=C:
+            lib.skd_abn_relu_backward_dx_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(e), p(ey), p(dx), None, p(dw), p(db), 1e-5, 0, st), 16 * n)
+        add("relu_backward_dx_nhwc(+dres)", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, e=e, ey=ey, dx=dx, dres=dres, dw=dw, db=db, rows=rows, C=C:
+            lib.skd_abn_relu_backward_dx_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(e), p(ey), p(dx), p(dres), p(dw), p(db), 1e-5, 0, st), 20 * n)
+    for rows, C in TEACHER:
+        n = rows * C
+        x, r = torch.randn(rows, C, device=dev), torch.randn(rows, C, device=dev)
+        w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        keep = (x, r, w, b, rm, rv)
+        add("apply_nhwc(eval,relu)", [rows, C], lambda x=x, w=w, b=b, rm=rm, rv=rv, rows=rows, C=C:
+            lib.skd_abn_apply_nhwc(rows, C, p(x), None, p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st), 8 * n, keep=keep)
+        add("apply_nhwc(eval,relu,+residual)", [rows, C], lambda x=x, r=r, w=w, b=b, rm=rm, rv=rv, rows=rows, C=C:
+            lib.skd_abn_apply_nhwc(rows, C, p(x), p(r), p(rm), p(rv), p(w), p(b), 1e-5, 3, 0.01, st), 12 * n)
+    B, Cs, Ct = 8, 128, 512
+    for M in PAIRWISE_M:
+        ldm = lib.skd_pairwise_ldm(M)
+        ldc = -(-Cs // 128) * 128
+        ps, pt = torch.randn(B, Cs, M, device=dev), torch.randn(B, Ct, M, device=dev)
+        fs, ft = torch.empty(B, Cs, ldm, device=dev), torch.empty(B, Ct, ldm, device=dev)
+        fst, nrm = torch.empty(B, ldm, ldc, device=dev), torch.empty(B, M, device=dev)
+        G, loss, gl = torch.empty(B, ldm, ldm, device=dev), torch.empty(1, device=dev), torch.ones(1, device=dev)
+        dp = torch.empty(B, Cs, ldm, device=dev)
+        ws = torch.empty(max(1, lib.skd_pairwise_workspace_floats(B, M)), device=dev)
+        keep = (ps, pt, fs, ft, fst, nrm, G, loss, gl, dp, ws)
+        lib.skd_channel_l2_normalise(B, Ct, M, p(pt), p(ft), ldm, None, 0, None, st)
+        add("l2_normalise(student,+transpose)", [B, Cs, M], lambda ps=ps, fs=fs, fst=fst, nrm=nrm, M=M, ldm=ldm, ldc=ldc:
+            lib.skd_channel_l2_normalise(B, Cs, M, p(ps), p(fs), ldm, p(fst), ldc, p(nrm), st), 4 * B * Cs * M * 3, keep=keep)
+        add("pairwise_gram_loss", [B, Cs, Ct, M], lambda fs=fs, ft=ft, G=G, loss=loss, ws=ws, M=M, ldm=ldm:
+            lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, p(fs), p(ft), p(G), p(loss), p(ws), st), flops=2.0 * B * M * M * (Cs + Ct))
+        add("pairwise_backward", [B, Cs, M], lambda fst=fst, G=G, nrm=nrm, gl=gl, dp=dp, M=M, ldm=ldm, ldc=ldc:
+            lib.skd_pairwise_backward(B, Cs, M, ldm, ldc, p(fst), p(G), p(nrm), p(gl), p(dp), st), flops=2.0 * B * M * M * Cs)
+    return cases
+
+
+def main():
+    import torch
+    from structure_knowledge_distillation_amd import _lib
+    lib = _lib.load()
+    mode = sys.argv[1] if len(sys.argv) > 1 else "time"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    only = sys.argv[3] if len(sys.argv) > 3 else None
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = build_cases(lib, torch, dev, st)
+    print(json.dumps({"manifest": [{k: c[k] for k in ("id", "name", "shape", "algo_bytes", "algo_flops")} for c in cases]}), flush=True)
+    marker_buf = torch.zeros(256 * (len(cases) + 2), device=dev)
+    torch.cuda.synchronize()
+    for c in cases:
+        if only and only not in c["name"]:
+            continue
+        fn = c["fn"]
+        if mode == "pmc":
+            assert lib.skd_leaky_relu(256 * (c["id"] + 1), marker_buf.data_ptr(), 1.0, st)     # marker: grid = id + 1 workgroups
+            for _ in range(2):
+                assert fn()
+            continue
+        for _ in range(3):
+            assert fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        row = {"id": c["id"], "name": c["name"], "shape": c["shape"], "us": round(ms * 1e3, 2)}
+        if c["algo_bytes"]:
+            row["GBs"] = round(c["algo_bytes"] / (ms * 1e-3) / 1e9, 1)
+            row["frac_hbm_8TBs"] = round(row["GBs"] / 8000.0, 3)
+        if c["algo_flops"]:
+            row["TFLOPs(full-matrix convention)"] = round(c["algo_flops"] / (ms * 1e-3) / 1e12, 2)
+            row["frac_fp32_mfma_157.3"] = round(row["TFLOPs(full-matrix convention)"] / 157.3, 4)
+        print(json.dumps(row), flush=True)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
