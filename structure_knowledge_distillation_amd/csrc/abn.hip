@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
 //   * wide tensors are cut into CB <= 4 channel blocks of >= 64 channels (256-byte row segments), so a workgroup's
 //     partial is 2*CW floats and a channel block's partials total <= 128 KiB;
 //   * partials are workgroup-major and contiguous: part[cb][rg][CW4][8] (per quad: four first sums, four second sums);
-//   * the LAST workgroup of a channel block to arrive (agent-scope release -> ticket -> acquire,
+//   * the LAST workgroup of a channel block to arrive (write-through partial stores -> drained -> agent-scope ticket;
 //     MI355X_MICROARCH.md "inter-workgroup visibility") sums the RG partial rows in double precision in a fixed
 //     order -- bit-identical whichever workgroup happens to be last -- and finishes the statistics in place
 //     (mean / var + running update, or edz / eydz).  No finalize launch, no atomically accumulated floats.
@@ -1120,6 +1120,28 @@ static unsigned *red_counters() {
   return p.ptr + (size_t)slot * kRedMaxCB;
 }
 
+// 16-byte write-through store / L1-bypassing load (sc0 sc1): the hand-off traffic of the reductions below.  A plain
+// store would stay dirty in the producer XCD's L2 until an agent-scope release (buffer_wbl2) flushes that WHOLE L2 --
+// right after a convolution that is megabytes of unrelated dirty lines on the reduction's critical path.  With
+// write-through partials the producer only drains its own stores (s_waitcnt vmcnt(0)) before taking its ticket, and
+// the last arriver reads them with sc1 loads: no release / acquire fence at all (MI355X_MICROARCH.md, "valid forms":
+// sc0 sc1 stores and loads on both sides).
+__device__ __forceinline__ void store_wt16(float *p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void load_wt16x4(const float *p0, const float *p1, const float *p2, const float *p3, f32x4 &v0,
+                                            f32x4 &v1, f32x4 &v2, f32x4 &v3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+
 // Workgroup epilogue of a channels-last reduction.  In: every thread's eight running sums.  Out: `true` in all
 // threads of the channel block's last-arriving workgroup, with the block's totals in fin[cq * 8 + k] (double).
 // lds: kRedThreads * 4 doubles; fin: L doubles.
@@ -1152,44 +1174,47 @@ __device__ __forceinline__ bool red_finish(float (&s1)[4], float (&s2)[4], float
     for (int k = 0; k < 8; ++k) o[k] = a[k];
   }
   __syncthreads();
+  const int L4 = g.L >> 2;                 // float4 per partial row (a power of two, 2 ... 128)
   float *mine = part + ((int64_t)cb * g.RG + rg) * g.L;
-  for (int i = t; i < g.L; i += kRedThreads) {
-    float s = 0.f;
-    for (int sl = 0; sl < nslots; ++sl) s += ldsf[sl * g.L + i];
-    mine[i] = s;
-  }
-  __syncthreads();   // every wave's partial stores are acknowledged before lane 0 releases them
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (unsigned)g.RG - 1u) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for a later launch
+  if (t < L4) {                            // fixed-order sum over the slots, one 16-byte write-through store per lane
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < nslots; ++sl) {
+      const float4 v = *reinterpret_cast<const float4 *>(ldsf + sl * g.L + 4 * t);
+      s[0] += v.x;
+      s[1] += v.y;
+      s[2] += v.z;
+      s[3] += v.w;
     }
-    *ticket_s = old;
+    store_wt16(mine + 4 * t, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's partial has left for memory
   }
   __syncthreads();
+  if (t == 0) *ticket_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   if (*ticket_s != (unsigned)g.RG - 1u) return false;
+  if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for a later launch
   // ---- last arriver: fixed-order double-precision sum of the RG partial rows of this channel block ----
-  const int L4 = g.L >> 2;                 // float4 per partial row (a power of two, 2 ... 512)
   const int NP = kRedThreads / L4;         // row phases
   const int j4 = t & (L4 - 1), ph = t / L4;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const float *col = part + (int64_t)cb * g.RG * g.L + j4 * 4;
   for (int r = ph; r < g.RG; r += 4 * NP) {
-    float4 v[4];
+    f32x4 v[4];
+    const float *q[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int rr = r + u * NP;
-      v[u] = rr < g.RG ? *reinterpret_cast<const float4 *>(col + (int64_t)rr * g.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+      q[u] = col + (int64_t)(rr < g.RG ? rr : r) * g.L;     // out-of-range phases re-read row r and are not added
     }
+    load_wt16x4(q[0], q[1], q[2], q[3], v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      acc[0] += (double)v[u].x;
-      acc[1] += (double)v[u].y;
-      acc[2] += (double)v[u].z;
-      acc[3] += (double)v[u].w;
+      if (r + u * NP < g.RG) {
+        acc[0] += (double)v[u][0];
+        acc[1] += (double)v[u][1];
+        acc[2] += (double)v[u][2];
+        acc[3] += (double)v[u][3];
+      }
     }
   }
 #pragma unroll
