@@ -174,7 +174,8 @@ def main():
     _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(1234)
-    args = default_args(batch_size=a.batch, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000)
+    # args.batch_size is the reference's GLOBAL batch (nn.DataParallel scatters it); every rank holds a.batch images
+    args = default_args(batch_size=a.batch * world, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000)
     model = NetModel(args)
     gen = torch.Generator().manual_seed(100 + rank)
     images = (torch.randn(a.batch, 3, a.size, a.size, generator=gen) * 57.0).to(dev)

@@ -152,10 +152,13 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
                                   const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
                                   float eps, int accumulate, skd_stream_t stream);
 /* cross-replica combine in one launch (functions.py:196-197, 208-209): gathered is (G, 2, C) = every rank's
- * [mean, var] (equal per-rank sample counts, as the reference assumes); writes the combined mean / var and, when
- * the running buffers are given, updates them with n = per-rank count * G. */
-int skd_abn_combine_stats(int G, int C, const float *gathered, float *mean, float *var, float *running_mean,
-                          float *running_var, float momentum, double n, skd_stream_t stream);
+ * [mean, var]; writes the combined mean / var and, when the running buffers are given, updates them.
+ * weights == NULL: the reference rule (equal per-rank sample counts), n = the POOLED count.
+ * weights != NULL: G floats w_g = n_g / sum(n) -> exact pooled statistics for unequal shards (equal shards give the
+ * reference rule back); n = THIS rank's count, rank = this rank's index into weights (pooled count = n / w[rank]). */
+int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean,
+                          float *var, float *running_mean, float *running_var, float momentum, double n,
+                          skd_stream_t stream);
 /* running-stat update with an explicit sample count n (functions.py:209) */
 int skd_abn_update_running(int C, float *running_mean, float *running_var, const float *mean,
                            const float *var, float momentum, double n, skd_stream_t stream);

@@ -477,21 +477,22 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
   return r;
 }
 
-/* ---- cross-replica combine, libs/functions.py:196-197 + 208-209 ---- */
-int skd_abn_combine_stats(int G, int C, const float *gathered, float *mean, float *var, float *rm, float *rv,
-                          float momentum, double n, stream_t st) {
-  if (G <= 0 || C <= 0 || !gathered || !mean || !var) return 0;
+/* ---- cross-replica combine, libs/functions.py:196-197 + 208-209 ----
+ * weights == NULL is the reference rule; weights (w_g = n_g / sum n) the pooled statistics of unequal shards. */
+int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var,
+                          float *rm, float *rv, float momentum, double n, stream_t st) {
+  if (G <= 0 || C <= 0 || !gathered || !mean || !var || (weights && (rank < 0 || rank >= G))) return 0;
   for (int c = 0; c < C; ++c) {
     double m = 0.0, v = 0.0;
-    for (int g = 0; g < G; ++g) m += gathered[((int64_t)g * 2) * C + c];
-    m /= G;                                                        /* means.mean(0) */
+    for (int g = 0; g < G; ++g) m += (weights ? (double)weights[g] : 1.0 / G) * gathered[((int64_t)g * 2) * C + c];   /* means.mean(0) */
     for (int g = 0; g < G; ++g) {
       const double d = m - gathered[((int64_t)g * 2) * C + c];
-      v += gathered[((int64_t)g * 2 + 1) * C + c] + d * d;         /* (vars + (mean - means)**2).mean(0) */
+      v += (weights ? (double)weights[g] : 1.0 / G) * (gathered[((int64_t)g * 2 + 1) * C + c] + d * d);   /* (vars + (mean - means)**2).mean(0) */
     }
     mean[c] = (float)m;
-    var[c] = (float)(v / G);
+    var[c] = (float)v;
   }
+  if (weights) n = n / (double)weights[rank];
   if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, n, st);
   return 1;
 }

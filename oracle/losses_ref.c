@@ -288,7 +288,8 @@ int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lm
       tap_of(Y, sy, h, &y0, &y1, &ly0, &ly1);
       for (int X = 0; X < W; ++X) {
         const int64_t t = target[((int64_t)b * H + Y) * W + X];
-        if (t == (int64_t)ignore_index || t < 0 || t >= C) continue;
+        if (t == (int64_t)ignore_index) continue;
+        if (t < 0 || t >= C) { cnt = NAN; continue; }              /* F.cross_entropy would assert: poison the call */
         int x0, x1; float lx0, lx1;
         tap_of(X, sx, w, &x0, &x1, &lx0, &lx1);
         cnt += 1.0;

@@ -17,7 +17,84 @@ import os as _os
 # MIOpen user find-db + kernel cache tuned for this step's convolution shapes on gfx950 (made by
 # tools/miopen_tune.py with MIOpen's own tuner; the ROCm image ships no gfx950 database).  Must be in
 # the environment before the first convolution initialises MIOpen.
+#
+# MIOpen treats the user db / cache directories as WRITABLE (an unseen problem appends to them), so the shipped
+# database is never handed over directly: it is copied once into a per-user, per-rank cache directory
+# (SKD_MIOPEN_CACHE, default ~/.cache/skd_amd, /tmp as a last resort) and MIOpen is pointed at the copy -- eight ranks
+# never append to the same git-tracked files, and a read-only install still works.
 MIOPEN_DB_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+MIOPEN_DB_VERSION = None       # (major, minor, patch) of the MIOpen build the shipped find-db was recorded with
+
+
+def _miopen_db_version():
+    import re
+    for f in sorted(_os.listdir(MIOPEN_DB_DIR)):
+        m = re.search(r"\.HIP\.(\d+)_(\d+)_(\d+)_", f)
+        if m:
+            return tuple(int(x) for x in m.groups())
+    return None
+
+
+def _private_miopen_db():
+    import hashlib
+    import shutil
+    import tempfile
+    tag = hashlib.sha1()
+    for root, _, files in sorted(_os.walk(MIOPEN_DB_DIR)):
+        for f in sorted(files):
+            tag.update(f.encode())
+            with open(_os.path.join(root, f), "rb") as fh:
+                tag.update(fh.read())
+    name = "miopen_db_%s_r%s" % (tag.hexdigest()[:12], _os.environ.get("LOCAL_RANK", "0"))
+    bases = [_os.environ.get("SKD_MIOPEN_CACHE"), _os.path.join(_os.path.expanduser("~"), ".cache", "skd_amd"),
+             _os.path.join(tempfile.gettempdir(), "skd_amd_%d" % _os.getuid())]
+    for base in bases:
+        if not base:
+            continue
+        dst = _os.path.join(base, name)
+        try:
+            if not _os.path.isdir(dst):
+                _os.makedirs(base, exist_ok=True)
+                tmp = tempfile.mkdtemp(prefix=name + ".", dir=base)
+                shutil.copytree(MIOPEN_DB_DIR, _os.path.join(tmp, "db"))
+                try:
+                    _os.rename(_os.path.join(tmp, "db"), dst)      # atomic: concurrent ranks race harmlessly
+                except OSError:
+                    pass
+                shutil.rmtree(tmp, ignore_errors=True)
+            if _os.path.isdir(dst) and _os.access(dst, _os.W_OK):
+                return dst
+        except OSError:
+            continue
+    return None
+
+
+def check_miopen_db(warn=True):
+    """True when the running MIOpen matches the build the shipped find-db was tuned on.  A mismatch means MIOpen
+    silently ignores the database (its file names carry the version) and falls back to untuned immediate-mode
+    heuristics -- 58-70 instead of 107-137 TFLOP/s on the dilated 3x3 convolutions of this step -- so it WARNS loudly;
+    re-run tools/miopen_tune.py on the new build."""
+    if MIOPEN_DB_VERSION is None:
+        return True
+    try:
+        import torch
+        v = torch.backends.cudnn.version()
+    except Exception:
+        return True
+    if not v:
+        return True
+    have = (v // 1000000, (v // 1000) % 1000, v % 1000)
+    if have != MIOPEN_DB_VERSION and warn:
+        import warnings
+        warnings.warn("structure_knowledge_distillation_amd: the shipped MIOpen find-db was tuned on MIOpen %d.%d.%d but this "
+                      "process runs MIOpen %d.%d.%d: the tuned convolution kernels will NOT be used (expect ~40 %% lower "
+                      "convolution throughput); re-run tools/miopen_tune.py" % (MIOPEN_DB_VERSION + have), RuntimeWarning)
+    return have == MIOPEN_DB_VERSION
+
+
 if _os.path.isdir(MIOPEN_DB_DIR):
-    _os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB_DIR)
-    _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(MIOPEN_DB_DIR, "cache"))
+    MIOPEN_DB_VERSION = _miopen_db_version()
+    if "MIOPEN_USER_DB_PATH" not in _os.environ:
+        _dst = _private_miopen_db() or MIOPEN_DB_DIR
+        _os.environ["MIOPEN_USER_DB_PATH"] = _dst
+        _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(_dst, "cache"))

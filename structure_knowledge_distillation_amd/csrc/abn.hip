@@ -231,20 +231,25 @@ __global__ __launch_bounds__(kThreads) void abn_stats_finalize_kernel(
 
 // Cross-replica combine (libs/functions.py:196-197, 208-209) in one launch: gathered is (G, 2, C) = per-rank
 // [mean, var]; mean = means.mean(0); var = (vars + (mean - means)^2).mean(0); running stats with n = count * G.
-__global__ void abn_combine_stats_kernel(int G, int C, const float *__restrict__ gathered, float *__restrict__ mean,
+// The reference rule assumes every replica saw the same number of samples.  `weights` (G floats summing to one,
+// w_g = n_g / sum n, may be NULL) generalises it to unequal shards -- the exact pooled statistics; with equal shards
+// it is the reference rule.  With weights, `nf` is THIS rank's count and the pooled count is nf / weights[rank].
+__global__ void abn_combine_stats_kernel(int G, int C, const float *__restrict__ gathered,
+                                         const float *__restrict__ weights, int rank, float *__restrict__ mean,
                                          float *__restrict__ var, float *running_mean, float *running_var,
                                          float momentum, float nf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float m = 0.f;
-  for (int g = 0; g < G; ++g) m += gathered[((int64_t)g * 2) * C + c];
-  m /= (float)G;
+  for (int g = 0; g < G; ++g) m += (weights ? weights[g] : 1.f) * gathered[((int64_t)g * 2) * C + c];
+  if (!weights) m /= (float)G;
   float v = 0.f;
   for (int g = 0; g < G; ++g) {
     const float d = m - gathered[((int64_t)g * 2) * C + c];
-    v += gathered[((int64_t)g * 2 + 1) * C + c] + d * d;
+    v += (weights ? weights[g] : 1.f) * (gathered[((int64_t)g * 2 + 1) * C + c] + d * d);
   }
-  v /= (float)G;
+  if (!weights) v /= (float)G;
+  if (weights) nf = nf / weights[rank];
   mean[c] = m;
   var[c] = v;
   if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m;
@@ -1418,11 +1423,11 @@ int skd_abn_stats(int N, int C, int S, const float *x, float *mean, float *var, 
   return ok();
 }
 
-int skd_abn_combine_stats(int G, int C, const float *gathered, float *mean, float *var, float *running_mean,
-                          float *running_var, float momentum, double n, skd_stream_t stream) {
-  if (G <= 0 || C <= 0 || !gathered || !mean || !var) return 0;
+int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var,
+                          float *running_mean, float *running_var, float momentum, double n, skd_stream_t stream) {
+  if (G <= 0 || C <= 0 || !gathered || !mean || !var || (weights && (rank < 0 || rank >= G))) return 0;
   abn_combine_stats_kernel<<<dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream)>>>(
-      G, C, gathered, mean, var, running_mean, running_var, momentum, (float)n);
+      G, C, gathered, weights, rank, mean, var, running_mean, running_var, momentum, (float)n);
   return ok();
 }
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void ce_rows_kernel(const float *__restri
   __shared__ float red2[2 * kWavesPerWG];
   const int64_t total = (int64_t)B * H * w;
   const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  float loss_m = 0.f, loss_d = 0.f, cnt = 0.f, zero = 0.f;
+  float loss_m = 0.f, loss_d = 0.f, cnt = 0.f, bad = 0.f;
   if (tid < total) {
     const int x = (int)(tid % w);
     const int Y = (int)((tid / w) % H);
@@ -107,7 +107,11 @@ __global__ __launch_bounds__(kThreads) void ce_rows_kernel(const float *__restri
         if (wt == 0.f && !own) continue;
         if (tx.i0 != x && tx.i0 != x - 1) continue;      // only taps {x-1, x} -> x or {x, x+1} reach column x
         const int64_t t = trow[X];
-        if (t == (int64_t)ignore_index || t < 0 || t >= C) continue;
+        if (t == (int64_t)ignore_index) continue;
+        if (t < 0 || t >= C) {               // F.cross_entropy asserts on such a label; here it poisons the loss (NaN)
+          if (own && head == 0) bad += 1.f;
+          continue;
+        }
         if (own && head == 0) cnt += 1.f;
         const bool left = tx.i0 == x - 1 && x > 0;       // taps (x-1, x); otherwise (x, x+1) [or (x, x) at the border]
         const bool same = tx.i1 == tx.i0;
@@ -148,11 +152,13 @@ __global__ __launch_bounds__(kThreads) void ce_rows_kernel(const float *__restri
     }
   }
   block_sum2(loss_m, loss_d, red);
-  block_sum2(cnt, zero, red2);
+  block_sum2(cnt, bad, red2);
   if (threadIdx.x == 0) {
     part[(int64_t)blockIdx.x * 3 + 0] = loss_m;
     part[(int64_t)blockIdx.x * 3 + 1] = loss_d;
-    part[(int64_t)blockIdx.x * 3 + 2] = cnt;
+    // a label outside [0, C) that is not ignore_index (raw Cityscapes ids, a mis-mapped label file) must not shrink the
+    // valid set silently: the valid count becomes NaN, and with it the loss and every gradient of this call
+    part[(int64_t)blockIdx.x * 3 + 2] = bad > 0.f ? __builtin_nanf("") : cnt;
   }
 }
 

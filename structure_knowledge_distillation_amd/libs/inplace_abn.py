@@ -186,17 +186,40 @@ class _Geom:
                       _lib.ptr(dweight), _lib.ptr(dbias), eps, st), "skd_abn_relu_backward_dx")
 
 
+def _replica_weights(group):
+    from ..utils import parallel
+    w = parallel.replica_weights()
+    if w is not None and w.numel() == _group_size(group):
+        return w
+    return None
+
+
 def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib, st):
-    """Cross-replica statistics (libs/functions.py:185-209): all_gather [mean, var], the reference combine rule,
-    running-stat update with n = count * replicas.  Returns contiguous (mean, var)."""
+    """Cross-replica statistics (libs/functions.py:185-209): all_gather [mean, var], the reference combine rule
+    (pooled with the per-rank sample weights when utils.parallel.set_replica_batch announced them), running-stat
+    update with the pooled n.  Returns contiguous (mean, var)."""
     g = _group_size(group)
     gathered = stat.new_empty((g, 2, c))
     dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=group)
     out = stat.new_empty((2, c))
-    _lib.check(lib.skd_abn_combine_stats(g, c, gathered.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                         _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
-                                         float(count * g), st), "skd_abn_combine_stats")
+    w = _replica_weights(group)
+    _lib.check(lib.skd_abn_combine_stats(g, c, gathered.data_ptr(), _lib.ptr(w), dist.get_rank(group) if w is not None else 0,
+                                         out[0].data_ptr(), out[1].data_ptr(), _lib.ptr(running_mean),
+                                         _lib.ptr(running_var), float(momentum),
+                                         float(count) if w is not None else float(count * g), st), "skd_abn_combine_stats")
     return out[0], out[1]
+
+
+def _sync_grad_stats(stat, group):
+    """libs/functions.py:271-272: [edz, eydz] are averaged over the replicas -- weighted by the per-rank sample
+    counts when they are known (the pooled expectation), plain mean otherwise."""
+    w = _replica_weights(group)
+    if w is not None:
+        stat.mul_(w[dist.get_rank(group)])
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+        stat.div_(_group_size(group))
 
 
 class _InPlaceABN(autograd.Function):
@@ -275,8 +298,7 @@ class _InPlaceABN(autograd.Function):
             ws = geo.workspace(lib, z)
             geo.backward_reduce(lib, z, dz, weight, bias, edz, eydz, ctx.eps, ctx.act, ctx.slope, ws, st)
             if ctx.group is not None:
-                dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)   # libs/functions.py:271-272
-                stat.div_(_group_size(ctx.group))
+                _sync_grad_stats(stat, ctx.group)
         if dx is None and geo.nhwc:
             dx = torch.empty_like(z)        # the channels-last dx entry always writes dx
         geo.backward_dx(lib, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, ctx.eps, ctx.act, ctx.slope, st)
@@ -346,10 +368,28 @@ class _ABNRelu(autograd.Function):
         ws = geo.workspace(lib, x)
         geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st)
         if ctx.group is not None:
-            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=ctx.group)   # libs/functions.py:271-272
-            stat.div_(_group_size(ctx.group))
+            _sync_grad_stats(stat, ctx.group)
         geo.relu_backward_dx(lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, ctx.eps, st)
         return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
+
+
+def _nhwc_unsupported(x):
+    """Channels-last tensor whose channel count the channels-last kernels do not take (power of two in [4, 1024])."""
+    if not _is_nhwc(x):
+        return False
+    c = x.shape[1]
+    return c < 4 or c > 1024 or bool(c & (c - 1))
+
+
+def _via_nchw(fn, x, *rest, residual=None):
+    """Run ``fn`` on an NCHW copy and hand the result back channels-last.  The reference accepts any channel count
+    (libs/functions.py:70-162); the channels-last kernels do not, so odd widths (and the teacher's 2048-channel layers
+    when somebody trains or differentiates it) take the NCHW kernels through two layout copies instead of failing.
+    Costs the in-place property for that call, nothing else."""
+    if residual is not None:
+        residual = residual.contiguous()
+    out = fn(x.contiguous(), *rest) if residual is None else fn(x.contiguous(), *rest, residual)
+    return out.contiguous(memory_format=torch.channels_last)
 
 
 def abn_relu_train(x, weight, bias, running_mean, running_var, residual=None, momentum=0.1, eps=1e-05, group=None,
@@ -362,6 +402,9 @@ def abn_relu_train(x, weight, bias, running_mean, running_var, residual=None, mo
         group = None
     elif group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = dist.group.WORLD
+    if _nhwc_unsupported(x):
+        return _via_nchw(lambda xc, r=None: _ABNRelu.apply(xc, weight, bias, running_mean, running_var, r, momentum, eps, group),
+                         x, residual=residual)
     return _ABNRelu.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, group)
 
 
@@ -385,6 +428,10 @@ def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activa
         raise ValueError("unknown activation %r" % (activation,))
     if x.numel() == 0:
         return x
+    if _is_nhwc(x) and x.shape[1] % 4 != 0:       # channels-last with an odd channel count: NCHW kernels on a copy
+        xc = abn_eval_fused(x.contiguous(), weight, bias, running_mean, running_var, eps, activation, slope,
+                            None if residual is None else residual.contiguous())
+        return x.copy_(xc)
     lib, st = _lib.get(), _lib.stream_of(x)
     if (x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
             and x.shape[1] % 4 == 0):
@@ -420,6 +467,9 @@ def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activa
 def inplace_abn(x, weight, bias, running_mean, running_var, training=True, momentum=0.1, eps=1e-05,
                 activation=ACT_LEAKY_RELU, slope=0.01):
     """Signature of libs/functions.py:70-73 (InPlaceABN.apply)."""
+    if _nhwc_unsupported(x):
+        return _via_nchw(lambda xc: _InPlaceABN.apply(xc, weight, bias, running_mean, running_var, training, momentum, eps,
+                                                      activation, slope, None), x)
     return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
                              activation, slope, None)
 
@@ -439,5 +489,8 @@ def inplace_abn_sync(x, weight, bias, running_mean, running_var, extra=None, tra
         group = extra
     if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = dist.group.WORLD
+    if _nhwc_unsupported(x):
+        return _via_nchw(lambda xc: _InPlaceABN.apply(xc, weight, bias, running_mean, running_var, training, momentum, eps,
+                                                      activation, slope, group), x)
     return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
                              activation, slope, group)

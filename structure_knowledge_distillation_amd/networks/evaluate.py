@@ -50,6 +50,11 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
     with torch.no_grad():
         for batch in loader:
             image, label, size = batch[0], batch[1], batch[2]
+            lab_np = np.asarray(label) if not torch.is_tensor(label) else label.numpy() if label.device.type == "cpu" else None
+            if lab_np is not None and bool(((lab_np != ignore_label) & ((lab_np < 0) | (lab_np >= num_classes))).any()):
+                # np.bincount of evaluate.py:188-198 would count such labels (and index out of the matrix); the fused
+                # kernel skips them -- refuse instead of scoring a quietly smaller set (raw label ids not mapped to trainIds?)
+                raise ValueError("label values outside [0, %d) other than ignore_label %d" % (num_classes, ignore_label))
             image = torch.as_tensor(np.asarray(image) if not torch.is_tensor(image) else image).float().to(device)
             label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).long().to(device)
             sz = np.asarray(size[0] if (torch.is_tensor(size) or isinstance(size, (list, tuple))) else size).reshape(-1)

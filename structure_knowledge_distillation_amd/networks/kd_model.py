@@ -51,16 +51,63 @@ def load_T_model(model, ckpt_path):
     return True
 
 
+def _strip_module(state_dict, with_module):
+    """Checkpoints written from an nn.DataParallel wrapper carry a 'module.' prefix (utils/utils.py:119-122, 141-145)."""
+    if with_module:
+        return state_dict
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
 def load_S_model(args, model, with_module=False):
-    """utils/utils.py:93-128: ImageNet ResNet18 weights by key intersection when available."""
-    path = getattr(args, "student_pretrain_model_imgnet", None)
-    if not getattr(args, "is_student_load_imgnet", False) or not path or not osp.isfile(str(path)):
-        logging.info("student: no ImageNet checkpoint, random initialisation")
+    """utils/utils.py:93-128.  Either the ImageNet ResNet18 weights by key intersection (``is_student_load_imgnet``), or --
+    ``S_resume`` -- the run's own ``<S_ckpt_path>/model_best.pth.tar``: a dict with 'state_dict' (+ optional 'step',
+    'epoch', 'best_mean_IU', 'IU_array') from which ``args.last_step / start_epoch / best_mean_IU`` are restored so
+    that train_and_eval.py:20-21 continues where it stopped.  Returns what was loaded: 'imagenet', 'resume' or False."""
+    ckpt_dir = getattr(args, "S_ckpt_path", None)
+    if ckpt_dir and not osp.exists(ckpt_dir) and not str(ckpt_dir).endswith((".pth", ".tar")):
+        os.makedirs(ckpt_dir, exist_ok=True)                                      # utils.py:95-96
+    if getattr(args, "is_student_load_imgnet", False):
+        path = getattr(args, "student_pretrain_model_imgnet", None)
+        if path and osp.isfile(str(path)):
+            saved = torch.load(path, map_location="cpu")
+            own = model.state_dict()
+            own.update({k: v for k, v in saved.items() if k in own and own[k].shape == v.shape})
+            model.load_state_dict(own)
+            logging.info("=> load %s", path)
+            return "imagenet"
+        logging.info("=> the pretrain model on imgnet %r does not exist", path)
         return False
-    saved = torch.load(path, map_location="cpu")
-    own = model.state_dict()
-    own.update({k: v for k, v in saved.items() if k in own and own[k].shape == v.shape})
-    model.load_state_dict(own)
+    if getattr(args, "S_resume", False) and ckpt_dir:
+        file = osp.join(str(ckpt_dir), "model_best.pth.tar")
+        if osp.isfile(file):
+            ckpt = torch.load(file, map_location="cpu")
+            args.last_step = ckpt.get("step")
+            args.start_epoch = ckpt.get("epoch")
+            args.best_mean_IU = ckpt.get("best_mean_IU")
+            model.load_state_dict(_strip_module(ckpt["state_dict"], with_module))
+            logging.info("=> loaded checkpoint %r (epoch:%s step:%s best_mean_IU:%s IU_array:%s)", file, args.start_epoch,
+                         args.last_step, args.best_mean_IU, ckpt.get("IU_array"))
+            return "resume"
+        logging.info("=> checkpoint %r does not exist: random initialisation", file)
+    return False
+
+
+def load_D_model(args, model, with_module=False):
+    """utils/utils.py:130-151: ``D_resume`` restores the discriminator (and start_epoch / best_mean_IU) from
+    ``<D_ckpt_path>/model_best.pth.tar``."""
+    ckpt_dir = getattr(args, "D_ckpt_path", None)
+    if not getattr(args, "D_resume", False) or not ckpt_dir:
+        return False
+    os.makedirs(ckpt_dir, exist_ok=True)
+    file = osp.join(str(ckpt_dir), "model_best.pth.tar")
+    if not osp.isfile(file):
+        logging.info("=> checkpoint %r does not exist: random initialisation", file)
+        return False
+    ckpt = torch.load(file, map_location="cpu")
+    args.start_epoch = ckpt["epoch"]
+    args.best_mean_IU = ckpt["best_mean_IU"]
+    model.load_state_dict(_strip_module(ckpt["state_dict"], with_module))
+    logging.info("=> loaded checkpoint %r (epoch %s)", file, ckpt["epoch"])
     return True
 
 
@@ -122,6 +169,7 @@ class NetModel():
 
         D_model = Discriminator(args.preprocess_GAN_mode, args.classes_num, args.batch_size,
                                 args.imsize_for_adv, args.adv_conv_dim)
+        load_D_model(args, D_model, False)
         print_model_parm_nums(D_model, "D_model")
         self.parallel_D = self.DataParallelModelProcess(D_model, 2, "train", device)
         self.D_model = D_model
@@ -158,6 +206,9 @@ class NetModel():
         # MIOpen find mode is opt-in: this ROCm image ships no gfx950 find/kernel database, so "find"
         # JIT-compiles every candidate solver for every convolution shape on a fresh machine.
         torch.backends.cudnn.benchmark = os.environ.get("SKD_MIOPEN_FIND", "0") == "1"
+        if not torch.backends.cudnn.benchmark:
+            from .. import check_miopen_db
+            check_miopen_db()        # warns when the shipped find-db does not belong to the running MIOpen build
         snap = getattr(args, "snapshot_dir", None)
         if snap and not os.path.exists(snap):
             os.makedirs(snap)
@@ -182,6 +233,7 @@ class NetModel():
         dev = self.args.device
         self.images = images.to(dev, non_blocking=True)
         self.labels = labels.long().to(dev, non_blocking=True)
+        parallel_old.set_replica_batch(self.images.shape[0], self.images.device)   # InPlaceABNSync pools by sample count
 
     def lr_poly(self, base_lr, iter, max_iter, power):
         return base_lr * ((1 - float(iter) / max_iter) ** (power))
@@ -282,10 +334,18 @@ class NetModel():
             self.discriminator_backward()
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
+        """networks/evaluate.py via kd_model.py:178-181.  One process per GPU: rank 0 evaluates (the replicas are
+        identical), the others wait at the barrier and receive the result -- the reference's single process evaluated
+        once, eight ranks must not each walk the validation set and race on the checkpoint file."""
         from .evaluate import evaluate_main
-        mean_IU, IU_array = evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
-                                          num_classes=num_classes, whole=whole)
-        return mean_IU, IU_array
+        world = parallel_old.world_size()
+        result = [None, None]
+        if parallel_old.rank() == 0:
+            result = list(evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
+                                        num_classes=num_classes, whole=whole))
+        if world > 1:
+            torch.distributed.broadcast_object_list(result, src=0)
+        return result[0], result[1]
 
     def print_info(self, epoch, step):
         logging.info("step:{:5d} G_lr:{:.6f} G_loss:{:.5f}(mc:{:.5f} pixelwise:{:.5f} pairwise:{:.5f}) "
@@ -294,8 +354,13 @@ class NetModel():
                          self.pi_G_loss, self.pa_G_loss, self.D_solver.param_groups[-1]["lr"], self.D_loss))
 
     def save_ckpt(self, epoch, step, mean_IU, IU_array):
-        torch.save(self.student.state_dict(),
-                   osp.join(self.args.snapshot_dir, "CS_scenes_" + str(step) + "_" + str(mean_IU) + ".pth"))
+        """kd_model.py:192-193; written by rank 0 only (every rank holds the same weights), then a barrier so nobody
+        races ahead into a step while the file is incomplete."""
+        if parallel_old.rank() == 0:
+            torch.save(self.student.state_dict(),
+                       osp.join(self.args.snapshot_dir, "CS_scenes_" + str(step) + "_" + str(mean_IU) + ".pth"))
+        if parallel_old.world_size() > 1:
+            torch.distributed.barrier()
 
 
 def default_args(**overrides):
@@ -308,6 +373,7 @@ def default_args(**overrides):
         lambda_d=0.1, lambda_gp=10.0, pool_scale=0.5, adv_loss_type="wgan-gp", imsize_for_adv=65,
         adv_conv_dim=64, preprocess_GAN_mode=1, parallel="True", gpu="0", gpu_num=1, best_mean_IU=0.0,
         T_ckpt_path=None, is_student_load_imgnet=False, student_pretrain_model_imgnet=None,
+        S_resume=True, S_ckpt_path=None, D_resume=True, D_ckpt_path=None, last_step=0, start_epoch=0,
         snapshot_dir=None, device=torch.device("cuda" if torch.cuda.is_available() else "cpu"))
     for k, v in overrides.items():
         setattr(a, k, v)

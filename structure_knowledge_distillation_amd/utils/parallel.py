@@ -23,7 +23,8 @@ import torch.distributed as dist
 import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
-           "init_distributed", "world_size", "rank", "broadcast_module"]
+           "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
+           "replica_weights"]
 
 
 def init_distributed(backend=None):
@@ -54,6 +55,40 @@ def world_size(group=None):
 
 def rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def per_rank_batch(global_batch, group=None):
+    """The reference's ``--batch-size`` is the GLOBAL minibatch: nn.DataParallel scatters it over the GPUs
+    (utils/parallel.py:54-64) and lr_g / lr_d are tuned for it.  With one process per GPU every rank's loader must
+    therefore deliver ``batch_size // world_size`` samples (``DistributedSampler(..., drop_last=True)``); use this
+    helper so a world size that does not divide the batch is an error instead of a silently different recipe."""
+    w = world_size(group)
+    if global_batch % w:
+        raise ValueError("global batch %d is not divisible by the %d replicas" % (global_batch, w))
+    return global_batch // w
+
+
+_REPLICA = {"weights": None, "key": None}
+
+
+def set_replica_batch(local_batch, device, group=None):
+    """Tell InPlaceABNSync how many samples THIS rank holds in the current step.  The reference's combine rule
+    (libs/functions.py:196-197) silently assumes equal shards; here the per-rank counts are all-gathered (one tiny
+    collective per step, no host sync) and the statistics are pooled with weights n_g / sum(n) -- identical to the
+    reference when the shards are equal, exact when a loader hands out a short last batch."""
+    if world_size(group) <= 1:
+        _REPLICA["weights"] = None
+        return None
+    mine = torch.tensor([float(local_batch)], device=device)
+    counts = torch.empty(world_size(group), device=device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    _REPLICA["weights"] = counts / counts.sum()
+    return _REPLICA["weights"]
+
+
+def replica_weights():
+    """(G,) device tensor of n_g / sum(n) set by ``set_replica_batch`` for this step, or None (equal shards)."""
+    return _REPLICA["weights"]
 
 
 def broadcast_module(module, src=0, group=None):

@@ -89,3 +89,41 @@ def test_default_args_mirror_train_options():
                 adv_loss_type="wgan-gp", imsize_for_adv=65, adv_conv_dim=64, preprocess_GAN_mode=1, parallel="True")
     for k, v in want.items():
         assert getattr(a, k) == v, k
+
+
+def test_student_and_discriminator_resume_round_trip(tmp_path):
+    """utils/utils.py:105-151: S_resume / D_resume load <ckpt dir>/model_best.pth.tar -- a dict with 'state_dict' whose
+    keys carry the nn.DataParallel 'module.' prefix when with_module is False -- and restore the counters that
+    train_and_eval.py:20-21 resumes from.  A restarted run must NOT silently start from step 0."""
+    student = PC.Res_pspnet(PC.BasicBlock, [2, 2, 2, 2], 19)
+    sdir, ddir = os.path.join(tmp_path, "Student"), os.path.join(tmp_path, "Distriminator")
+    os.makedirs(sdir)
+    os.makedirs(ddir)
+    saved = {"module." + k: v + 0.25 for k, v in student.state_dict().items()}
+    torch.save({"state_dict": saved, "step": 1234, "epoch": 3, "best_mean_IU": 0.61, "IU_array": [0.5] * 19},
+               os.path.join(sdir, "model_best.pth.tar"))
+    d = sagan_models.Discriminator(1, 19, 8, 65, 64)
+    torch.save({"state_dict": {"module." + k: v * 0 + 0.5 for k, v in d.state_dict().items()}, "epoch": 4, "best_mean_IU": 0.7},
+               os.path.join(ddir, "model_best.pth.tar"))
+    args = kd_model.default_args(S_ckpt_path=sdir, D_ckpt_path=ddir, device=torch.device("cpu"))
+    assert args.S_resume and args.D_resume                                          # train_options.py:23,25 defaults
+    fresh = PC.Res_pspnet(PC.BasicBlock, [2, 2, 2, 2], 19)
+    want = {k: v + 0.25 for k, v in student.state_dict().items()}
+    assert kd_model.load_S_model(args, fresh, False) == "resume"
+    assert (args.last_step, args.start_epoch, args.best_mean_IU) == (1234, 3, 0.61)
+    assert all(torch.equal(fresh.state_dict()[k], want[k]) for k in want)
+    d2 = sagan_models.Discriminator(1, 19, 8, 65, 64)
+    assert kd_model.load_D_model(args, d2, False)
+    assert (args.start_epoch, args.best_mean_IU) == (4, 0.7)
+    assert all(bool((v == 0.5).all()) for k, v in d2.state_dict().items() if v.is_floating_point())
+    # with_module=True takes the keys as they are (utils.py:121-122)
+    torch.save({"state_dict": student.state_dict()}, os.path.join(sdir, "model_best.pth.tar"))
+    assert kd_model.load_S_model(args, fresh, True) == "resume" and args.last_step is None
+    # nothing to resume from: says so, loads nothing, keeps the counters
+    empty = kd_model.default_args(S_ckpt_path=os.path.join(tmp_path, "none"), D_ckpt_path=os.path.join(tmp_path, "noneD"),
+                                  device=torch.device("cpu"), last_step=7)
+    assert kd_model.load_S_model(empty, fresh, False) is False and empty.last_step == 7
+    assert kd_model.load_D_model(empty, d2, False) is False
+    # the ImageNet branch wins over S_resume, as in the reference (utils.py:97 vs 105)
+    args.is_student_load_imgnet, args.student_pretrain_model_imgnet = True, os.path.join(tmp_path, "missing.pth")
+    assert kd_model.load_S_model(args, fresh, False) is False

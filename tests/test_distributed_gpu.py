@@ -114,3 +114,26 @@ def test_netmodel_step_replicas_stay_identical():
     for k in outs[0]["after"]:
         assert torch.equal(outs[0]["after"][k], outs[1]["after"][k]), "replicas diverged: %s" % k
     assert outs[0]["losses"] != outs[1]["losses"]      # different shards, different local losses
+
+
+def test_bench_under_torchrun_two_ranks_over_gloo():
+    """The exact command line the driver uses for its multi-GPU runs (python -m torch.distributed.run ... bench.py
+    --gpus N), with two ranks sharing cuda:0 over gloo (SKD_DIST_BACKEND): rendezvous, replica broadcast, SyncABN
+    collectives in every training BN, bucketed gradient all-reduce from the backward hooks, barrier + max-over-ranks
+    timing and the single JSON line from rank 0 are all exercised end to end."""
+    import json
+    import subprocess
+    env = dict(os.environ, SKD_DIST_BACKEND="gloo", MIOPEN_LOG_LEVEL="3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 4 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
+    for k, v in out["config"]["losses_last_step"].items():
+        assert v == v and abs(v) < 1e6, (k, v)          # finite

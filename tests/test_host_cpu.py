@@ -2,6 +2,7 @@
 NetModel step are run with oracle/libskd_ref.so installed as the C-ABI double (same entry points,
 host pointers) and compared with the torch oracle.  No compute goes through libskd_hip.so here."""
 import argparse
+import os
 
 import pytest
 import torch
@@ -338,3 +339,26 @@ def test_evaluate_main_whole_image_miou():
     assert np.allclose(iu, want_iu) and abs(mean_iu - want_mean) < 1e-12
     with pytest.raises(NotImplementedError):
         E.evaluate_main(net, batches, "0", "512,512", 7, whole=False)
+
+
+def test_miopen_db_is_private_writable_copy_and_version_guard(tmp_path, monkeypatch):
+    """The shipped find-db is never handed to MIOpen directly (it appends to its user db): a per-user / per-rank copy
+    is; and a MIOpen build other than the one the db was tuned on is reported loudly instead of silently running
+    untuned kernels."""
+    import importlib
+    import warnings
+    import structure_knowledge_distillation_amd as S
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("MIOPEN_CUSTOM_CACHE_DIR", raising=False)
+    monkeypatch.setenv("SKD_MIOPEN_CACHE", str(tmp_path))
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    S = importlib.reload(S)
+    dst = os.environ["MIOPEN_USER_DB_PATH"]
+    assert dst.startswith(str(tmp_path)) and dst.endswith("_r3") and os.path.isdir(os.path.join(dst, "cache"))
+    assert sorted(os.listdir(dst)) == sorted(os.listdir(S.MIOPEN_DB_DIR))
+    assert S.MIOPEN_DB_VERSION == (3, 5, 0) and S.check_miopen_db() is True
+    monkeypatch.setattr(S, "MIOPEN_DB_VERSION", (9, 9, 9))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert S.check_miopen_db() is False
+    assert any("find-db" in str(x.message) for x in w)

@@ -344,14 +344,29 @@ def test_abn_combine_stats(hip, ref, G, C):
     gathered = torch.cat([torch.randn(G, 1, C, generator=g), torch.rand(G, 1, C, generator=g) + 0.1], 1).contiguous()
     rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
     mr, vr, rmr, rvr = torch.empty(C), torch.empty(C), rm.clone(), rv.clone()
-    assert ref.skd_abn_combine_stats(G, C, P(gathered), P(mr), P(vr), P(rmr), P(rvr), 0.1, float(4225 * 8 * G), None)
+    assert ref.skd_abn_combine_stats(G, C, P(gathered), None, 0, P(mr), P(vr), P(rmr), P(rvr), 0.1, float(4225 * 8 * G), None)
     mg, vg, rmg, rvg = torch.empty(C, device=DEV), torch.empty(C, device=DEV), gpu(rm), gpu(rv)
-    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(mg), P(vg), P(rmg), P(rvg), 0.1, float(4225 * 8 * G), None)
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), None, 0, P(mg), P(vg), P(rmg), P(rvg), 0.1, float(4225 * 8 * G), None)
     close(mg, mr, 1e-6, "mean"); close(vg, vr, 1e-6, "var"); close(rmg, rmr, 1e-6, "running_mean"); close(rvg, rvr, 1e-6, "running_var")
     want_m = gathered[:, 0].double().mean(0)
     want_v = (gathered[:, 1].double() + (want_m - gathered[:, 0].double()) ** 2).mean(0)
     close(mg, want_m.float(), 1e-6, "mean vs formula"); close(vg, want_v.float(), 1e-6, "var vs formula")
-    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(mg), P(vg), None, None, 0.1, 100.0, None)   # no running buffers
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), None, 0, P(mg), P(vg), None, None, 0.1, 100.0, None)   # no running buffers
+    # unequal shards: weights w_g = n_g / sum(n) give the pooled statistics of the concatenated data exactly
+    counts = torch.arange(1, G + 1, dtype=torch.float64) * 7
+    xs = [torch.randn(int(n), C, generator=g, dtype=torch.float64) * (1 + i) + i for i, n in enumerate(counts)]
+    gathered = torch.stack([torch.stack([x.mean(0), x.var(0, unbiased=False)]) for x in xs]).float().contiguous()
+    w = (counts / counts.sum()).float()
+    allx = torch.cat(xs)
+    rank = G - 1
+    rmg, rvg, rmr, rvr = gpu(rm), gpu(rv), rm.clone(), rv.clone()
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(gpu(w)), rank, P(mg), P(vg), P(rmg), P(rvg), 0.1, float(counts[rank]), None)
+    assert ref.skd_abn_combine_stats(G, C, P(gathered), P(w), rank, P(mr), P(vr), P(rmr), P(rvr), 0.1, float(counts[rank]), None)
+    close(mg, allx.mean(0).float(), 2e-6, "pooled mean", floor=1.0); close(vg, allx.var(0, unbiased=False).float(), 5e-6, "pooled var")
+    close(mg, mr, 1e-6, "weighted mean vs oracle"); close(vg, vr, 1e-6, "weighted var vs oracle"); close(rvg, rvr, 1e-6, "weighted running_var")
+    n_tot = float(counts.sum())
+    close(rvg, (rv * 0.9 + 0.1 * allx.var(0, unbiased=False).float() * n_tot / (n_tot - 1)), 1e-5, "running_var with the pooled count")
+    assert hip.skd_abn_combine_stats(G, C, P(gpu(gathered)), P(gpu(w)), G, P(mg), P(vg), None, None, 0.1, 1.0, None) == 0       # rank out of range
 
 
 def test_abn_reference_corner_semantics(hip, ref):
@@ -568,6 +583,14 @@ def test_ce_dsn(hip, ref, geom):
     y255 = torch.full((B, H, W), 255, dtype=torch.int64, device=DEV)
     assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), P(gpu(ld)), P(y255), 255, 0.4, P(lg2), None, None, P(ws), None)
     assert float(lg2) != float(lg2)
+    # a label outside [0, C) that is not ignore_index (F.cross_entropy asserts on it): never a silently smaller valid
+    # set -- the loss and both gradients of the call come back NaN
+    ybad = yg.clone()
+    ybad[0, H - 1, W // 2] = C + 3
+    assert hip.skd_ce_dsn_forward(B, C, h, w, H, W, P(gpu(lm)), P(gpu(ld)), P(ybad), 255, 0.4, P(lg2), P(gmg), P(gdg), P(ws), None)
+    assert float(lg2) != float(lg2) and bool(torch.isnan(gmg).all()) and bool(torch.isnan(gdg).all())
+    assert ref.skd_ce_dsn_forward(B, C, h, w, H, W, P(lm), P(ld), P(ybad.cpu()), 255, 0.4, P(lr), P(gmr), P(gdr), P(torch.empty(8)), None)
+    assert float(lr) != float(lr)
 
 
 @pytest.mark.parametrize("geom", [(8, 512, 65, 65, 128), (2, 2048, 65, 65, 512), (2, 7, 33, 33, 5), (3, 4, 46, 61, 3), (1, 2, 7, 9, 2), (1, 1, 129, 129, 1)])

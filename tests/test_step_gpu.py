@@ -466,3 +466,34 @@ def test_step_config1_pi_only():
     model, gS, o64, o32, P64, P32 = _config1_step(pa=False)
     assert model.pa_G_loss == 0.0
     _check_vs_live_oracle(model, gS, o64, o32, P64, P32, "config1 Pi only")
+
+
+@pytest.mark.parametrize("C", [48, 2048, 6])
+def test_channels_last_abn_any_channel_count(C):
+    """The reference takes any channel count; the channels-last kernels take powers of two in [4, 1024].  Other widths
+    (and 2048, the teacher's widest layer, when it is trained or differentiated) go through the NCHW kernels on a copy
+    instead of raising: same numbers as the NCHW path, result handed back channels-last."""
+    torch.manual_seed(C)
+    x = torch.randn(2, C, 9, 7, device=DEV) * 2 + 1
+    r = torch.randn(2, C, 9, 7, device=DEV)
+    g = torch.randn(2, C, 9, 7, device=DEV)
+    outs = []
+    for nhwc in (False, True):
+        mod = libs.InPlaceABNSync(C, activation="none").to(DEV).train()
+        with torch.no_grad():
+            mod.weight.copy_(torch.linspace(0.5, 1.5, C))
+            mod.bias.copy_(torch.linspace(-1, 1, C))
+        xi = x.clone().requires_grad_(True)
+        ri = r.clone().requires_grad_(True)
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        y = mod.forward_relu((xi * 1.0).contiguous(memory_format=fmt), ri.contiguous(memory_format=fmt))
+        if nhwc:
+            assert y.is_contiguous(memory_format=torch.channels_last)
+        (y * g).sum().backward()
+        z = mod((xi.detach() * 1.0).contiguous(memory_format=fmt))              # the in-place leaky / none form
+        mod.eval()
+        with torch.no_grad():
+            e = mod.forward_relu((x * 1.0).contiguous(memory_format=fmt))
+        outs.append((y.detach(), xi.grad, ri.grad, mod.weight.grad, mod.bias.grad, z.detach(), e, mod.running_var.clone()))
+    for a, b in zip(*outs):
+        assert rel(a, b) < 1e-5
