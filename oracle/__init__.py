@@ -15,9 +15,11 @@ Parity pinning: the reference ships no tests, golden vectors or fixtures
 reference's own Python (``oracle/ref_import.py``, only possible in the build
 container where /root/reference exists) on seeded inputs and committing the
 results under ``tests/golden/`` (generator: ``tests/golden/make_golden.py``).
-The native InPlace-ABN kernels (libs/src/bn.cu) cannot be built or run here
-(CUDA + THC + torch.utils.ffi), so for those four kernels the pin is the
-formula-level restatement in ``oracle/abn_ref.c`` checked against plain
-autograd of the same closed form: **parity unpinned by any reference-run
-output** for bn.cu itself.
+The native InPlace-ABN kernels (libs/src/bn.cu + common.h + bn.h) are pinned by RUNNING them: their own build
+(nvcc + THC + torch.utils.ffi) is impossible here, but the three source files are self-contained CUDA-runtime code
+that hipcc compiles for gfx950 once the runtime-API names are respelled (``oracle/build_ref.py``: the substitution
+table is the whole recipe; nothing of the reference is copied into the repository).  The result,
+``oracle/_ref/libbn_ref.so`` (git-ignored, built by ``__graft_entry__.build()`` where /root/reference exists, shipped
+to the GPU box), is compared three ways -- reference kernels vs ``oracle/abn_ref.c`` vs ``libskd_hip.so`` -- by
+``tests/test_ref_kernels_gpu.py`` on the nine entry points of libs/src/bn.h.
 """
