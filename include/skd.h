@@ -282,6 +282,22 @@ int skd_ppm_concat(int B, int Cout, int Cfeat, int H, int W, int nsizes, const i
                    const float *const *priors, const float *feats, float *cat, skd_stream_t stream);
 int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
                             const float *gcat, float *const *gpriors, skd_stream_t stream);
+/* Channels-last (NHWC) forms of the four entries above, for networks whose activations are kept channels-last
+ * (no NCHW <-> NHWC copies around the pyramid module).  Layouts: feats / dx / gfeats (B, H, W, C); pooled level k
+ * (B, s_k, s_k, C) at floats [B * C * sum_{j<k} s_j^2, ...) of one buffer; prior_k / gprior_k (B, s_k, s_k, Cout);
+ * cat / gcat (B, H, W, L*Cout + Cfeat).  C, Cout, Cfeat multiples of 4.  workspace: skd_ppm_nhwc_workspace_floats()
+ * floats (pass C = 0 or Cout = 0 for the entry that is not used).  concat_backward writes the feature-map slice of
+ * gcat to `gfeats` as a contiguous tensor (NULL: skip) and the prior gradients to gpriors (NULL: skip). */
+int64_t skd_ppm_nhwc_workspace_floats(int B, int C, int Cout, int H, int W, int nsizes, const int *sizes);
+int skd_ppm_pool_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *x, float *pooled,
+                      float *workspace, skd_stream_t stream);
+int skd_ppm_pool_backward_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *gpooled,
+                               float *dx, skd_stream_t stream);
+int skd_ppm_concat_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                        const float *const *priors, const float *feats, float *cat, skd_stream_t stream);
+int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes,
+                                 const float *gcat, float *const *gpriors, float *gfeats, float *workspace,
+                                 skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 9. Whole-image evaluation tail, networks/evaluate.py:106-113, 186-206:

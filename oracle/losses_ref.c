@@ -443,6 +443,106 @@ int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes
   return 1;
 }
 
+/* ---- channels-last forms of the pyramid entries: layout conversion around the NCHW restatements above ---- */
+static float *nhwc_to_nchw(int B, int C, int H, int W, const float *x) {      /* (B,H,W,C) -> new (B,C,H,W) */
+  float *p = (float *)malloc(sizeof(float) * (size_t)B * C * H * W + 4);
+  if (p && x)
+    for (int b = 0; b < B; ++b)
+      for (int64_t e = 0; e < (int64_t)H * W; ++e)
+        for (int c = 0; c < C; ++c) p[((int64_t)b * C + c) * H * W + e] = x[(((int64_t)b * H * W) + e) * C + c];
+  return p;
+}
+static void nchw_to_nhwc(int B, int C, int H, int W, const float *p, float *x) {
+  for (int b = 0; b < B; ++b)
+    for (int64_t e = 0; e < (int64_t)H * W; ++e)
+      for (int c = 0; c < C; ++c) x[(((int64_t)b * H * W) + e) * C + c] = p[((int64_t)b * C + c) * H * W + e];
+}
+
+int64_t skd_ppm_nhwc_workspace_floats(int B, int C, int Cout, int H, int W, int nsizes, const int *sizes) {
+  (void)C; (void)Cout; (void)H; (void)W;
+  return (B > 0 && nsizes > 0 && nsizes <= 4 && sizes) ? 1 : 0;
+}
+
+int skd_ppm_pool_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *x, float *pooled, float *ws,
+                      stream_t st) {
+  (void)ws;
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || !x || !pooled || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  float *px = nhwc_to_nchw(B, C, H, W, x);
+  float *pp = (float *)malloc(sizeof(float) * (size_t)skd_ppm_pooled_floats(B * C, nsizes, sizes));
+  int r = (px && pp) ? skd_ppm_pool(B * C, H, W, nsizes, sizes, px, pp, st) : 0;
+  int64_t off = 0;
+  for (int k = 0; r && k < nsizes; ++k) {
+    const int s = sizes[k];
+    nchw_to_nhwc(B, C, s, s, pp + off, pooled + off);
+    off += (int64_t)B * C * s * s;
+  }
+  free(px); free(pp);
+  return r;
+}
+
+int skd_ppm_pool_backward_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *g, float *dx, stream_t st) {
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || !g || !dx || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  float *pg = (float *)malloc(sizeof(float) * (size_t)skd_ppm_pooled_floats(B * C, nsizes, sizes));
+  float *pd = (float *)malloc(sizeof(float) * (size_t)B * C * H * W);
+  if (!pg || !pd) { free(pg); free(pd); return 0; }
+  int64_t off = 0;
+  for (int k = 0; k < nsizes; ++k) {
+    const int s = sizes[k];
+    float *t = nhwc_to_nchw(B, C, s, s, g + off);
+    if (!t) { free(pg); free(pd); return 0; }
+    memcpy(pg + off, t, sizeof(float) * (size_t)B * C * s * s);
+    free(t);
+    off += (int64_t)B * C * s * s;
+  }
+  const int r = skd_ppm_pool_backward(B * C, H, W, nsizes, sizes, pg, pd, st);
+  if (r) nchw_to_nhwc(B, C, H, W, pd, dx);
+  free(pg); free(pd);
+  return r;
+}
+
+int skd_ppm_concat_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes, const float *const *priors,
+                        const float *feats, float *cat, stream_t st) {
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || Cfeat < 0 || (Cfeat & 3) || H <= 0 || W <= 0 || !priors || !cat) return 0;
+  if (nsizes <= 0 || nsizes > 4 || !sizes || (Cfeat > 0 && !feats)) return 0;
+  const float *pp[4] = {0, 0, 0, 0};
+  float *own[4] = {0, 0, 0, 0};
+  for (int k = 0; k < nsizes; ++k) {
+    if (!priors[k]) return 0;
+    own[k] = nhwc_to_nchw(B, Cout, sizes[k], sizes[k], priors[k]);
+    pp[k] = own[k];
+  }
+  const int Ctot = nsizes * Cout + Cfeat;
+  float *pf = Cfeat > 0 ? nhwc_to_nchw(B, Cfeat, H, W, feats) : NULL;
+  float *pc = (float *)malloc(sizeof(float) * (size_t)B * Ctot * H * W);
+  const int r = pc ? skd_ppm_concat(B, Cout, Cfeat, H, W, nsizes, sizes, pp, pf, pc, st) : 0;
+  if (r) nchw_to_nhwc(B, Ctot, H, W, pc, cat);
+  for (int k = 0; k < 4; ++k) free(own[k]);
+  free(pf); free(pc);
+  return r;
+}
+
+int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes, const float *gcat,
+                                 float *const *gpriors, float *gfeats, float *ws, stream_t st) {
+  (void)ws;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || Cfeat < 0 || (Cfeat & 3) || H <= 0 || W <= 0 || !gcat) return 0;
+  if (nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  const int Ctot = nsizes * Cout + Cfeat;
+  if (gfeats && Cfeat > 0)
+    for (int64_t e = 0; e < (int64_t)B * H * W; ++e)
+      memcpy(gfeats + e * Cfeat, gcat + e * Ctot + nsizes * Cout, sizeof(float) * (size_t)Cfeat);
+  if (!gpriors) return 1;
+  float *pc = nhwc_to_nchw(B, Ctot, H, W, gcat);
+  float *own[4] = {0, 0, 0, 0};
+  for (int k = 0; k < nsizes; ++k) own[k] = (float *)malloc(sizeof(float) * (size_t)B * Cout * sizes[k] * sizes[k]);
+  const int r = pc ? skd_ppm_concat_backward(B, Cout, Cfeat, H, W, nsizes, sizes, pc, own, st) : 0;
+  for (int k = 0; k < nsizes; ++k) {
+    if (r && gpriors[k]) nchw_to_nhwc(B, Cout, sizes[k], sizes[k], own[k], gpriors[k]);
+    free(own[k]);
+  }
+  free(pc);
+  return r;
+}
+
 /* ---- evaluation tail: upsample + argmax + confusion matrix, networks/evaluate.py:106-113, 136-154, 186-198 ---- */
 int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *logits, const int64_t *target,
                       int ignore_index, uint8_t *pred, int64_t *confusion, stream_t st) {

@@ -247,6 +247,272 @@ __global__ __launch_bounds__(kThreads) void ppm_concat_bwd_kernel(const float *_
   }
 }
 
+
+// =============================================================================================
+// Channels-last (NHWC) forms.  Both networks keep their activations channels-last (MIOpen's fp32 kernels on gfx950
+// are NHWC-native); with only the NCHW kernels above the pyramid module cost four layout copies per network and step
+// (feature map -> NCHW, concatenated tensor -> NHWC, and the same for the gradients: 277 + 554 MB for the teacher
+// alone, ~1.5 ms per step).  Layouts: feats (B, H, W, C); pooled level k (B, s, s, C); priors (B, s, s, Cout);
+// cat (B, H, W, L*Cout + Cfeat); every channel count a multiple of 4 (a thread moves channel quads).
+//   pool      the bin edges of all levels cut each axis into <= kMaxCuts segments inside which the set of covering
+//             bins is constant; ONE read of the feature map produces the (segment x segment) cell sums
+//             (ppm_cells_nhwc), a tiny second kernel adds the cells of every bin (ppm_bins_nhwc).
+//   pool_bwd  per pixel: <= 2 x 2 covering bins per level, looked up from per-coordinate tables in LDS.
+//   concat    per pixel and channel quad: four-tap bilinear from the (L2-resident) priors, or a copy of feats.
+//   concat_bwd  separable pull-back: row pass (reduce over X, fused with the contiguous copy of the feature-map
+//             slice of the gradient) -> column pass (reduce over Y).  No atomics anywhere.
+// =============================================================================================
+constexpr int kMaxCuts = 40;   // 2 * sum(sizes) + 1 for sizes (1, 2, 3, 6) is 25
+
+struct Cuts {
+  int ny, nx;                  // number of segments per axis
+  int y[kMaxCuts], x[kMaxCuts];
+};
+
+static bool make_cuts(int H, int W, const Levels &lv, Cuts &c) {
+  auto build = [&](int n, int *out, int &cnt) {
+    bool mark[4096];
+    if (n + 1 > 4096) return false;
+    for (int i = 0; i <= n; ++i) mark[i] = false;
+    mark[0] = mark[n] = true;
+    for (int k = 0; k < lv.n; ++k)
+      for (int i = 0; i < lv.size[k]; ++i) {
+        mark[(i * n) / lv.size[k]] = true;
+        mark[((i + 1) * n + lv.size[k] - 1) / lv.size[k]] = true;
+      }
+    cnt = 0;
+    for (int i = 0; i <= n; ++i)
+      if (mark[i]) {
+        if (cnt >= kMaxCuts) return false;
+        out[cnt++] = i;
+      }
+    cnt -= 1;  // segments
+    return cnt >= 1;
+  };
+  return build(H, c.y, c.ny) && build(W, c.x, c.nx);
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) { return make_float4(s * a.x + b.x, s * a.y + b.y, s * a.z + b.z, s * a.w + b.w); }
+
+// cells[b][vy][vx][C] = sum of feats over the pixels of segment cell (vy, vx).   grid (ny*nx, B)
+__global__ __launch_bounds__(kThreads) void ppm_cells_nhwc_kernel(const float *__restrict__ x, float *__restrict__ cells,
+                                                                 int H, int W, int C4, Cuts cu) {
+  __shared__ float4 red[kThreads];
+  const int cell = blockIdx.x, b = blockIdx.y;
+  const int vy = cell / cu.nx, vx = cell - vy * cu.nx;
+  const int h0 = cu.y[vy], h1 = cu.y[vy + 1], w0 = cu.x[vx], w1 = cu.x[vx + 1];
+  const int cw = w1 - w0, npix = (h1 - h0) * cw;
+  const int Q = C4 < kThreads ? C4 : kThreads;   // quads handled per pass
+  const int P = kThreads / Q;                    // pixel lanes (1 when C4 >= 256)
+  const int t = threadIdx.x;
+  const int ql = t % Q, pl = t / Q;
+  const float *base = x + (int64_t)b * H * W * C4 * 4;
+  float *out = cells + ((int64_t)b * cu.ny * cu.nx + cell) * C4 * 4;
+  for (int q0 = 0; q0 < C4; q0 += Q) {
+    const int q = q0 + ql;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < C4 && pl < P) {
+      for (int p = pl; p < npix; p += 4 * P) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p + u * P;
+          if (pp < npix) {
+            const int hh = h0 + pp / cw, ww = w0 + pp % cw;
+            v[u] = *reinterpret_cast<const float4 *>(base + ((int64_t)hh * W + ww) * C4 * 4 + q * 4);
+          } else {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        acc = f4add(acc, f4add(f4add(v[0], v[1]), f4add(v[2], v[3])));
+      }
+    }
+    if (P > 1) {
+      red[t] = acc;
+      __syncthreads();
+      if (pl == 0 && q < C4) {
+        for (int r = 1; r < P; ++r) acc = f4add(acc, red[r * Q + ql]);
+        *reinterpret_cast<float4 *>(out + q * 4) = acc;
+      }
+      __syncthreads();
+    } else if (q < C4) {
+      *reinterpret_cast<float4 *>(out + q * 4) = acc;
+    }
+  }
+}
+
+// pooled level k, (B, s, s, C): mean over the bin = sum of its cells / area.   grid (bins, B)
+__global__ __launch_bounds__(kThreads) void ppm_bins_nhwc_kernel(const float *__restrict__ cells, float *__restrict__ pooled,
+                                                                int B, int H, int W, int C4, Cuts cu, Levels lv) {
+  const int bin = blockIdx.x, b = blockIdx.y;
+  int k = 0;
+  while (k + 1 < lv.n && bin >= lv.bin_off[k + 1]) ++k;
+  const int s = lv.size[k], local = bin - lv.bin_off[k];
+  const int i = local / s, j = local - i * s;
+  const int h0 = bin_start(i, H, s), h1 = bin_end(i, H, s), w0 = bin_start(j, W, s), w1 = bin_end(j, W, s);
+  int va = 0, vb = 0, ua = 0, ub = 0;
+  while (cu.y[va] < h0) ++va;
+  vb = va;
+  while (cu.y[vb] < h1) ++vb;
+  while (cu.x[ua] < w0) ++ua;
+  ub = ua;
+  while (cu.x[ub] < w1) ++ub;
+  const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+  const float *src = cells + (int64_t)b * cu.ny * cu.nx * C4 * 4;
+  float *dst = pooled + ((int64_t)B * lv.bin_off[k] + ((int64_t)b * s * s + local)) * C4 * 4;
+  for (int q = threadIdx.x; q < C4; q += kThreads) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = va; v < vb; ++v)
+      for (int u = ua; u < ub; ++u) acc = f4add(acc, *reinterpret_cast<const float4 *>(src + ((int64_t)v * cu.nx + u) * C4 * 4 + q * 4));
+    *reinterpret_cast<float4 *>(dst + q * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+// dx[b][h][w][c] = sum over levels and covering bins of g[bin][c] / area(bin).   grid (H, B)
+__global__ __launch_bounds__(kThreads) void ppm_pool_bwd_nhwc_kernel(const float *__restrict__ g, float *__restrict__ dx,
+                                                                    int B, int H, int W, int C4, Levels lv) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // first[L*W] (int) | count[L*W] (int) | inv[L*W*2]
+  int *first = reinterpret_cast<int *>(sm);
+  int *count = first + lv.n * W;
+  float *inv = reinterpret_cast<float *>(count + lv.n * W);
+  const int h = blockIdx.x, b = blockIdx.y;
+  for (int o = threadIdx.x; o < lv.n * W; o += kThreads) {
+    const int k = o / W, c = o - k * W, s = lv.size[k];
+    const int ia = (c * s) / W;
+    int f = ia;
+    if (ia > 0 && c < bin_end(ia - 1, W, s)) f = ia - 1;
+    int cnt = 1;
+    if (f + 1 < s && c >= bin_start(f + 1, W, s)) cnt = 2;
+    first[o] = f;
+    count[o] = cnt;
+    inv[2 * o] = 1.f / (float)(bin_end(f, W, s) - bin_start(f, W, s));
+    inv[2 * o + 1] = cnt == 2 ? 1.f / (float)(bin_end(f + 1, W, s) - bin_start(f + 1, W, s)) : 0.f;
+  }
+  __syncthreads();
+  // the row's own covering bins per level (uniform over the workgroup)
+  int rf[kMaxLevels], rc[kMaxLevels];
+  float ri[kMaxLevels][2];
+  for (int k = 0; k < lv.n; ++k) {
+    const int s = lv.size[k];
+    const int ia = (h * s) / H;
+    int f = ia;
+    if (ia > 0 && h < bin_end(ia - 1, H, s)) f = ia - 1;
+    rc[k] = (f + 1 < s && h >= bin_start(f + 1, H, s)) ? 2 : 1;
+    rf[k] = f;
+    ri[k][0] = 1.f / (float)(bin_end(f, H, s) - bin_start(f, H, s));
+    ri[k][1] = rc[k] == 2 ? 1.f / (float)(bin_end(f + 1, H, s) - bin_start(f + 1, H, s)) : 0.f;
+  }
+  float *out = dx + ((int64_t)b * H + h) * W * C4 * 4;
+  for (int item = threadIdx.x; item < W * C4; item += kThreads) {
+    const int w = item / C4, q = item - w * C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < lv.n; ++k) {
+      const int s = lv.size[k], o = k * W + w;
+      const float *gk = g + ((int64_t)B * lv.bin_off[k] + (int64_t)b * s * s) * C4 * 4 + q * 4;
+      for (int a = 0; a < rc[k]; ++a)
+        for (int c = 0; c < count[o]; ++c) {
+          const float wt = ri[k][a] * inv[2 * o + c];
+          acc = f4fma(wt, *reinterpret_cast<const float4 *>(gk + (int64_t)((rf[k] + a) * s + first[o] + c) * C4 * 4), acc);
+        }
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)item * 4) = acc;
+  }
+}
+
+// cat[b][h][w][k*Cout + c] = bilinear(prior_k[b][:, :, c]);  cat[b][h][w][L*Cout + c'] = feats[b][h][w][c'].  grid (chunks, H, B)
+__global__ __launch_bounds__(kThreads) void ppm_concat_nhwc_kernel(PriorPtrs pr, const float *__restrict__ feats,
+                                                                  float *__restrict__ cat, int Cout4, int Cf4, int H,
+                                                                  int W, Levels lv) {
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int Ct4 = lv.n * Cout4 + Cf4;
+  const int64_t row = ((int64_t)b * H + h) * W;
+  for (int item = blockIdx.x * kThreads + threadIdx.x; item < W * Ct4; item += gridDim.x * kThreads) {
+    const int w = item / Ct4, q = item - w * Ct4;
+    float4 v;
+    if (q >= lv.n * Cout4) {
+      v = *reinterpret_cast<const float4 *>(feats + ((row + w) * Cf4 + (q - lv.n * Cout4)) * 4);
+    } else {
+      const int k = q / Cout4, cq = q - k * Cout4, s = lv.size[k];
+      const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f;
+      const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+      const Tap ty = tap_of(h, sy, s), tx = tap_of(w, sx, s);
+      const float *src = pr.p[k] + (int64_t)b * s * s * Cout4 * 4 + cq * 4;
+      const float4 a00 = *reinterpret_cast<const float4 *>(src + (int64_t)(ty.i0 * s + tx.i0) * Cout4 * 4);
+      const float4 a01 = *reinterpret_cast<const float4 *>(src + (int64_t)(ty.i0 * s + tx.i1) * Cout4 * 4);
+      const float4 a10 = *reinterpret_cast<const float4 *>(src + (int64_t)(ty.i1 * s + tx.i0) * Cout4 * 4);
+      const float4 a11 = *reinterpret_cast<const float4 *>(src + (int64_t)(ty.i1 * s + tx.i1) * Cout4 * 4);
+      // same association as the NCHW kernel: ty.l0 * (tx.l0 * a00 + tx.l1 * a01) + ty.l1 * (tx.l0 * a10 + tx.l1 * a11)
+      v.x = ty.l0 * (tx.l0 * a00.x + tx.l1 * a01.x) + ty.l1 * (tx.l0 * a10.x + tx.l1 * a11.x);
+      v.y = ty.l0 * (tx.l0 * a00.y + tx.l1 * a01.y) + ty.l1 * (tx.l0 * a10.y + tx.l1 * a11.y);
+      v.z = ty.l0 * (tx.l0 * a00.z + tx.l1 * a01.z) + ty.l1 * (tx.l0 * a10.z + tx.l1 * a11.z);
+      v.w = ty.l0 * (tx.l0 * a00.w + tx.l1 * a01.w) + ty.l1 * (tx.l0 * a10.w + tx.l1 * a11.w);
+    }
+    *reinterpret_cast<float4 *>(cat + ((row + w) * Ct4 + q) * 4) = v;
+  }
+}
+
+// row pass of the pull-back: rowacc[b][Y][rowbin(k, x)][Cout] = sum_X wx(X, x) * gcat[b][Y][X][k*Cout + c], and the
+// feature-map slice of gcat copied out contiguously.   grid (H, B)
+__global__ __launch_bounds__(kThreads) void ppm_concat_bwd_rows_nhwc_kernel(const float *__restrict__ gcat,
+                                                                           float *__restrict__ rowacc,
+                                                                           float *__restrict__ gfeats, int Cout4,
+                                                                           int Cf4, int H, int W, Levels lv) {
+  const int Y = blockIdx.x, b = blockIdx.y;
+  const int Ct4 = lv.n * Cout4 + Cf4;
+  const float *src = gcat + ((int64_t)b * H + Y) * W * Ct4 * 4;
+  if (gfeats != nullptr) {
+    float *dst = gfeats + ((int64_t)b * H + Y) * W * Cf4 * 4;
+    for (int item = threadIdx.x; item < W * Cf4; item += kThreads) {
+      const int w = item / Cf4, q = item - w * Cf4;
+      *reinterpret_cast<float4 *>(dst + (int64_t)item * 4) =
+          *reinterpret_cast<const float4 *>(src + ((int64_t)w * Ct4 + lv.n * Cout4 + q) * 4);
+    }
+  }
+  if (rowacc == nullptr) return;
+  float *out = rowacc + ((int64_t)b * H + Y) * lv.rows * Cout4 * 4;
+  for (int item = threadIdx.x; item < lv.rows * Cout4; item += kThreads) {
+    const int rb = item / Cout4, cq = item - rb * Cout4;
+    int k = 0;
+    while (k + 1 < lv.n && rb >= lv.row_off[k + 1]) ++k;
+    const int s = lv.size[k], x = rb - lv.row_off[k];
+    const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int X = 0; X < W; ++X) {
+      const Tap t = tap_of(X, sx, s);
+      float wt = 0.f;
+      if (t.i0 == x) wt += t.l0;
+      if (t.i1 == x) wt += t.l1;
+      if (wt != 0.f) acc = f4fma(wt, *reinterpret_cast<const float4 *>(src + ((int64_t)X * Ct4 + k * Cout4 + cq) * 4), acc);
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)item * 4) = acc;
+  }
+}
+
+// column pass: gprior_k[b][y][x][c] = sum_Y wy(Y, y) * rowacc[b][Y][rowbin(k, x)][c].   grid (bins, B)
+__global__ __launch_bounds__(kThreads) void ppm_concat_bwd_cols_nhwc_kernel(const float *__restrict__ rowacc, GradPtrs gp,
+                                                                           int Cout4, int H, Levels lv) {
+  const int bin = blockIdx.x, b = blockIdx.y;
+  int k = 0;
+  while (k + 1 < lv.n && bin >= lv.bin_off[k + 1]) ++k;
+  const int s = lv.size[k], local = bin - lv.bin_off[k];
+  const int y = local / s, x = local - y * s;
+  const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f;
+  float *dst = gp.p[k] + ((int64_t)b * s * s + local) * Cout4 * 4;
+  for (int cq = threadIdx.x; cq < Cout4; cq += kThreads) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Y = 0; Y < H; ++Y) {
+      const Tap t = tap_of(Y, sy, s);
+      float wt = 0.f;
+      if (t.i0 == y) wt += t.l0;
+      if (t.i1 == y) wt += t.l1;
+      if (wt != 0.f)
+        acc = f4fma(wt, *reinterpret_cast<const float4 *>(rowacc + (((int64_t)b * H + Y) * lv.rows + lv.row_off[k] + x) * Cout4 * 4 + cq * 4), acc);
+    }
+    *reinterpret_cast<float4 *>(dst + cq * 4) = acc;
+  }
+}
+
 }  // namespace
 }  // namespace skd
 
@@ -326,6 +592,78 @@ int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes
   }
   ppm_concat_bwd_kernel<<<dim3((unsigned)(B * nsizes * Cout)), dim3(kThreads), smem, as_stream(stream)>>>(
       gcat, gp, B, Cout, Cfeat, H, W, lv);
+  return ok();
+}
+
+
+// ---- channels-last entries (layouts in the section header above) ----------------------------------------------
+
+int64_t skd_ppm_nhwc_workspace_floats(int B, int C, int Cout, int H, int W, int nsizes, const int *sizes) {
+  Levels lv;
+  Cuts cu;
+  if (B <= 0 || H <= 0 || W <= 0 || !make_levels(nsizes, sizes, lv) || !make_cuts(H, W, lv, cu)) return 0;
+  const int64_t cells = (int64_t)B * cu.ny * cu.nx * (C > 0 ? C : 0);
+  const int64_t rows = (int64_t)B * H * lv.rows * (Cout > 0 ? Cout : 0);
+  return cells > rows ? cells : rows;
+}
+
+int skd_ppm_pool_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *x, float *pooled,
+                      float *workspace, skd_stream_t stream) {
+  Levels lv;
+  Cuts cu;
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || !x || !pooled || !workspace) return 0;
+  if (!make_levels(nsizes, sizes, lv) || !make_cuts(H, W, lv, cu)) return 0;
+  hipStream_t st = as_stream(stream);
+  ppm_cells_nhwc_kernel<<<dim3((unsigned)(cu.ny * cu.nx), (unsigned)B), dim3(kThreads), 0, st>>>(x, workspace, H, W, C / 4, cu);
+  ppm_bins_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, pooled, B, H, W, C / 4, cu, lv);
+  return ok();
+}
+
+int skd_ppm_pool_backward_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, const float *gpooled, float *dx,
+                               skd_stream_t stream) {
+  Levels lv;
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || !gpooled || !dx || !make_levels(nsizes, sizes, lv)) return 0;
+  for (int k = 0; k < nsizes; ++k)
+    if (sizes[k] > H || sizes[k] > W) return 0;
+  const size_t smem = sizeof(float) * (size_t)lv.n * W * 4;
+  if (smem > 64 * 1024) return 0;
+  ppm_pool_bwd_nhwc_kernel<<<dim3((unsigned)H, (unsigned)B), dim3(kThreads), smem, as_stream(stream)>>>(gpooled, dx, B, H, W, C / 4, lv);
+  return ok();
+}
+
+int skd_ppm_concat_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes, const float *const *priors,
+                        const float *feats, float *cat, skd_stream_t stream) {
+  Levels lv;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || Cfeat < 0 || (Cfeat & 3) || H <= 0 || W <= 0 || !priors || !cat) return 0;
+  if (!make_levels(nsizes, sizes, lv) || (Cfeat > 0 && !feats) || H > 65535 || B > 65535) return 0;
+  PriorPtrs pr;
+  for (int k = 0; k < kMaxLevels; ++k) pr.p[k] = k < nsizes ? priors[k] : nullptr;
+  for (int k = 0; k < nsizes; ++k)
+    if (!pr.p[k]) return 0;
+  const int Ct4 = (nsizes * Cout + Cfeat) / 4;
+  int gx = (int)cdiv((int64_t)W * Ct4, kThreads * 16);
+  if (gx < 1) gx = 1;
+  ppm_concat_nhwc_kernel<<<dim3((unsigned)gx, (unsigned)H, (unsigned)B), dim3(kThreads), 0, as_stream(stream)>>>(
+      pr, feats, cat, Cout / 4, Cfeat / 4, H, W, lv);
+  return ok();
+}
+
+int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int nsizes, const int *sizes, const float *gcat,
+                                 float *const *gpriors, float *gfeats, float *workspace, skd_stream_t stream) {
+  Levels lv;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || Cfeat < 0 || (Cfeat & 3) || H <= 0 || W <= 0 || !gcat) return 0;
+  if (!make_levels(nsizes, sizes, lv) || H > 65535 || B > 65535) return 0;
+  if (gpriors && !workspace) return 0;
+  GradPtrs gp;
+  for (int k = 0; k < kMaxLevels; ++k) gp.p[k] = (gpriors && k < nsizes) ? gpriors[k] : nullptr;
+  if (gpriors)
+    for (int k = 0; k < nsizes; ++k)
+      if (!gp.p[k]) return 0;
+  hipStream_t st = as_stream(stream);
+  ppm_concat_bwd_rows_nhwc_kernel<<<dim3((unsigned)H, (unsigned)B), dim3(kThreads), 0, st>>>(
+      gcat, gpriors ? workspace : nullptr, Cfeat > 0 ? gfeats : nullptr, Cout / 4, Cfeat / 4, H, W, lv);
+  if (gpriors)
+    ppm_concat_bwd_cols_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, gp, Cout / 4, H, lv);
   return ok();
 }
 

@@ -102,12 +102,48 @@ def cross_entropy_dsn(logits_main, logits_dsn, target, ignore_index=255, aux_wei
     return _CrossEntropyDSN.apply(logits_main, logits_dsn, target, ignore_index, aux_weight)
 
 
+def _is_cl(t):
+    """4-D, channels-last memory (and not also plain-contiguous), channel count a multiple of 4."""
+    return (t.dim() == 4 and t.shape[1] % 4 == 0 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _new_cl(ref, b, c, h, w):
+    """Uninitialised (b, c, h, w) tensor with channels-last memory (b, h, w, c)."""
+    return ref.new_empty((b, h, w, c), dtype=torch.float32).permute(0, 3, 1, 2)
+
+
 class _PPMPool(Function):
-    """All pyramid levels of AdaptiveAvgPool2d from one read of the feature map."""
+    """All pyramid levels of AdaptiveAvgPool2d from one read of the feature map (NCHW or channels-last)."""
 
     @staticmethod
     def forward(ctx, x, sizes):
         _lib.require_device(x)
+        if x.dtype != torch.float32:
+            raise TypeError("ppm_pool: fp32 tensors only (got %s)" % x.dtype)
+        ctx.cl = _is_cl(x)
+        if ctx.cl:
+            b, c, h, w = x.shape
+            lib, st = _lib.get(), _lib.stream_of(x)
+            arr = _lib.int_array(sizes)
+            total = lib.skd_ppm_pooled_floats(b * c, len(sizes), arr)
+            if total <= 0:
+                raise ValueError("ppm_pool: bad pyramid sizes %r" % (sizes,))
+            buf = x.new_empty((total,))
+            ws = x.new_empty((max(1, lib.skd_ppm_nhwc_workspace_floats(b, c, 0, h, w, len(sizes), arr)),))
+            _lib.check(lib.skd_ppm_pool_nhwc(b, c, h, w, len(sizes), arr, x.data_ptr(), buf.data_ptr(), ws.data_ptr(), st),
+                       "skd_ppm_pool_nhwc")
+            ctx.geom = (b, c, h, w, tuple(sizes))
+            outs, off = [], 0
+            for s_ in sizes:
+                n = b * c * s_ * s_
+                outs.append(buf[off:off + n].view(b, s_, s_, c).permute(0, 3, 1, 2))     # (b, c, s, s), channels-last memory
+                off += n
+            return tuple(outs)
         x = _f32c(x, "ppm_pool")
         b, c, h, w = x.shape
         lib, st = _lib.get(), _lib.stream_of(x)
@@ -130,6 +166,14 @@ class _PPMPool(Function):
     def backward(ctx, *grads):
         b, c, h, w, sizes = ctx.geom
         ref = next(g for g in grads if g is not None)
+        if ctx.cl:
+            flat = torch.cat([(_cl(g).permute(0, 2, 3, 1) if g is not None else ref.new_zeros((b, s_, s_, c))).reshape(-1)
+                              for g, s_ in zip(grads, sizes)]).to(torch.float32)
+            dx = _new_cl(ref, b, c, h, w)
+            lib, st = _lib.get(), _lib.stream_of(flat)
+            _lib.check(lib.skd_ppm_pool_backward_nhwc(b, c, h, w, len(sizes), _lib.int_array(sizes), flat.data_ptr(),
+                                                      dx.data_ptr(), st), "skd_ppm_pool_backward_nhwc")
+            return dx, None
         flat = torch.cat([(g if g is not None else ref.new_zeros((b, c, s_, s_))).reshape(-1)
                           for g, s_ in zip(grads, sizes)]).to(torch.float32)
         dx = ref.new_empty((b, c, h, w), dtype=torch.float32)
@@ -150,6 +194,22 @@ class _PPMConcat(Function):
     @staticmethod
     def forward(ctx, feats, *priors):
         _lib.require_device(feats, *priors)
+        ctx.cl = _is_cl(feats) and feats.dtype == torch.float32 and all(p.dtype == torch.float32 and p.shape[1] % 4 == 0 for p in priors)
+        if ctx.cl:
+            b, cf, h, w = feats.shape
+            cout = priors[0].shape[1]
+            sizes = []
+            for p in priors:
+                if p.shape[0] != b or p.shape[1] != cout or p.shape[2] != p.shape[3]:
+                    raise ValueError("ppm_concat: priors must be (B, Cout, s, s)")
+                sizes.append(p.shape[2])
+            priors = [_cl(p) for p in priors]                     # memory (b, s, s, cout)
+            lib, st = _lib.get(), _lib.stream_of(feats)
+            cat = _new_cl(feats, b, len(priors) * cout + cf, h, w)
+            _lib.check(lib.skd_ppm_concat_nhwc(b, cout, cf, h, w, len(sizes), _lib.int_array(sizes), _lib.ptr_array(priors),
+                                               feats.data_ptr(), cat.data_ptr(), st), "skd_ppm_concat_nhwc")
+            ctx.geom = (b, cout, cf, h, w, tuple(sizes))
+            return cat
         feats = _f32c(feats, "ppm_concat")
         priors = [_f32c(p, "ppm_concat") for p in priors]
         b, cf, h, w = feats.shape
@@ -170,6 +230,18 @@ class _PPMConcat(Function):
     @once_differentiable
     def backward(ctx, gcat):
         b, cout, cf, h, w, sizes = ctx.geom
+        if ctx.cl:
+            gcat = _cl(gcat.to(torch.float32))
+            lib, st = _lib.get(), _lib.stream_of(gcat)
+            arr = _lib.int_array(sizes)
+            need_p = any(ctx.needs_input_grad[1:])
+            gfeats = _new_cl(gcat, b, cf, h, w) if ctx.needs_input_grad[0] else None
+            gpriors = [_new_cl(gcat, b, cout, s_, s_) for s_ in sizes] if need_p else None
+            ws = gcat.new_empty((max(1, lib.skd_ppm_nhwc_workspace_floats(b, 0, cout, h, w, len(sizes), arr)),)) if need_p else None
+            _lib.check(lib.skd_ppm_concat_backward_nhwc(b, cout, cf, h, w, len(sizes), arr, gcat.data_ptr(),
+                                                        _lib.ptr_array(gpriors) if need_p else None, _lib.ptr(gfeats),
+                                                        _lib.ptr(ws), st), "skd_ppm_concat_backward_nhwc")
+            return (gfeats,) + (tuple(gpriors) if need_p else (None,) * len(sizes))
         gcat = _f32c(gcat, "ppm_concat backward")
         lib, st = _lib.get(), _lib.stream_of(gcat)
         gfeats = gcat[:, len(sizes) * cout:] if ctx.needs_input_grad[0] else None

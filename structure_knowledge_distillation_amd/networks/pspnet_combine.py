@@ -109,12 +109,12 @@ class PSPModule(nn.Module):
         for stage in self.stages:
             o = stage[0].output_size
             sizes.append(o[0] if isinstance(o, (tuple, list)) else o)
-        if (feats.dtype == torch.float32 and len(sizes) <= 4 and feats.size(3) <= 256
+        nhwc = feats.dim() == 4 and not feats.is_contiguous() and feats.is_contiguous(memory_format=torch.channels_last)
+        if (feats.dtype == torch.float32 and len(sizes) <= 4 and (nhwc or feats.size(3) <= 256)
                 and min(feats.size(2), feats.size(3)) >= max(sizes)):
             # csrc/ppm.hip: every pyramid level from one read of feats; priors up-sampled straight into the
             # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
-            if not feats.is_contiguous():
-                feats = feats.contiguous()     # channels-last teacher features: the PPM kernels work on NCHW planes
+            # channels-last feature maps take the channels-last kernels (no layout copies); anything else the NCHW ones
             pooled = SF.ppm_pool(feats, sizes)
             priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
             return self.bottleneck(SF.ppm_concat(priors, feats))

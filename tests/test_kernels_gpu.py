@@ -593,7 +593,8 @@ def test_ce_dsn(hip, ref, geom):
     assert float(lr) != float(lr)
 
 
-@pytest.mark.parametrize("geom", [(8, 512, 65, 65, 128), (2, 2048, 65, 65, 512), (2, 7, 33, 33, 5), (3, 4, 46, 61, 3), (1, 2, 7, 9, 2), (1, 1, 129, 129, 1)])
+@pytest.mark.parametrize("geom", [(8, 512, 65, 65, 128), (2, 2048, 65, 65, 512), (2, 7, 33, 33, 5), (3, 4, 46, 61, 3), (1, 2, 7, 9, 2), (1, 1, 129, 129, 1),
+                                  (2, 8, 33, 47, 4), (1, 12, 129, 255, 8), (2, 48, 6, 6, 20)])
 def test_ppm(hip, ref, geom):
     B, C, H, W, Cout = geom
     sizes = (1, 2, 3, 6)
@@ -628,6 +629,47 @@ def test_ppm(hip, ref, geom):
     tp = torch.nn.functional.adaptive_avg_pool2d(x.double(), 3)
     off = B * C * 5
     close(pg[off:off + B * C * 9].view(B, C, 3, 3), tp.float(), 1e-5, "pool vs torch")
+    # ---- channels-last entries: the same numbers as the NCHW oracle results, in (B, H, W, C) memory ----
+    if C % 4:
+        assert hip.skd_ppm_pool_nhwc(B, C, H, W, 4, arr, P(pg), P(pg), P(pg), None) == 0       # channel quads only
+        return
+    if Cout % 4:
+        return
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()                       # (B, C, h, w) values -> (B, h, w, C) memory
+    x_cl = gpu(nhwc(x))
+    ws = torch.empty(max(1, hip.skd_ppm_nhwc_workspace_floats(B, C, Cout, H, W, 4, arr)), device=DEV)
+    pcl = torch.full((total,), 7.0, device=DEV)
+    assert hip.skd_ppm_pool_nhwc(B, C, H, W, 4, arr, P(x_cl), P(pcl), P(ws), None)
+    off = 0
+    for s_ in sizes:
+        n = B * C * s_ * s_
+        close(pcl[off:off + n].view(B, s_, s_, C).permute(0, 3, 1, 2), pr[off:off + n].view(B, C, s_, s_), 1e-5, "nhwc pooled level %d" % s_)
+        off += n
+    gp_cl, off = [], 0
+    for s_ in sizes:
+        n = B * C * s_ * s_
+        gp_cl.append(nhwc(gp[off:off + n].view(B, C, s_, s_)).reshape(-1))
+        off += n
+    dx_cl = torch.full((B, H, W, C), 7.0, device=DEV)
+    assert hip.skd_ppm_pool_backward_nhwc(B, C, H, W, 4, arr, P(gpu(torch.cat(gp_cl))), P(dx_cl), None)
+    close(dx_cl.permute(0, 3, 1, 2), dxr, 1e-5, "nhwc pool backward")
+    pr_cl = [gpu(nhwc(t)) for t in priors]
+    cat_cl = torch.full((B, H, W, 4 * Cout + C), 7.0, device=DEV)
+    assert hip.skd_ppm_concat_nhwc(B, Cout, C, H, W, 4, arr, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in pr_cl]), P(x_cl), P(cat_cl), None)
+    close(cat_cl.permute(0, 3, 1, 2), cat_r, 1e-5, "nhwc concat")
+    assert torch.equal(cat_cl[..., 4 * Cout:].cpu(), nhwc(x)), "feature slice is a bit-exact copy"
+    gg_cl = [torch.full((B, s_, s_, Cout), 7.0, device=DEV) for s_ in sizes]
+    gf_cl = torch.full((B, H, W, C), 7.0, device=DEV)
+    gc_cl = gpu(nhwc(gc))
+    assert hip.skd_ppm_concat_backward_nhwc(B, Cout, C, H, W, 4, arr, P(gc_cl), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gg_cl]), P(gf_cl), P(ws), None)
+    for a, b, s_ in zip(gg_cl, gr, sizes):
+        close(a.permute(0, 3, 1, 2), b, 2e-5, "nhwc concat backward level %d" % s_)
+    assert torch.equal(gf_cl.cpu(), nhwc(gc[:, 4 * Cout:])), "gradient of the feature map = its slice of gcat"
+    # the C oracle's channels-last forms agree with its NCHW forms by construction; one spot check keeps them honest
+    cat_o = torch.empty(B, H, W, 4 * Cout + C)
+    keep = [nhwc(t) for t in priors] + [nhwc(x)]
+    assert ref.skd_ppm_concat_nhwc(B, Cout, C, H, W, 4, arr, (ctypes.c_void_p * 4)(*[t.data_ptr() for t in keep[:4]]), P(keep[4]), P(cat_o), None)
+    assert torch.equal(cat_o.permute(0, 3, 1, 2), cat_r)
 
 
 @pytest.mark.parametrize("geom", [(1, 19, 129, 257, 1024, 2048), (2, 19, 65, 65, 512, 512), (2, 11, 46, 61, 360, 480), (1, 3, 1, 1, 4, 4),
