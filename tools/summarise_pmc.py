@@ -88,13 +88,13 @@ def main():
                 other = max(0.0, k.get("TCC_EA0_RDREQ_sum", 0.0) - r128 - r64 - r32)
                 k["read_bytes_by_request_size"] = r128 * 128 + r64 * 64 + r32 * 32 + other * 64
                 tot_exact += k["read_bytes_by_request_size"]
-            if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "SQ_BUSY_CYCLES" in k and k["SQ_BUSY_CYCLES"]:
-                # MFMA_BUSY counts per SIMD, SQ_BUSY per SQ (= per CU... summed over XCD SQs): report the raw ratio and
-                # the per-SIMD normalised one (4 SIMDs per CU)
-                k["mfma_busy_over_sq_busy"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / k["SQ_BUSY_CYCLES"], 4)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k and k["GRBM_GUI_ACTIVE"]:
-                # fraction of the chip's SIMD-cycles (256 CUs x 4 SIMDs x active cycles) with the matrix pipe busy
-                k["mfma_pipe_busy_frac"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] * 256 * 4), 4)
+                # Fraction of the chip's SIMD-cycles with the matrix pipe busy.  SQ_VALU_MFMA_BUSY_CYCLES is summed over
+                # all SIMDs (= 64 cycles x SQ_INSTS_MFMA for v_mfma_f32_32x32x2_f32, checked against the instruction
+                # count); GRBM_GUI_ACTIVE is reported summed over the 8 XCCs (8 x clock x duration), so one XCC's active
+                # cycles = GRBM / 8 and the chip offers 256 CUs x 4 SIMDs x GRBM / 8 SIMD-cycles.
+                k["mfma_pipe_busy_frac"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4), 4)
+                k["clock_GHz_under_pmc"] = round(k["GRBM_GUI_ACTIVE"] / 8.0 / (k.get("dur_us_under_pmc", 0) * 1e3), 3) if k.get("dur_us_under_pmc") else None
         if c.get("algo_bytes") and have_f and have_w:
             c["hbm_bytes (2*FETCH_SIZE + WRITE_SIZE, all kernels of one call)"] = round(tot_fetch + tot_write)
             c["hbm_over_algorithmic"] = round((tot_fetch + tot_write) / c["algo_bytes"], 4)

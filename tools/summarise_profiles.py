@@ -1,6 +1,7 @@
 """Turn the rocprofv3 outputs merged into gpurun_out/ into the small summaries committed under profiles/.
 
-    python tools/summarise_profiles.py <tag>        e.g. r01b
+    python tools/summarise_profiles.py <tag> [steps] [session]     e.g. r02b 8 s4  (session = sub-directory of gpurun_out/
+                                                                   written by tools/gpu_session.sh; default: gpurun_out/ itself)
 
 Writes profiles/<tag>_bench_kernel_stats.csv (verbatim rocprofv3 --stats table), profiles/<tag>_step_breakdown.md
 (per-category ms/step) and profiles/<tag>_abn_pmc.json (FETCH_SIZE / WRITE_SIZE per ABN kernel launch; FETCH_SIZE is
@@ -43,8 +44,11 @@ def category(n):
 
 
 def main():
+    global G
     tag = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    if len(sys.argv) > 3:
+        G = os.path.join(G, sys.argv[3])
     os.makedirs(P, exist_ok=True)
     src = os.path.join(G, "prof_bench", "bench_kernel_stats.csv")
     if os.path.exists(src):
@@ -132,7 +136,7 @@ def main():
             if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
                 d["hbm_MB (2*FETCH + WRITE)"] = round((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) / 1e3, 1)
         json.dump(pmc, open(os.path.join(P, tag + "_abn_pmc.json"), "w"), indent=1, sort_keys=True)
-    for f in ("bench.json", "abn_microbench.log"):
+    for f in ("bench.json", "bench_quick.json", "abn_microbench.log", "micro.jsonl", "conv_shapes.md"):
         if os.path.exists(os.path.join(G, f)):
             shutil.copy(os.path.join(G, f), os.path.join(P, tag + "_" + f))
 
