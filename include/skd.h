@@ -316,6 +316,24 @@ int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *log
 int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, float *workspace,
                 skd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210
+ *     (CSDataSet.__getitem__ after the PNG decode), one launch per batch:
+ *       label = lut[label] (id -> trainId, datasets.py:143-148,162-171); image / label resized by f (cv2.resize,
+ *       INTER_LINEAR 8-bit fixed point / INTER_NEAREST -- bit-exact restatement, see csrc/input_pipeline.hip);
+ *       image = float32(image) - mean; bottom / right padding to the crop size (image 0.0, label ignore_label);
+ *       crop at (h_off, w_off); HWC -> CHW (or kept channels-last); horizontal mirror when flip < 0.
+ *     images (B, H0, W0, 3) uint8 BGR and labels (B, H0, W0) uint8 raw ids are DEVICE buffers (labels / out_label may
+ *     both be NULL: image only); scale / dst_h / dst_w / h_off / w_off / flip are per-sample DEVICE arrays holding the
+ *     host's random draws (dst = cvRound(size * f), the size of the virtual scaled image); lut (256 bytes) is a DEVICE
+ *     array; mean (3 floats, BGR order) is a HOST array.  out_image: (B, 3, crop_h, crop_w) fp32, or (B, crop_h, crop_w, 3)
+ *     memory when channels_last != 0; out_label: (B, crop_h, crop_w) int64.
+ * ---------------------------------------------------------------------------------- */
+int skd_cs_transform(int B, int H0, int W0, const uint8_t *images, const uint8_t *labels, const uint8_t *lut,
+                     const double *scale, const int *dst_h, const int *dst_w, const int *h_off, const int *w_off,
+                     const int *flip, int crop_h, int crop_w, const float *mean, int ignore_label, float *out_image,
+                     int channels_last, int64_t *out_label, skd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
