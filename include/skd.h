@@ -223,6 +223,12 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
 int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t,
                           const float *G, const float *norm_s, const float *grad_loss,
                           float *dpooled, skd_stream_t stream);
+/* Small graphs (M <= 64; the reference default --pool-scale 0.5 gives M = 9): norm + both Grams + loss (+ gradient)
+ * of one image in one workgroup, no padding to MFMA tiles.  pooled_s (B, Cs, M), pooled_t (B, Ct, M);
+ * loss[0] = sum (A_T - A_S)^2 / M^2 / B; dpooled (B, Cs, M) or NULL = d loss / d pooled_s for an upstream gradient
+ * of 1 (the norm is a constant, utils.py:175).  workspace: B floats. */
+int skd_pairwise_small(int B, int Cs, int Ct, int M, const float *pooled_s, const float *pooled_t, float *loss,
+                       float *dpooled, float *workspace, skd_stream_t stream);
 /* dpooled rows have stride ldp floats (ldp = ldm from above, or M for a dense tensor) */
 int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float *dpooled,
                           int64_t ldp, const int32_t *index, float *dx /* (planes, H, W) */,

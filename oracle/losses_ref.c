@@ -201,6 +201,27 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *f
   return 1;
 }
 
+/* small-graph entry: the same stages composed (normalise -> Gram / loss -> backward with an upstream gradient of 1) */
+int skd_pairwise_small(int B, int Cs, int Ct, int M, const float *ps, const float *pt, float *loss, float *dpooled,
+                       float *ws, stream_t st) {
+  (void)ws;
+  if (B <= 0 || Cs <= 0 || Ct <= 0 || M <= 0 || M > 64 || !ps || !pt || !loss) return 0;
+  const int ldm = skd_pairwise_ldm(M), ldc = (int)(cdiv64(Cs, 128) * 128);
+  float *fs = (float *)malloc(sizeof(float) * (size_t)B * Cs * ldm), *ft = (float *)malloc(sizeof(float) * (size_t)B * Ct * ldm);
+  float *fst = (float *)malloc(sizeof(float) * (size_t)B * ldm * ldc), *nrm = (float *)malloc(sizeof(float) * (size_t)B * M);
+  float *G = (float *)malloc(sizeof(float) * (size_t)B * ldm * ldm), *dp = (float *)malloc(sizeof(float) * (size_t)B * Cs * ldm);
+  int r = fs && ft && fst && nrm && G && dp;
+  const float one = 1.f;
+  r = r && skd_channel_l2_normalise(B, Cs, M, ps, fs, ldm, fst, ldc, nrm, st) && skd_channel_l2_normalise(B, Ct, M, pt, ft, ldm, NULL, 0, NULL, st);
+  r = r && skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, fs, ft, G, loss, NULL, st);
+  if (r && dpooled) {
+    r = skd_pairwise_backward(B, Cs, M, ldm, ldc, fst, G, nrm, &one, dp, st);
+    for (int64_t q = 0; r && q < (int64_t)B * Cs; ++q) memcpy(dpooled + q * M, dp + q * ldm, sizeof(float) * (size_t)M);
+  }
+  free(fs); free(ft); free(fst); free(nrm); free(G); free(dp);
+  return r;
+}
+
 /* ---- spectral norm -------------------------------------------------------------------------- */
 int64_t skd_spectral_workspace_floats(int h, int w) { (void)h; (void)w; return 1; }
 

@@ -433,6 +433,100 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
   }
 }
 
+
+// =============================================================================================
+// Small graphs (M <= 64 nodes): the whole similarity loss of one image in ONE workgroup.
+// The reference's default --pool-scale 0.5 pools the 65 x 65 feature map to 3 x 3 = 9 nodes (criterion.py:241-244);
+// through the MFMA path above those 9 nodes were padded to a 128-wide tile and cost five launches (two normalise,
+// Gram, partial sum, backward GEMM: ~0.3 ms per step for an 81-entry matrix).  Here one 256-thread workgroup per
+// image keeps everything on chip: channel norms -> normalised features in LDS, chunk by chunk -> both Gram matrices
+// in registers (M^2 <= 4096 pairs, 16 per thread) -> G = A_T - A_S in LDS -> loss partial and, when asked,
+// dL/dP = -4 / (M^2 B) * (Fhat_S G) / norm_S.  fp32 FMAs in a fixed order (no MFMA: K <= 512 and M <= 64 is 2.6 MFLOP
+// per image), deterministic.
+// =============================================================================================
+constexpr int kSmallM = 64;
+constexpr int kSmallChunk = 32;   // channels per LDS chunk
+
+__global__ __launch_bounds__(kThreads) void pairwise_small_kernel(const float *__restrict__ ps, const float *__restrict__ pt,
+                                                                 float *__restrict__ part, float *__restrict__ dpooled,
+                                                                 int Cs, int Ct, int M, float coef) {
+  __shared__ float nrm[2][kSmallM];                  // [0] student, [1] teacher: sqrt(sum_c f^2) + 1e-8
+  __shared__ float tile[kSmallChunk][kSmallM + 1];
+  __shared__ float Gs[kSmallM][kSmallM + 1];
+  __shared__ float red[2 * kWavesPerWG];
+  __shared__ float ssq[kThreads];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float *S = ps + (int64_t)b * Cs * M, *T = pt + (int64_t)b * Ct * M;
+  // ---- channel norms (utils.py:170-171) ----
+  const int lanes = kThreads / kSmallM;              // 4 channel slices per node
+  for (int which = 0; which < 2; ++which) {
+    const float *F = which == 0 ? S : T;
+    const int C = which == 0 ? Cs : Ct;
+    const int m = t % kSmallM, sl = t / kSmallM;
+    float a = 0.f;
+    if (m < M)
+      for (int c = sl; c < C; c += lanes) {
+        const float v = F[(int64_t)c * M + m];
+        a += v * v;
+      }
+    ssq[t] = a;
+    __syncthreads();
+    if (t < M) nrm[which][t] = sqrtf((ssq[t] + ssq[t + kSmallM]) + (ssq[t + 2 * kSmallM] + ssq[t + 3 * kSmallM])) + 1e-8f;
+    __syncthreads();
+  }
+  // ---- Gram matrices: thread owns pairs p = t, t + 256, ... of the M x M matrix ----
+  float acc[kSmallM * kSmallM / kThreads];
+#pragma unroll
+  for (int k = 0; k < kSmallM * kSmallM / kThreads; ++k) acc[k] = 0.f;
+  const int npairs = M * M;
+  for (int which = 1; which >= 0; --which) {         // teacher (+), then student (-)
+    const float *F = which == 0 ? S : T;
+    const int C = which == 0 ? Cs : Ct;
+    const float sign = which == 0 ? -1.f : 1.f;
+    for (int c0 = 0; c0 < C; c0 += kSmallChunk) {
+      for (int e = t; e < kSmallChunk * M; e += kThreads) {
+        const int c = e / M, m = e - c * M;
+        tile[c][m] = c0 + c < C ? F[(int64_t)(c0 + c) * M + m] / nrm[which][m] : 0.f;   // utils.py:176
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kSmallM * kSmallM / kThreads; ++k) {
+        const int p = t + k * kThreads;
+        if (p < npairs) {
+          const int i = p / M, j = p - i * M;
+          float a = 0.f;
+#pragma unroll 8
+          for (int c = 0; c < kSmallChunk; ++c) a += tile[c][i] * tile[c][j];
+          acc[k] += sign * a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- G = A_T - A_S, loss partial (utils.py:178-183) ----
+  float sq = 0.f, unused = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSmallM * kSmallM / kThreads; ++k) {
+    const int p = t + k * kThreads;
+    if (p < npairs) {
+      Gs[p / M][p % M] = acc[k];
+      sq += acc[k] * acc[k];
+    }
+  }
+  block_sum2(sq, unused, red);       // contains a __syncthreads(): Gs is complete afterwards
+  if (t == 0) part[b] = sq;
+  if (dpooled == nullptr) return;
+  __syncthreads();
+  // ---- dP[c][m] = coef * sum_n Fhat_S[c][n] G[n][m] / norm_S[m] ----
+  float *out = dpooled + (int64_t)b * Cs * M;
+  for (int e = t; e < Cs * M; e += kThreads) {
+    const int c = e / M, m = e - c * M;
+    float a = 0.f;
+    for (int n = 0; n < M; ++n) a += (S[(int64_t)c * M + n] / nrm[0][n]) * Gs[n][m];
+    out[e] = coef * a / nrm[0][m];
+  }
+}
+
 }  // namespace
 }  // namespace skd
 
@@ -548,6 +642,21 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *f
   pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B), dim3(kThreads), kGemmLds, as_stream(stream)>>>(
       fhat_s_t, G, norm_s, grad_loss, dpooled, Cs, M, ldm, ldc, ntm, coef);
   return ok();
+}
+
+
+// Whole similarity loss for small graphs (M <= 64) in one launch per call (+ the deterministic final sum):
+// pooled_s (B, Cs, M), pooled_t (B, Ct, M) -> loss[0] = sum (A_T - A_S)^2 / M^2 / B and, when dpooled != NULL,
+// dpooled (B, Cs, M) = dloss / dpooled_s (for an upstream gradient of 1; utils.py:170-183 with the norm detached).
+// workspace: B floats.
+int skd_pairwise_small(int B, int Cs, int Ct, int M, const float *pooled_s, const float *pooled_t, float *loss,
+                       float *dpooled, float *workspace, skd_stream_t stream) {
+  if (B <= 0 || Cs <= 0 || Ct <= 0 || M <= 0 || M > kSmallM || !pooled_s || !pooled_t || !loss || !workspace) return 0;
+  hipStream_t st = as_stream(stream);
+  const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
+  pairwise_small_kernel<<<dim3((unsigned)B), dim3(kThreads), 0, st>>>(pooled_s, pooled_t, workspace, dpooled, Cs, Ct, M, coef);
+  if (!ok()) return 0;
+  return launch_final_sum(workspace, B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
 }
 
 }  // extern "C"

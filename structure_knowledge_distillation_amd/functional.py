@@ -413,6 +413,25 @@ class _PairWise(Function):
         m = oh * ow
         lib, st = _lib.get(), _lib.stream_of(feat_s)
         need = ctx.needs_input_grad[0]
+        if m <= 64:
+            # small graphs (the reference default pools to 3 x 3 = 9 nodes): pool, then ONE fused launch for
+            # normalise + both Grams + loss + gradient w.r.t. the pooled student features
+            p_s, p_t = feat_s.new_empty((b, cs, m)), feat_s.new_empty((b, ct, m))
+            index = torch.empty((b, cs, m), dtype=torch.int32, device=feat_s.device) if need else None
+            _lib.check(lib.skd_maxpool_argmax(b * cs, h, w, kh, kw, feat_s.data_ptr(), p_s.data_ptr(), _lib.ptr(index), st),
+                       "skd_maxpool_argmax")
+            _lib.check(lib.skd_maxpool_argmax(b * ct, h, w, kh, kw, feat_t.data_ptr(), p_t.data_ptr(), None, st),
+                       "skd_maxpool_argmax")
+            loss = feat_s.new_empty(())
+            dp = feat_s.new_empty((b, cs, m)) if need else None
+            ws = feat_s.new_empty((b,))
+            _lib.check(lib.skd_pairwise_small(b, cs, ct, m, p_s.data_ptr(), p_t.data_ptr(), loss.data_ptr(), _lib.ptr(dp),
+                                              ws.data_ptr(), st), "skd_pairwise_small")
+            ctx.geom = (b, cs, h, w, kh, kw, m, 0, 0)
+            ctx.small = True
+            ctx.save_for_backward(dp, index)
+            return loss
+        ctx.small = False
         ldm = lib.skd_pairwise_ldm(m)
         ldc = -(-cs // 128) * 128
         p_s = feat_s.new_empty((b, cs, m))
@@ -444,6 +463,17 @@ class _PairWise(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gl):
+        if ctx.small:
+            dp, index = ctx.saved_tensors
+            if dp is None:
+                return None, None, None, None
+            b, cs, h, w, kh, kw, m, _, _ = ctx.geom
+            lib, st = _lib.get(), _lib.stream_of(dp)
+            dpg = dp * gl.to(torch.float32)
+            dx = dp.new_empty((b, cs, h, w))
+            _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dpg.data_ptr(), m, index.data_ptr(), dx.data_ptr(), st),
+                       "skd_maxunpool_scatter")
+            return dx, None, None, None
         fh_s_t, g, norm_s, index = ctx.saved_tensors
         if g is None:
             return None, None, None, None

@@ -534,6 +534,32 @@ def test_pairwise_stages(hip, ref, B, Cs, Ct, M):
     close(h[6][..., :M], 0.5 * x.grad.float(), 5e-5, "dpooled vs autograd", floor=1.0 if M == 1 else 1e-6)
 
 
+@pytest.mark.parametrize("B,Cs,Ct,M", [(8, 128, 512, 9), (2, 16, 40, 9), (3, 128, 512, 64), (2, 130, 70, 25), (1, 5, 3, 1), (2, 128, 512, 6)])
+def test_pairwise_small_m_fused(hip, ref, B, Cs, Ct, M):
+    """The one-launch small-graph entry (reference default: 3 x 3 = 9 nodes) against the C oracle's staged pipeline and
+    against fp64 autograd of utils.py:170-183."""
+    g = torch.Generator().manual_seed(M * 7 + Cs)
+    ps, pt = torch.randn(B, Cs, M, generator=g), torch.randn(B, Ct, M, generator=g)
+    lr, dr = torch.empty(1), torch.empty(B, Cs, M)
+    assert ref.skd_pairwise_small(B, Cs, Ct, M, P(ps), P(pt), P(lr), P(dr), P(torch.empty(B)), None)
+    lg, dg = torch.empty(1, device=DEV), torch.full((B, Cs, M), 9.0, device=DEV)
+    ws = torch.empty(B, device=DEV)
+    assert hip.skd_pairwise_small(B, Cs, Ct, M, P(gpu(ps)), P(gpu(pt)), P(lg), P(dg), P(ws), None)
+    close(lg, lr, 1e-5, "loss", floor=1e-6)
+    close(dg, dr, 5e-5, "dpooled", floor=1.0 if M == 1 else 1e-6)
+    lg2 = torch.empty(1, device=DEV)
+    assert hip.skd_pairwise_small(B, Cs, Ct, M, P(gpu(ps)), P(gpu(pt)), P(lg2), None, P(ws), None)      # loss only
+    assert float(lg2) == float(lg)
+    x = ps.double().requires_grad_(True)
+    fh = x / ((x ** 2).sum(1, keepdim=True).sqrt() + 1e-8).detach()
+    th = pt.double() / ((pt.double() ** 2).sum(1, keepdim=True).sqrt() + 1e-8)
+    L = ((torch.einsum("icm,icn->imn", th, th) - torch.einsum("icm,icn->imn", fh, fh)) ** 2).sum() / M ** 2 / B
+    L.backward()
+    close(lg, L.detach().reshape(1).float(), 1e-5, "loss vs autograd", floor=1e-6)
+    close(dg, x.grad.float(), 5e-5, "dpooled vs autograd", floor=1.0 if M == 1 else 1e-6)
+    assert hip.skd_pairwise_small(B, Cs, Ct, 65, P(gpu(ps)), P(gpu(pt)), P(lg2), None, P(ws), None) == 0  # M > 64: the MFMA path
+
+
 @pytest.mark.parametrize("h,w", [(64, 304), (128, 1024), (256, 2048), (512, 4096), (7, 5), (1, 1), (33, 1000)])
 def test_spectral_norm(hip, ref, h, w):
     g = torch.Generator().manual_seed(h)
