@@ -323,6 +323,20 @@ int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, fl
                 skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * 11. 1x1 convolution + eval-mode InPlace-ABN (+ residual) + activation as one fp32-MFMA GEMM (frozen teacher,
+ *     networks/pspnet_combine.py:65-84).  Channels-last operands:
+ *       out[m][n] = act( ((sum_k x[m][k] * w[n][k] - mean[n]) * invstd[n]) * (|weight[n]| + eps) + bias[n] [+ residual[m][n]] )
+ *     x (M, K) = (B*H*W, Cin); w (N, K) = the (Cout, Cin, 1, 1) convolution weight; residual / out (M, N); mean / var =
+ *     the running statistics; weight / bias may be NULL (gamma 1, beta 0); activation: SKD_ACT_NONE / RELU / LEAKY_RELU.
+ *     skd_conv1x1_abn_supported(): K % 64 == 0 and N % 128 == 0 (every stride-1 1x1 convolution of the ResNet101
+ *     teacher except the two with 64 output channels); other problems stay on convolution + skd_abn_apply_nhwc.
+ * ---------------------------------------------------------------------------------- */
+int skd_conv1x1_abn_supported(int64_t M, int K, int N);
+int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                         const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                         int activation, float slope, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210
  *     (CSDataSet.__getitem__ after the PNG decode), one launch per batch:
  *       label = lut[label] (id -> trainId, datasets.py:143-148,162-171); image / label resized by f (cv2.resize,

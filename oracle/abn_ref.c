@@ -496,3 +496,30 @@ int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weig
   if (rm && rv) skd_abn_update_running(C, rm, rv, mean, var, momentum, n, st);
   return 1;
 }
+
+/* ---- 1x1 convolution + eval-mode ABN (+ residual) + activation, channels-last (include/skd.h section 11):
+ *      the convolution as a plain dot product in double, then the forward formula of bn.cu:146-159 ---- */
+int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % 64 == 0 && N % 128 == 0; }
+
+int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                         const float *mean, const float *var, const float *weight, const float *bias, float eps, int act,
+                         float slope, stream_t st) {
+  (void)st;
+  if (!skd_conv1x1_abn_supported(M, K, N) || !x || !w || !out || !mean || !var) return 0;
+  if (act != ACT_NONE && act != ACT_RELU && act != ACT_LEAKY) return 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double a = 0.0;
+      for (int k = 0; k < K; ++k) a += (double)x[m * K + k] * (double)w[(int64_t)n * K + k];
+      const float conv = (float)a;
+      const float is = (var[n] != 0.f || eps != 0.f) ? 1.f / sqrtf(var[n] + eps) : 0.f;
+      const float ga = weight ? fabsf(weight[n]) + eps : 1.f, be = bias ? bias[n] : 0.f;
+      float z = ((conv - mean[n]) * is) * ga + be;
+      if (residual) z += residual[m * N + n];
+      if (act == ACT_RELU) z = z < 0.f ? 0.f : z;
+      if (act == ACT_LEAKY) z = z < 0.f ? z * slope : z;
+      out[m * N + n] = z;
+    }
+  return 1;
+}

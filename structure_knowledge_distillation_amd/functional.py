@@ -260,6 +260,43 @@ def ppm_concat(priors, feats):
     return _PPMConcat.apply(feats, *priors)
 
 
+def conv1x1_abn_supported(x, conv):
+    """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
+    input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 64 and Cout of 128."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None and conv.weight.dtype == torch.float32):
+        return False
+    m = x.shape[0] * x.shape[2] * x.shape[3]
+    return bool(_lib.get().skd_conv1x1_abn_supported(m, conv.in_channels, conv.out_channels))
+
+
+def conv1x1_abn_eval(x, conv_weight, running_mean, running_var, weight, bias, eps=1e-5, activation="relu", slope=0.01,
+                     residual=None):
+    """act(bn_running(conv1x1(x)) [+ residual]) as ONE fp32-MFMA GEMM with the normalisation in its epilogue (inference
+    only; networks/pspnet_combine.py:65-84 for the frozen teacher).  x (B, Cin, H, W) and residual / result
+    (B, Cout, H, W) in channels-last memory; conv_weight (Cout, Cin, 1, 1)."""
+    if torch.is_grad_enabled() and (x.requires_grad or conv_weight.requires_grad):
+        raise RuntimeError("conv1x1_abn_eval is inference-only")
+    _lib.require_device(x, conv_weight, running_mean, running_var, weight, bias, residual)
+    act = {"none": 0, "leaky_relu": 1, "relu": 3}[activation]
+    b, k, h, w = x.shape
+    n = conv_weight.shape[0]
+    out = _new_cl(x, b, n, h, w)
+    if residual is not None:
+        residual = _cl(residual)
+        if tuple(residual.shape) != (b, n, h, w):
+            raise ValueError("residual shape %s != output shape %s" % (tuple(residual.shape), (b, n, h, w)))
+    wt = conv_weight.reshape(n, k)      # (N, K, 1, 1): the same memory in NCHW and channels-last
+    if not wt.is_contiguous():
+        wt = wt.contiguous()
+    _lib.check(_lib.get().skd_conv1x1_abn_nhwc(b * h * w, k, n, x.data_ptr(), wt.data_ptr(), _lib.ptr(residual), out.data_ptr(),
+                                               running_mean.data_ptr(), running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                                               float(eps), act, float(slope), _lib.stream_of(x)), "skd_conv1x1_abn_nhwc")
+    return out
+
+
 def seg_confusion(logits, target=None, ignore_index=255, confusion=None, want_pred=True):
     """Evaluation tail (networks/evaluate.py:106-113, 186-198): bilinear (align_corners) upsample of ``logits``
     (B, C, h, w) to the size of ``target`` (B, H, W) [or of ``want_pred`` = (H, W) when no target], argmax over the

@@ -789,3 +789,39 @@ def _pa_torch(fs, ft, k):
         f = f.reshape(f.shape[0], f.shape[1], -1)
         return torch.einsum("icm,icn->imn", f, f)
     return ((sim(pt) - sim(ps)) ** 2).sum() / (pt.shape[-1] * pt.shape[-2]) ** 2 / pt.shape[0]
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 1024, 256), (129, 2048, 512), (128, 128, 128)])
+@pytest.mark.parametrize("act,with_res", [(3, True), (3, False), (0, False), (1, True)])
+def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
+    """1x1 convolution + eval-mode ABN (+ residual) + activation as one fp32-MFMA GEMM vs the C oracle (double dot
+    product, then the bn.cu forward formula)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    r = torch.randn(M, N, generator=g) if with_res else None
+    mean, var = torch.randn(N, generator=g) * 0.3, torch.rand(N, generator=g) + 0.5
+    ga, be = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    o_r, o_g = torch.empty(M, N), torch.full((M, N), 7.0, device=DEV)
+    assert ref.skd_conv1x1_abn_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, act, 0.01, None)
+    assert hip.skd_conv1x1_abn_nhwc(M, K, N, P(gpu(x)), P(gpu(w)), P(gpu(r)), P(o_g), P(gpu(mean)), P(gpu(var)), P(gpu(ga)), P(gpu(be)), 1e-5, act, 0.01, None)
+    close(o_g, o_r, 2e-5, "conv1x1+abn")
+    assert hip.skd_conv1x1_abn_supported(M, K, N) == 1 and hip.skd_conv1x1_abn_supported(M, K + 32, N) == 0 and hip.skd_conv1x1_abn_supported(M, K, N + 64) == 0
+    assert hip.skd_conv1x1_abn_nhwc(M, K + 32, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
+
+
+def test_conv1x1_abn_gemm_full_size_vs_conv2d():
+    """The teacher's layer3 block tail at batch 8 (M = 33800, K = 256, N = 1024) against conv2d + the fused ABN pass."""
+    from structure_knowledge_distillation_amd import functional as SF
+    from structure_knowledge_distillation_amd.libs import inplace_abn as IA
+    torch.manual_seed(0)
+    x = torch.randn(8, 256, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(8, 1024, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(256, 1024, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    rm, rv = torch.randn(1024, device=DEV) * 0.1, torch.rand(1024, device=DEV) + 0.5
+    w, b = torch.randn(1024, device=DEV), torch.randn(1024, device=DEV)
+    with torch.no_grad():
+        assert SF.conv1x1_abn_supported(x, conv)
+        got = SF.conv1x1_abn_eval(x, conv.weight, rm, rv, w, b, 1e-5, "relu", 0.01, res)
+        want = IA.abn_eval_fused(conv(x), w, b, rm, rv, 1e-5, "relu", 0.01, res)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    close(got, want, 2e-5, "fused GEMM vs conv2d + ABN pass")
