@@ -7,6 +7,7 @@ and ``forward`` returns the same 7-element list ``[logits, dsn, feat_after_psp, 
 the hand-written InPlace-ABN of csrc/abn.hip (``libs``), applied in place on the conv output.
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,15 @@ def _fused(module, x):
     (eval + no_grad, kd_model.py:121-122), out of place with batch statistics for the training student.
     Eval mode WITH a graph (rare) and non-fp32 inputs take the reference's op sequence."""
     return x.dtype == torch.float32 and (module.training or not torch.is_grad_enabled())
+
+
+def _gemm_tail(x):
+    """SKD_TEACHER_GEMM=1: run the frozen network's stride-1 1x1 convolutions + BN (+ residual) + ReLU as ONE
+    fp32-MFMA GEMM (csrc/conv1x1.hip) instead of MIOpen convolution + the in-place ABN pass.  OFF by default: measured
+    on this MIOpen build (tools/conv1x1_bench.py, profiles/r02*_conv1x1_ab.jsonl) the fused GEMM wins only on the three
+    widest problems (K >= 512 and N >= 1024: 1.01-1.06x) and loses on the K = 256 block tails that dominate the teacher
+    (0.77x), for +2.8 ms per teacher forward overall; MIOpen's own conv+bias+ReLU fusion is a naive kernel here (100x+)."""
+    return (os.environ.get("SKD_TEACHER_GEMM", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -76,9 +86,17 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if _fused(self, x):
-            out = self.bn1.forward_relu(self.conv1(x))
+            gemm = not self.training and _gemm_tail(x)
+            if gemm and SF.conv1x1_abn_supported(x, self.conv1):
+                out = SF.conv1x1_abn_eval(x, self.conv1.weight, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight,
+                                          self.bn1.bias, self.bn1.eps, "relu")
+            else:
+                out = self.bn1.forward_relu(self.conv1(x))
             out = self.bn2.forward_relu(self.conv2(out))
             residual = self.downsample(x) if self.downsample is not None else x
+            if gemm and SF.conv1x1_abn_supported(out, self.conv3):
+                return SF.conv1x1_abn_eval(out, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
+                                           self.bn3.bias, self.bn3.eps, "relu", residual=residual)
             return self.bn3.forward_relu(self.conv3(out), residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))

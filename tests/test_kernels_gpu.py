@@ -812,7 +812,8 @@ def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
 def test_conv1x1_abn_gemm_full_size_vs_conv2d():
     """The teacher's layer3 block tail at batch 8 (M = 33800, K = 256, N = 1024) against conv2d + the fused ABN pass."""
     from structure_knowledge_distillation_amd import functional as SF
-    from structure_knowledge_distillation_amd.libs import inplace_abn as IA
+    import importlib
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
     torch.manual_seed(0)
     x = torch.randn(8, 256, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
     res = torch.randn(8, 1024, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)

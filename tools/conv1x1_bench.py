@@ -23,7 +23,8 @@ SHAPES = [  # (Cin, Cout, HW, count per teacher forward, residual?)
 def main():
     import torch
     from structure_knowledge_distillation_amd import _lib, functional as SF
-    from structure_knowledge_distillation_amd.libs import inplace_abn as IA
+    import importlib
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
     _lib.load()
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     dev = torch.device("cuda", 0)
