@@ -16,7 +16,7 @@ for sec in "$@"; do
       stamp "tests_new rc=$?"; grep -E "passed|failed|error" $O/pytest_new.log | tail -3 | tee -a $O/session.log
       grep -E "worst|B=8 |config1 " $O/pytest_new.log | tee -a $O/session.log ;;
     tests_all)
-      timeout 1500 python -m pytest tests -m gpu -q --tb=short -s > $O/pytest_gpu.log 2>&1
+      timeout 1500 python -m pytest tests -m gpu -q --tb=short -s --durations=12 > $O/pytest_gpu.log 2>&1
       stamp "tests_all rc=$?"; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 | tee -a $O/session.log
       grep -E "worst|B=8 |config1 " $O/pytest_gpu.log | tee -a $O/session.log ;;
     smoke)
@@ -71,6 +71,9 @@ EOF
         python $R/tools/conv_table.py 10 > $O/conv_table.jsonl 2> $O/conv_table.err)
       stamp "conv rc=$?"; tail -1 $O/conv_table.jsonl | tee -a $O/session.log
       python tools/summarise_conv_table.py $O/conv_table.jsonl $O/prof_conv $O/conv_shapes.md >> $O/session.log 2>&1 ;;
+    c11)
+      timeout 300 python tools/conv1x1_bench.py 20 > $O/conv1x1_ab.jsonl 2> $O/conv1x1_ab.err
+      stamp "c11 rc=$?"; tail -1 $O/conv1x1_ab.jsonl | tee -a $O/session.log ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
