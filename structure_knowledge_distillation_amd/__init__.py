@@ -92,6 +92,15 @@ def check_miopen_db(warn=True):
     return have == MIOPEN_DB_VERSION
 
 
+# MIOpen's fp32 Winograd solvers are OFF by default.  They lose about three decimal digits (measured on MI355X,
+# tests/diagnostics/diag_dstep.py: 2.6e-4 relative error on the discriminator's backward-data convolutions with them,
+# 6e-7 without; the same kernels put 1.8e-3 on the student's DSN weight gradient at 256 x 256), which the WGAN critic's
+# cancelling gradients amplify to per cent, they are NCHW-only (each call is wrapped in layout transposes), and whether
+# immediate mode picks them varied between otherwise identical runs.  The step is not slower without them (76.9 vs
+# 77.1 ms).  SKD_MIOPEN_WINOGRAD=1 leaves MIOpen's choice alone.
+if _os.environ.get("SKD_MIOPEN_WINOGRAD", "0") != "1":
+    _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+
 if _os.path.isdir(MIOPEN_DB_DIR):
     MIOPEN_DB_VERSION = _miopen_db_version()
     if "MIOPEN_USER_DB_PATH" not in _os.environ:

@@ -6,12 +6,11 @@ Tolerances:
   losses mc / pi / pa / G           <= 1e-4 relative (north_star); observed ~1e-6
   D loss (contains the WGAN-GP double backward)   <= 1e-4 relative
   running statistics                 <= 1e-5 relative
-  parameter gradients                error vs the fp64 oracle <= 8x the error of the fp32 CPU oracle vs the
-                                     fp64 oracle for the same tensor, + 1e-3 of the tensor's norm.  Backbone
-                                     gradients are ill-conditioned at random init (BN-projection amplification,
-                                     SURVEY.md section 4: CPU fp32 vs fp64 already differ by 5e-3..1e-2), and
-                                     MIOpen's tuned fp32 solvers include Winograd, whose transforms round ~10x
-                                     coarser than a direct sum.  A wrong formula shows up as O(1), not O(1e-3).
+  parameter gradients                ONE bound everywhere: error vs the fp64 oracle <= GRAD_BOUND (3) x the error of
+                                     the fp32 CPU oracle vs the fp64 oracle for the same tensor + GRAD_FLOOR (5e-3) of
+                                     the tensor's norm -- see the comment at GRAD_FLOOR for where the floor comes
+                                     from (measured run-to-run noise of MIOpen's atomic split-K kernels) and the
+                                     "worst five" tables the tests print.  A wrong formula shows up as O(1).
   second step                        the first step's update has diverged the weights at that level, so its
                                      losses are compared at 4x the fp32-CPU-oracle deviation (floor 1e-4)
 """
@@ -179,7 +178,7 @@ def test_discriminator_step_vs_oracle():
         assert got is not None, k
         base = float((g32[k].double() - gw).norm())
         err = float((got.detach().cpu().double() - gw).norm())
-        assert err <= 8 * base + 2e-4 * float(gw.norm()) + 1e-9, (k, err, base, float(gw.norm()))
+        assert err <= GRAD_BOUND * base + GRAD_FLOOR * float(gw.norm()) + 1e-9, (k, err, base, float(gw.norm()))   # the ONE bound, below
     after = D.state_dict()
     for k in P64:
         if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
@@ -261,7 +260,9 @@ def test_full_step_vs_oracle(ho):
         for k, gw in o64["grads_S"].items():
             base = float((o32["grads_S"][k].double() - gw).norm())
             err = float((gS[k].double() - gw).norm())
-            assert err <= 8 * base + 1e-3 * float(gw.norm()) + 1e-6, (step, k, err, base, float(gw.norm()))
+            # first step: the ONE bound (GRAD_BOUND / GRAD_FLOOR below); second step: the weights have already moved apart
+            # by the first update at that level, so the comparison widens to 8 x the CPU-fp32 deviation
+            assert err <= (GRAD_BOUND if step == 0 else 8.0) * base + GRAD_FLOOR * float(gw.norm()) + 1e-6, (step, k, err, base, float(gw.norm()))
             worst = max(worst, err / (float(gw.norm()) + 1e-12))
         after = model.student.state_dict()
         for k in PS64:
@@ -287,7 +288,15 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # tensor's norm (tensors the CPU happens to get almost exactly -- biases of 19 channels, BN vectors -- have a base
 # error near zero).  The tests print the worst observed ratio so the bound can be audited from the log.
 GRAD_BOUND = 3.0
-GRAD_FLOOR = 2e-3
+GRAD_FLOOR = 5e-3
+# Why 5e-3 and not less: MIOpen's fastest fp32 weight-gradient / backward-data kernels on gfx950 split K over
+# workgroups and combine the partial sums with fp32 ATOMIC adds (the "gkgs" igemm kernels), i.e. in an order that
+# changes from run to run.  On the ill-conditioned pre-BN gradients of this model (partial sums ~1e4 x the result)
+# that alone moved single tensors by 1e-3 ... 3e-3 of their norm between otherwise identical runs on the same box
+# (dsn.0.weight at 256 x 256: 4e-6 / 9.7e-4 / 1.77e-3 in four consecutive runs; D's first layer: 6e-7 / 3e-3), while
+# the CPU fp32 oracle, with its fixed summation order, sits at 4e-6 for the same tensor.  Every tensor whose CPU error
+# is not tiny stays within ~0.5 of the 3 x base part of the bound.  The formulas themselves are pinned tightly where
+# the critic's convolutions run on PyTorch's im2col + rocBLAS path instead (test_full_step_b8_vs_golden, last part).
 
 
 def _load_oracle_weights(model, PS, PT, PD=None):
@@ -370,7 +379,7 @@ def test_full_step_b8_vs_golden():
     # teacher's logit differences, which the WGAN critic amplifies (-mean D(T) + mean D(S) cancels to a few per cent of
     # either term), so that comparison is reported with its own bound; the D STEP ITSELF is pinned by re-running the
     # fp64 / fp32 oracle's discriminator step on the very logits the GPU produced.
-    cast = lambda P, dt: {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    cast = lambda P, dt: {k: (v.detach().clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in P.items()}   # never alias PD
     pS_gpu, pT_gpu = model.preds_S[0].detach().cpu(), model.preds_T[0].detach().cpu()
     cfg = O.StepConfig(weight_decay=gold["cfg"]["weight_decay"], lambda_pa=gold["cfg"]["lambda_pa"], dropout_p=0.0)
     ref = {}
@@ -384,6 +393,24 @@ def test_full_step_b8_vs_golden():
     assert abs(model.D_loss - ref["f64"][0]) <= 1e-5 * abs(ref["f64"][0]), (model.D_loss, ref["f64"][0])
     _report("B=8 discriminator step on the GPU's own logits",
             [(k, float((gD[k].cpu().double() - g).norm()), float((ref["f32"][1][k].double() - g).norm()), float(g.norm()))
+             for k, g in ref["f64"][1].items() if g is not None and float(g.norm()) > 1e-12], GRAD_BOUND, GRAD_FLOOR)
+    # The same D step once more with the convolutions on PyTorch's own im2col + rocBLAS path (MIOpen off): every
+    # hand-written kernel and every formula of the critic step (spectral norm incl. the u / v rebinding quirk, attention,
+    # WGAN-GP double backward) against the fp64 oracle at 1e-5 -- what remains above is the atomic split-K noise of
+    # MIOpen's fast convolution kernels.
+    D2 = sagan_models.Discriminator(1, 19, B, 65, 64).to(DEV).train()
+    D2.load_state_dict({k: v.clone() for k, v in PD.items()})
+    with torch.backends.cudnn.flags(enabled=False):
+        with torch.no_grad():
+            D2(pS_gpu.to(DEV))                                                     # the G step's critic forward
+        d_t2, d_s2 = D2(pT_gpu.to(DEV)), D2(pS_gpu.to(DEV))
+        loss2 = cfg.lambda_d * C.CriterionAdv("wgan-gp")(d_s2, d_t2) + cfg.lambda_d * C.CriterionAdditionalGP(D2, cfg.lambda_gp)(
+            [pS_gpu.to(DEV)], [pT_gpu.to(DEV)], alpha=alpha.to(DEV))
+        loss2.backward()
+    assert abs(float(loss2) - ref["f64"][0]) <= 1e-5 * abs(ref["f64"][0])
+    g2 = {k: p.grad for k, p in D2.named_parameters() if p.grad is not None}
+    _report("B=8 discriminator step, convolutions on the im2col + rocBLAS path",
+            [(k, float((g2[k].cpu().double() - g).norm()), float((ref["f32"][1][k].double() - g).norm()), float(g.norm()))
              for k, g in ref["f64"][1].items() if g is not None and float(g.norm()) > 1e-12], GRAD_BOUND, 1e-5)
     _check_grads(gD, gold["grads_D"], "B=8 discriminator gradients end to end (informative bound)", bound=10.0, floor=2e-2)
     after = model.student.state_dict()
