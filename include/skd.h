@@ -305,6 +305,22 @@ int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int n
                                  const float *gcat, float *const *gpriors, float *gfeats, float *workspace,
                                  skd_stream_t stream);
 
+/* The pyramid priors folded THROUGH the 3x3 bottleneck convolution (networks/pspnet_combine.py:104-111: the
+ * concatenation, the up-sampling of the priors and the convolution over their channels are all linear):
+ *     bottleneck_conv(cat(up(prior_1..L), feats)) = conv3x3(feats; W[:, L*Cm:]) + fold(Z_1..L)
+ *     Z_k (B, s_k, s_k, 9, Cout) = prior_k (B*s_k^2, Cm) x W[:, k*Cm:(k+1)*Cm] rearranged to (Cm, 9*Cout)   (caller's GEMM)
+ *     fold[b][y][x][co] = sum_{k, tap (ty, tx) with (y + ty - 1, x + tx - 1) inside the map}
+ *                         bilinear_{align_corners}(Z_k[b][.][.][tap][co]) at (y + ty - 1, x + tx - 1)
+ * skd_ppm_fold_nhwc ADDS fold to `out` (B, H, W, Cout) in place (out holds the feature-map part of the convolution);
+ * skd_ppm_fold_backward_nhwc writes gz_k = d loss / d Z_k from gout = d loss / d out (the gradient w.r.t. the
+ * feature-map part is gout itself).  3x3 kernel, padding 1, stride 1, dilation 1; Cout % 4 == 0;
+ * 3 * sum_k s_k <= 64 (LDS).  workspace: skd_ppm_fold_nhwc_workspace_floats() floats (backward only). */
+int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int nsizes, const int *sizes);
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
+                      skd_stream_t stream);
+int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
+                               float *const *gz, float *workspace, skd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * 9. Whole-image evaluation tail, networks/evaluate.py:106-113, 186-206:
  *      up = bilinear upsample (h,w) -> (H,W), align_corners=True;  pred = argmax_c up (first maximum, uint8);

@@ -564,6 +564,87 @@ int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int n
   return r;
 }
 
+/* ---- pyramid priors folded through the 3x3 bottleneck convolution (include/skd.h section 8; the identity
+ * conv3x3(cat(up(priors), feats)) = conv3x3(feats) + fold(Z) of networks/pspnet_combine.py:104-111), evaluated here
+ * by its definition: every tap reads the bilinear interpolation of its own Z map at the shifted position. ---- */
+int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int nsizes, const int *sizes) {
+  (void)H; (void)W; (void)sizes;
+  if (B <= 0 || Cout <= 0 || nsizes <= 0) return 0;
+  return 4;
+}
+
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
+                      stream_t st) {
+  (void)st;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !z || !out || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  for (int k = 0; k < nsizes; ++k)
+    if (!z[k] || sizes[k] <= 0) return 0;
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float *o = out + (((int64_t)b * H + y) * W + x) * Cout;
+        for (int c = 0; c < Cout; ++c) {
+          double acc = (double)o[c];
+          for (int k = 0; k < nsizes; ++k) {
+            const int s = sizes[k];
+            const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+            const float *zk = z[k] + (int64_t)b * s * s * 9 * Cout;
+            for (int ty = 0; ty < 3; ++ty)
+              for (int tx = 0; tx < 3; ++tx) {
+                const int yp = y + ty - 1, xp = x + tx - 1;
+                if (yp < 0 || yp >= H || xp < 0 || xp >= W) continue;
+                int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+                tap_of(yp, sy, s, &y0, &y1, &ly0, &ly1);
+                tap_of(xp, sx, s, &x0, &x1, &lx0, &lx1);
+                const int tap = ty * 3 + tx;
+#define ZAT(jy, jx) ((double)zk[(((int64_t)(jy) * s + (jx)) * 9 + tap) * Cout + c])
+                acc += (double)ly0 * ((double)lx0 * ZAT(y0, x0) + (double)lx1 * ZAT(y0, x1)) +
+                       (double)ly1 * ((double)lx0 * ZAT(y1, x0) + (double)lx1 * ZAT(y1, x1));
+#undef ZAT
+              }
+          }
+          o[c] = (float)acc;
+        }
+      }
+  return 1;
+}
+
+int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
+                               float *const *gz, float *ws, stream_t st) {
+  (void)st; (void)ws;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !gout || !gz || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
+  for (int k = 0; k < nsizes; ++k) {
+    if (!gz[k] || sizes[k] <= 0) return 0;
+    const int s = sizes[k];
+    const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+    const int64_t n = (int64_t)B * s * s * 9 * Cout;
+    double *acc = (double *)calloc((size_t)n, sizeof(double));
+    if (!acc) return 0;
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          const float *g = gout + (((int64_t)b * H + y) * W + x) * Cout;
+          for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx) {
+              const int yp = y + ty - 1, xp = x + tx - 1;
+              if (yp < 0 || yp >= H || xp < 0 || xp >= W) continue;
+              int yy[2], xx[2]; float ly[2], lx[2];
+              tap_of(yp, sy, s, &yy[0], &yy[1], &ly[0], &ly[1]);
+              tap_of(xp, sx, s, &xx[0], &xx[1], &lx[0], &lx[1]);
+              for (int a = 0; a < 2; ++a)
+                for (int d = 0; d < 2; ++d) {
+                  double *dst = acc + ((((int64_t)b * s + yy[a]) * s + xx[d]) * 9 + ty * 3 + tx) * Cout;
+                  const double wt = (double)ly[a] * (double)lx[d];
+                  for (int c = 0; c < Cout; ++c) dst[c] += wt * (double)g[c];
+                }
+            }
+        }
+    for (int64_t i = 0; i < n; ++i) gz[k][i] = (float)acc[i];
+    free(acc);
+  }
+  return 1;
+}
+
 /* ---- evaluation tail: upsample + argmax + confusion matrix, networks/evaluate.py:106-113, 136-154, 186-198 ---- */
 int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *logits, const int64_t *target,
                       int ignore_index, uint8_t *pred, int64_t *confusion, stream_t st) {

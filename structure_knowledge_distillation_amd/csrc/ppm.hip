@@ -513,6 +513,163 @@ __global__ __launch_bounds__(kThreads) void ppm_concat_bwd_cols_nhwc_kernel(cons
   }
 }
 
+
+// ---- pyramid priors folded through the 3x3 bottleneck convolution (channels-last) ---------------------------------
+// bottleneck(cat(up(prior_1) .. up(prior_L), feats)) is linear in every input, and up(prior_k) is a bilinear function
+// of s_k x s_k values, so  conv3x3(cat) = conv3x3(feats; W_feats) + sum_k fold_k  with
+//     Z_k[b][jy][jx][tap][co] = sum_ci prior_k[b][jy][jx][ci] * W[co][k*Cm + ci][tap]          (a (B s^2) x Cm x 9 Cout GEMM)
+//     fold_k[b][y][x][co]     = sum_{tap = (ty, tx), (y', x') = (y + ty - 1, x + tx - 1) inside the map}
+//                               sum_{jy in taps(y'), jx in taps(x')} ly(y', jy) * lx(x', jx) * Z_k[b][jy][jx][tap][co]
+// (zero padding = taps outside the map dropped).  Half of the bottleneck's input channels (2048 of 4096 in the teacher,
+// 512 of 1024 in the student) never meet the convolution: 638 GFLOP per teacher forward at batch 8 become a 1.9 GFLOP
+// GEMM plus this kernel, and the concatenated tensor (554 MB) is never written.
+// Separable evaluation: a thread owns one (b, x, channel quad) column; it first contracts the x direction into
+// T[ty][jy] (3 * sum_k s_k float4 entries, kept in LDS as private indexed storage -- no sharing, no barriers), then walks
+// down y adding <= 6 entries per level to the convolution output in place.
+constexpr int kFoldThreads = 64;
+
+struct FoldPtrs {
+  const float *z[kMaxLevels];
+};
+struct FoldGradPtrs {
+  float *z[kMaxLevels];
+};
+
+__device__ __forceinline__ float4 lds_get(const float4 *t, int e) { return t[e * kFoldThreads + threadIdx.x]; }
+
+__global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp, float *__restrict__ out, int B, int H,
+                                                                     int W, int C4, int ychunk, Levels lv) {
+  extern __shared__ __attribute__((aligned(16))) float4 tcol[];  // [3 * lv.rows][kFoldThreads]
+  const int64_t col = (int64_t)blockIdx.x * kFoldThreads + threadIdx.x;
+  if (col >= (int64_t)B * W * C4) return;
+  const int q = (int)(col % C4), x = (int)((col / C4) % W), b = (int)(col / ((int64_t)C4 * W));
+  for (int k = 0; k < lv.n; ++k) {
+    const int s = lv.size[k];
+    const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+    const float *zk = zp.z[k] + (int64_t)b * s * s * 9 * C4 * 4 + q * 4;
+    Tap tx3[3];
+    bool vx[3];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int xp = x + tx - 1;
+      vx[tx] = xp >= 0 && xp < W;
+      tx3[tx] = tap_of(vx[tx] ? xp : 0, sx, s);
+    }
+    for (int ty = 0; ty < 3; ++ty)
+      for (int jy = 0; jy < s; ++jy) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          if (vx[tx]) {
+            const float *r = zk + ((int64_t)(jy * s) * 9 + ty * 3 + tx) * C4 * 4;
+            acc = f4fma(tx3[tx].l0, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i0 * 9 * C4 * 4), acc);
+            acc = f4fma(tx3[tx].l1, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i1 * 9 * C4 * 4), acc);
+          }
+        tcol[(3 * lv.row_off[k] + ty * s + jy) * kFoldThreads + threadIdx.x] = acc;
+      }
+  }
+  const int y0 = blockIdx.y * ychunk, y1 = y0 + ychunk < H ? y0 + ychunk : H;
+  const int64_t ystride = (int64_t)W * C4 * 4;
+  float *o = out + (((int64_t)b * H + y0) * W + x) * C4 * 4 + q * 4;
+  constexpr int U = 4;
+  for (int y = y0; y < y1; y += U, o += U * ystride) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (y + u < y1) v[u] = *reinterpret_cast<const float4 *>(o + u * ystride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (y + u >= y1) break;
+      for (int k = 0; k < lv.n; ++k) {
+        const int s = lv.size[k];
+        const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int yp = y + u + ty - 1;
+          if (yp < 0 || yp >= H) continue;
+          const Tap t = tap_of(yp, sy, s);
+          const int e = 3 * lv.row_off[k] + ty * s;
+          v[u] = f4fma(t.l0, lds_get(tcol, e + t.i0), v[u]);
+          v[u] = f4fma(t.l1, lds_get(tcol, e + t.i1), v[u]);
+        }
+      }
+      *reinterpret_cast<float4 *>(o + u * ystride) = v[u];
+    }
+  }
+}
+
+// transpose, column pass: TT[b][chunk][e = (k, ty, jy)][x][c] = sum_{y in chunk} ly(y + ty - 1, jy) * g[b][y][x][c]
+__global__ __launch_bounds__(kFoldThreads) void ppm_fold_bwd_cols_nhwc_kernel(const float *__restrict__ g,
+                                                                              float *__restrict__ ws, int B, int H, int W,
+                                                                              int C4, int ychunk, Levels lv) {
+  extern __shared__ __attribute__((aligned(16))) float4 tcol[];
+  const int64_t col = (int64_t)blockIdx.x * kFoldThreads + threadIdx.x;
+  if (col >= (int64_t)B * W * C4) return;
+  const int q = (int)(col % C4), x = (int)((col / C4) % W), b = (int)(col / ((int64_t)C4 * W));
+  const int E = 3 * lv.rows;
+  for (int e = 0; e < E; ++e) tcol[e * kFoldThreads + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int y0 = blockIdx.y * ychunk, y1 = y0 + ychunk < H ? y0 + ychunk : H;
+  const int64_t ystride = (int64_t)W * C4 * 4;
+  const float *src = g + (((int64_t)b * H + y0) * W + x) * C4 * 4 + q * 4;
+  constexpr int U = 4;
+  for (int y = y0; y < y1; y += U, src += U * ystride) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (y + u < y1) v[u] = *reinterpret_cast<const float4 *>(src + u * ystride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (y + u >= y1) break;
+      for (int k = 0; k < lv.n; ++k) {
+        const int s = lv.size[k];
+        const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int yp = y + u + ty - 1;
+          if (yp < 0 || yp >= H) continue;
+          const Tap t = tap_of(yp, sy, s);
+          const int e = 3 * lv.row_off[k] + ty * s;
+          float4 *a0 = tcol + (e + t.i0) * kFoldThreads + threadIdx.x;
+          *a0 = f4fma(t.l0, v[u], *a0);
+          float4 *a1 = tcol + (e + t.i1) * kFoldThreads + threadIdx.x;
+          *a1 = f4fma(t.l1, v[u], *a1);
+        }
+      }
+    }
+  }
+  float *dst = ws + ((((int64_t)blockIdx.y * B + b) * E) * W + x) * C4 * 4 + q * 4;
+  for (int e = 0; e < E; ++e) *reinterpret_cast<float4 *>(dst + (int64_t)e * W * C4 * 4) = tcol[e * kFoldThreads + threadIdx.x];
+}
+
+// transpose, bin pass: dZ_k[b][jy][jx][tap][c] = sum_chunks sum_x lx(x + tx - 1, jx) * TT[..][(k, ty, jy)][x][c], fixed order.
+// grid (lv.bins, B); items = 9 * C4
+__global__ __launch_bounds__(kThreads) void ppm_fold_bwd_bins_nhwc_kernel(const float *__restrict__ ws, FoldGradPtrs gz,
+                                                                         int B, int W, int C4, int chunks, Levels lv) {
+  const int bin = blockIdx.x, b = blockIdx.y;
+  int k = 0;
+  while (k + 1 < lv.n && bin >= lv.bin_off[k + 1]) ++k;
+  const int s = lv.size[k], j = bin - lv.bin_off[k], jy = j / s, jx = j - jy * s;
+  const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
+  const int E = 3 * lv.rows;
+  for (int item = threadIdx.x; item < 9 * C4; item += kThreads) {
+    const int tap = item / C4, q = item - tap * C4, ty = tap / 3, tx = tap - ty * 3;
+    const int e = 3 * lv.row_off[k] + ty * s + jy;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int x = 0; x < W; ++x) {
+      const int xp = x + tx - 1;
+      if (xp < 0 || xp >= W) continue;
+      const Tap t = tap_of(xp, sx, s);
+      float wt = 0.f;
+      if (t.i0 == jx) wt += t.l0;
+      if (t.i1 == jx) wt += t.l1;
+      if (wt == 0.f) continue;
+      for (int c = 0; c < chunks; ++c)
+        acc = f4fma(wt, *reinterpret_cast<const float4 *>(ws + (((((int64_t)c * B + b) * E + e) * W + x) * C4 + q) * 4), acc);
+    }
+    *reinterpret_cast<float4 *>(gz.z[k] + ((((int64_t)b * s + jy) * s + jx) * 9 + tap) * C4 * 4 + q * 4) = acc;
+  }
+}
+
 }  // namespace
 }  // namespace skd
 
@@ -664,6 +821,58 @@ int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int n
       gcat, gpriors ? workspace : nullptr, Cfeat > 0 ? gfeats : nullptr, Cout / 4, Cfeat / 4, H, W, lv);
   if (gpriors)
     ppm_concat_bwd_cols_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, gp, Cout / 4, H, lv);
+  return ok();
+}
+
+static int fold_chunks(int B, int H, int W, int C4) {
+  // ~1024 single-wave workgroups keep every CU's LDS full once; more y-chunks when the map has few columns
+  const int64_t wgs = cdiv((int64_t)B * W * C4, kFoldThreads);
+  int chunks = (int)(1024 / (wgs > 0 ? wgs : 1));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 8) chunks = 8;
+  if (chunks > H) chunks = H;
+  return chunks;
+}
+
+int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int nsizes, const int *sizes) {
+  Levels lv;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !make_levels(nsizes, sizes, lv)) return 0;
+  return (int64_t)fold_chunks(B, H, W, Cout / 4) * B * 3 * lv.rows * W * Cout;
+}
+
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
+                      skd_stream_t stream) {
+  Levels lv;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !z || !out || !make_levels(nsizes, sizes, lv)) return 0;
+  const size_t smem = sizeof(float4) * (size_t)3 * lv.rows * kFoldThreads;
+  if (smem > 64 * 1024) return 0;
+  FoldPtrs zp;
+  for (int k = 0; k < kMaxLevels; ++k) zp.z[k] = k < nsizes ? z[k] : nullptr;
+  for (int k = 0; k < nsizes; ++k)
+    if (!zp.z[k]) return 0;
+  const int C4 = Cout / 4, chunks = fold_chunks(B, H, W, C4), ychunk = (int)cdiv(H, chunks);
+  const dim3 grid((unsigned)cdiv((int64_t)B * W * C4, kFoldThreads), (unsigned)cdiv(H, ychunk));
+  ppm_fold_nhwc_kernel<<<grid, dim3(kFoldThreads), smem, as_stream(stream)>>>(zp, out, B, H, W, C4, ychunk, lv);
+  return ok();
+}
+
+int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
+                               float *const *gz, float *workspace, skd_stream_t stream) {
+  Levels lv;
+  if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !gout || !gz || !workspace) return 0;
+  if (!make_levels(nsizes, sizes, lv) || B > 65535) return 0;
+  const size_t smem = sizeof(float4) * (size_t)3 * lv.rows * kFoldThreads;
+  if (smem > 64 * 1024) return 0;
+  FoldGradPtrs gp;
+  for (int k = 0; k < kMaxLevels; ++k) gp.z[k] = k < nsizes ? gz[k] : nullptr;
+  for (int k = 0; k < nsizes; ++k)
+    if (!gp.z[k]) return 0;
+  const int C4 = Cout / 4, chunks0 = fold_chunks(B, H, W, C4), ychunk = (int)cdiv(H, chunks0);
+  const int chunks = (int)cdiv(H, ychunk);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)cdiv((int64_t)B * W * C4, kFoldThreads), (unsigned)chunks);
+  ppm_fold_bwd_cols_nhwc_kernel<<<grid, dim3(kFoldThreads), smem, st>>>(gout, workspace, B, H, W, C4, ychunk, lv);
+  ppm_fold_bwd_bins_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, gp, B, W, C4, chunks, lv);
   return ok();
 }
 

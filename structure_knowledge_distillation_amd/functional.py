@@ -260,6 +260,75 @@ def ppm_concat(priors, feats):
     return _PPMConcat.apply(feats, *priors)
 
 
+class _PPMFold(Function):
+    """base += fold(Z_1 .. Z_L) (include/skd.h section 8), in place on the channels-last convolution output `base`."""
+
+    @staticmethod
+    def forward(ctx, base, sizes, *zs):
+        _lib.require_device(base, *zs)
+        b, cout, h, w = base.shape
+        if cout % 4 or not base.is_contiguous(memory_format=torch.channels_last) or base.dtype != torch.float32:
+            raise ValueError("ppm_fold: base must be a float32 channels-last (B, Cout, H, W) tensor")
+        if len(zs) != len(sizes):
+            raise ValueError("ppm_fold: one Z per pyramid level")
+        for z, s_ in zip(zs, sizes):
+            if z.dtype != torch.float32 or not z.is_contiguous() or z.numel() != b * s_ * s_ * 9 * cout:
+                raise ValueError("ppm_fold: Z_k must be a contiguous float32 (B*s*s, 9*Cout) tensor")
+        lib, st = _lib.get(), _lib.stream_of(base)
+        _lib.check(lib.skd_ppm_fold_nhwc(b, cout, h, w, len(sizes), _lib.int_array(sizes), _lib.ptr_array(list(zs)),
+                                         base.data_ptr(), st), "skd_ppm_fold_nhwc")
+        ctx.geom = (b, cout, h, w, tuple(sizes))
+        ctx.zshapes = [z.shape for z in zs]
+        ctx.mark_dirty(base)
+        return base
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        b, cout, h, w, sizes = ctx.geom
+        gout = _cl(gout.to(torch.float32))
+        gzs = [None] * len(sizes)
+        if any(ctx.needs_input_grad[2:]):
+            lib, st = _lib.get(), _lib.stream_of(gout)
+            arr = _lib.int_array(sizes)
+            gzs = [gout.new_empty(shape) for shape in ctx.zshapes]
+            ws = gout.new_empty((max(1, lib.skd_ppm_fold_nhwc_workspace_floats(b, cout, h, w, len(sizes), arr)),))
+            _lib.check(lib.skd_ppm_fold_backward_nhwc(b, cout, h, w, len(sizes), arr, gout.data_ptr(), _lib.ptr_array(gzs),
+                                                      ws.data_ptr(), st), "skd_ppm_fold_backward_nhwc")
+        return (gout if ctx.needs_input_grad[0] else None, None) + tuple(gzs)
+
+
+def ppm_fold_supported(feats, sizes):
+    """True when the folded evaluation of the PSP bottleneck (ppm_fold_bottleneck) takes this feature map."""
+    return (feats.is_cuda or _lib.test_backend_active()) and feats.dtype == torch.float32 and feats.dim() == 4 \
+        and _is_cl(feats) and 3 * sum(sizes) <= 64 and len(sizes) <= 4
+
+
+def ppm_fold_bottleneck(priors, feats, weight, cache=None):
+    """conv3x3(cat([upsample(p) for p in priors] + [feats], 1), weight, padding=1) (pspnet_combine.py:104-111) without
+    the concatenated tensor and without convolving the priors' channels: the feature-map slice of the weight goes through
+    the convolution, the priors through a (B s^2) x Cm x 9 Cout GEMM each and the fold kernel (csrc/ppm.hip).
+    priors: (B, Cm, s, s) channels-last; feats: (B, Cf, H, W) channels-last; weight: (Cout, L*Cm + Cf, 3, 3).
+    `cache` (a dict) keeps the rearranged weight slices of a frozen network between calls."""
+    import torch.nn.functional as F
+    cm = priors[0].shape[1]
+    n_prior = len(priors) * cm
+    cout = weight.shape[0]
+    sizes = tuple(int(p.shape[2]) for p in priors)
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    mats = cache.get("mats") if cache is not None and cache.get("key") == key else None
+    if mats is None:
+        wf = weight[:, n_prior:].contiguous(memory_format=torch.channels_last)
+        wk = [weight[:, k * cm:(k + 1) * cm].permute(1, 2, 3, 0).reshape(cm, 9 * cout) for k in range(len(priors))]
+        mats = (wf, wk)
+        if cache is not None and not (torch.is_grad_enabled() and weight.requires_grad):
+            cache["key"], cache["mats"] = key, mats
+    wf, wk = mats
+    base = F.conv2d(feats, wf, None, 1, 1)
+    zs = [torch.mm(_cl(p).permute(0, 2, 3, 1).reshape(-1, cm), m) for p, m in zip(priors, wk)]
+    return _PPMFold.apply(base, sizes, *zs)
+
+
 def conv1x1_abn_supported(x, conv):
     """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
     input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 64 and Cout of 128."""

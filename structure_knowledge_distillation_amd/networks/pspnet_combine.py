@@ -135,6 +135,16 @@ class PSPModule(nn.Module):
             # channels-last feature maps take the channels-last kernels (no layout copies); anything else the NCHW ones
             pooled = SF.ppm_pool(feats, sizes)
             priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
+            conv = self.bottleneck[0]
+            if (nhwc and os.environ.get("SKD_PSP_FOLD", "1") == "1" and SF.ppm_fold_supported(feats, sizes) and conv.bias is None
+                    and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+                    and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels % 4 == 0
+                    and all(p.shape[1] == priors[0].shape[1] for p in priors)):
+                # the priors never meet the convolution: conv3x3(cat) = conv3x3(feats) + fold(priors x W) by linearity
+                if not hasattr(self, "_fold_cache"):
+                    self._fold_cache = {}
+                out = SF.ppm_fold_bottleneck(priors, feats, conv.weight, self._fold_cache)
+                return self.bottleneck[2](self.bottleneck[1](out))
             return self.bottleneck(SF.ppm_concat(priors, feats))
         h, w = feats.size(2), feats.size(3)
         priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=True)

@@ -367,3 +367,49 @@ def test_miopen_db_is_private_writable_copy_and_version_guard(tmp_path, monkeypa
         warnings.simplefilter("always")
         assert S.check_miopen_db() is False
     assert any("find-db" in str(x.message) for x in w)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 8, 9, 11), (2, 8, 4, 6, 6), (3, 12, 4, 13, 7)])
+def test_psp_fold_equals_concat_then_convolution(shape, monkeypatch):
+    """PSPModule's folded bottleneck (conv3x3(feats) + fold(priors x W), csrc/ppm.hip) against the reference sequence
+    pspnet_combine.py:104-111 -- upsample, cat, conv3x3 -- on the same module: outputs and every gradient."""
+    import torch.nn.functional as F
+    from structure_knowledge_distillation_amd.networks.pspnet_combine import PSPModule
+    b, cf, cm, h, w = shape
+    torch.manual_seed(5)
+    m = PSPModule(cf, cm).train()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.3)
+    x = torch.randn(b, cf, h, w).contiguous(memory_format=torch.channels_last)
+
+    def run(fold):
+        monkeypatch.setenv("SKD_PSP_FOLD", "1" if fold else "0")
+        for p in m.parameters():
+            p.grad = None
+        for mod in m.modules():                                   # same running statistics on both runs
+            if hasattr(mod, "running_mean") and mod.running_mean is not None:
+                mod.running_mean.zero_()
+                mod.running_var.fill_(1.0)
+        xx = x.clone().requires_grad_(True)
+        torch.manual_seed(11)                                     # Dropout2d mask
+        out = m(xx)
+        torch.manual_seed(12)
+        (out * torch.randn(out.shape)).sum().backward()
+        return out.detach(), xx.grad, {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    o1, g1, p1 = run(True)
+    o0, g0, p0 = run(False)
+    assert rel(o1, o0) < 2e-5, rel(o1, o0)
+    assert rel(g1, g0) < 2e-5, rel(g1, g0)
+    for k in p0:
+        assert rel(p1[k], p0[k]) < 5e-5, (k, rel(p1[k], p0[k]))
+    # and the bottleneck convolution alone against plain torch ops in float64 (the reference graph itself)
+    from structure_knowledge_distillation_amd import functional as SF
+    with torch.no_grad():
+        m.eval()
+        pooled = [F.adaptive_avg_pool2d(x, st[0].output_size).contiguous(memory_format=torch.channels_last) for st in m.stages]
+        priors = [st[2](st[1](p)) for st, p in zip(m.stages, pooled)]
+        pri = [F.interpolate(p.double().contiguous(), size=(h, w), mode="bilinear", align_corners=True) for p in priors]
+        want = F.conv2d(torch.cat(pri + [x.double().contiguous()], 1), m.bottleneck[0].weight.double(), None, 1, 1)
+        got = SF.ppm_fold_bottleneck(priors, x, m.bottleneck[0].weight, {})
+    assert rel(got, want) < 2e-5, rel(got, want)

@@ -826,3 +826,97 @@ def test_conv1x1_abn_gemm_full_size_vs_conv2d():
         want = IA.abn_eval_fused(conv(x), w, b, rm, rv, 1e-5, "relu", 0.01, res)
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     close(got, want, 2e-5, "fused GEMM vs conv2d + ABN pass")
+
+
+@pytest.mark.parametrize("geom", [(2, 512, 65, 65, (1, 2, 3, 6)), (8, 128, 65, 65, (1, 2, 3, 6)), (2, 128, 33, 33, (1, 2, 3, 6)),
+                                  (1, 8, 129, 257, (1, 2, 3, 6)), (3, 4, 7, 9, (1, 2, 3, 6)), (2, 12, 6, 6, (1, 2, 3, 6)),
+                                  (1, 4, 1, 5, (1,)), (2, 20, 46, 61, (2, 6)), (1, 16, 3, 2, (1, 2))])
+def test_ppm_fold(hip, ref, geom):
+    """skd_ppm_fold_nhwc / skd_ppm_fold_backward_nhwc (the pyramid priors folded through the 3x3 bottleneck
+    convolution, pspnet_combine.py:104-111) against the plain-C definition; the backward is the exact transpose."""
+    B, Cout, H, W, sizes = geom
+    L = len(sizes)
+    arr = (ctypes.c_int * L)(*sizes)
+    g = torch.Generator().manual_seed(Cout + H + W)
+    zs = [torch.randn(B * s * s, 9 * Cout, generator=g) for s in sizes]
+    base = torch.randn(B, H, W, Cout, generator=g)
+    out_r = base.clone()
+    assert ref.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zs]), P(out_r), None)
+    zg = [gpu(z) for z in zs]
+    out_g = gpu(base)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None)
+    close(out_g, out_r, 2e-5, "fold forward")
+    # a second call accumulates on top (in-place += contract)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None)
+    close(out_g, 2 * out_r - base, 2e-5, "fold forward accumulates")
+    gout = torch.randn(B, H, W, Cout, generator=g)
+    gr = [torch.full_like(z, float("nan")) for z in zs]
+    assert ref.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gout), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gr]), P(torch.empty(8)), None)
+    nws = hip.skd_ppm_fold_nhwc_workspace_floats(B, Cout, H, W, L, arr)
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device=DEV)
+    gg = [torch.full_like(z, float("nan")) for z in zg]
+    assert hip.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gpu(gout)), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gg]), P(ws), None)
+    for k in range(L):
+        close(gg[k], gr[k], 2e-5, "fold backward level %d" % sizes[k], floor=float(gout.abs().max()))
+    # transpose identity at full precision: <fold(Z), G> == <Z, fold^T(G)>
+    zero = torch.zeros(B, H, W, Cout, device=DEV)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(zero), None)
+    lhs = float((zero.double() * gpu(gout).double()).sum())
+    rhs = sum(float((zg[k].double() * gg[k].double()).sum()) for k in range(L))
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), float(zero.double().norm() * gout.double().norm()) * 1e-2), (lhs, rhs)
+    # rejected: channel count not a multiple of 4, missing pointers
+    assert hip.skd_ppm_fold_nhwc(B, Cout + 1, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None) == 0
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, None, P(out_g), None) == 0
+
+
+@pytest.mark.parametrize("cfg", [(2, 512, 128, 65, 65, True), (2, 2048, 512, 33, 33, False), (1, 64, 16, 129, 257, False)])
+def test_psp_module_fold_vs_concat(cfg, monkeypatch):
+    """PSPModule on the GPU: folded bottleneck vs the concatenate-then-convolve sequence of pspnet_combine.py:104-111
+    (same module, same weights) and vs plain torch ops in float64 on the CPU."""
+    import torch.nn.functional as F
+    from structure_knowledge_distillation_amd.networks.pspnet_combine import PSPModule
+    B, Cf, Cm, H, W, train = cfg
+    torch.manual_seed(3)
+    m = PSPModule(Cf, Cm)
+    for p in m.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.05)
+    m = m.to(DEV).to(memory_format=torch.channels_last)
+    x = (torch.randn(B, Cf, H, W) * 2).to(DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(fold):
+        monkeypatch.setenv("SKD_PSP_FOLD", "1" if fold else "0")
+        for p in m.parameters():
+            p.grad = None
+        if not train:
+            with torch.no_grad():
+                return m.eval()(x.clone()), None, None
+        m.train()
+        for mod in m.modules():
+            if getattr(mod, "running_mean", None) is not None:
+                mod.running_mean.zero_()
+                mod.running_var.fill_(1.0)
+        xx = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        out = m(xx)
+        torch.manual_seed(12)
+        (out * torch.randn(out.shape, device=DEV)).sum().backward()
+        return out.detach(), xx.grad, {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    o1, g1, p1 = run(True)
+    o0, g0, p0 = run(False)
+    close(o1, o0, 2e-5, "PSP output fold vs concat")
+    if train:
+        close(g1, g0, 5e-5, "PSP input gradient")
+        for k in p0:
+            close(p1[k], p0[k], 2e-4, "PSP grad " + k, floor=float(p0[k].abs().max()))
+    # bottleneck convolution alone vs the reference graph in float64
+    from structure_knowledge_distillation_amd import functional as SF
+    with torch.no_grad():
+        m.eval()
+        sizes = (1, 2, 3, 6)
+        priors = [st[2](st[1](p)) for st, p in zip(m.stages, SF.ppm_pool(x, sizes))]
+        got = SF.ppm_fold_bottleneck(priors, x, m.bottleneck[0].weight, {})
+        pri = [F.interpolate(p.cpu().double().contiguous(), size=(H, W), mode="bilinear", align_corners=True) for p in priors]
+        want = F.conv2d(torch.cat(pri + [x.cpu().double().contiguous()], 1), m.bottleneck[0].weight.cpu().double(), None, 1, 1)
+    close(got, want, 2e-5, "folded bottleneck vs float64 cat+conv")
