@@ -199,6 +199,11 @@ class NetModel():
 
         self._teacher_stream = (torch.cuda.Stream(device=device) if (os.environ.get("SKD_TEACHER_STREAM", "0") == "1"
                                                                     and torch.device(device).type == "cuda") else None)
+        # The D step (kd_model.py:153-165) only needs the two logit tensors and D's own state: it runs on a second HIP
+        # stream next to the student's backbone backward (its ~700 launches are 3-8 us kernels on (8, 19..512, <=65, 65)
+        # tensors that leave the chip idle when serialised).  SKD_D_STREAM=0 restores the serial order.
+        self._d_stream = (torch.cuda.Stream(device=device, priority=-1)
+                          if (os.environ.get("SKD_D_STREAM", "1") == "1" and torch.device(device).type == "cuda") else None)
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
         self.log_teacher_ce = os.environ.get("SKD_TEACHER_CE", "0") == "1"
@@ -328,10 +333,40 @@ class NetModel():
     def optimize_parameters(self):
         self.forward()
         self.G_solver.zero_grad()
-        self.student_backward()
+        ho = self.args.ho == True  # noqa: E712
+        side = self._d_stream if ho else None
+        if side is None:
+            self.student_backward()
+            self.G_solver.step()
+            if ho:
+                self.discriminator_backward()
+            return
+        # Same operations, same order per data dependency: the D step may start as soon as the student's logits have
+        # received their gradient -- by then the student loss has finished back-propagating through D, so D's
+        # spectral-norm state is free to advance (spectral.py:30-31) -- and runs beside the backbone backward and the
+        # student's SGD update, neither of which it reads or writes.
+        dev = self.preds_S[0].device
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        fired = []
+
+        def _logits_grad_ready(grad):
+            ready.record(torch.cuda.current_stream(grad.device))
+            fired.append(True)
+
+        handle = self.preds_S[0].register_hook(_logits_grad_ready)
+        try:
+            self.student_backward()
+        finally:
+            handle.remove()
         self.G_solver.step()
-        if self.args.ho == True:  # noqa: E712
+        if fired:
+            side.wait_event(ready)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
             self.discriminator_backward()
+        main.wait_stream(side)
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
         """networks/evaluate.py via kd_model.py:178-181.  One process per GPU: rank 0 evaluates (the replicas are

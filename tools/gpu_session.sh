@@ -74,6 +74,22 @@ EOF
     c11)
       timeout 300 python tools/conv1x1_bench.py 20 > $O/conv1x1_ab.jsonl 2> $O/conv1x1_ab.err
       stamp "c11 rc=$?"; tail -1 $O/conv1x1_ab.jsonl | tee -a $O/session.log ;;
+    tune_fold)
+      # MIOpen find for the new convolution problems, appended to a copy of the shipped db; later sections use the copy
+      rm -rf $O/miopen_db; cp -r structure_knowledge_distillation_amd/miopen_db $O/miopen_db
+      timeout 1000 python tools/miopen_tune.py $O/miopen_db psp_fold > $O/tune_fold.log 2>&1
+      stamp "tune_fold rc=$?"; tail -12 $O/tune_fold.log | tee -a $O/session.log
+      export MIOPEN_USER_DB_PATH=$O/miopen_db MIOPEN_CUSTOM_CACHE_DIR=$O/miopen_db/cache ;;
+    tests_fold)
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
+        -k "fold or ppm or b8 or config1 or full_step" > $O/pytest_fold.log 2>&1
+      stamp "tests_fold rc=$?"; grep -E "passed|failed|error" $O/pytest_fold.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |worst|B=8 |config1 " $O/pytest_fold.log | head -30 | tee -a $O/session.log ;;
+    bench_ab)
+      for v in "SKD_PSP_FOLD=0 SKD_D_STREAM=0" "SKD_PSP_FOLD=1 SKD_D_STREAM=0" "SKD_PSP_FOLD=1 SKD_D_STREAM=1"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
+        stamp "bench_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err

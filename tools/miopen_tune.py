@@ -23,6 +23,7 @@ PHASES = {  # name: (batch, find, what, timeout_s)
     "full8_nhwc": (8, True, "full_nhwc", 900),
     "full2_nhwc": (2, False, "full_nhwc", 400),
     "full2": (2, False, "full", 400),
+    "psp_fold": (8, True, "psp_fold", 900),   # the feature-map halves of the two PSP bottleneck convolutions (folded priors)
 }
 
 
@@ -37,6 +38,26 @@ def child(phase):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     t0 = time.time()
+    if what == "psp_fold":
+        import torch.nn.functional as F
+        torch.backends.cudnn.benchmark = True
+        for (b, hw) in ((8, 65), (2, 65), (2, 33)):
+            for (cf, cm, train) in ((2048, 512, False), (512, 128, True)):
+                x = torch.randn(b, cf, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+                w = torch.randn(cm, cf, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+                t1 = time.time()
+                if train:
+                    x.requires_grad_(True)
+                    w.requires_grad_(True)
+                    y = F.conv2d(x, w, None, 1, 1)
+                    y.backward(torch.randn_like(y))
+                else:
+                    with torch.no_grad():
+                        F.conv2d(x, w, None, 1, 1)
+                torch.cuda.synchronize()
+                print("  %d x %d x %dx%d -> %d: %.1f s" % (b, cf, hw, hw, cm, time.time() - t1), flush=True)
+        print("phase %s done in %.1f s" % (phase, time.time() - t0), flush=True)
+        return
     args = default_args(batch_size=batch, device=dev, ho=(what in ("full", "full_nhwc")), weight_decay=5e-4, lambda_pa=0.5)
     model = NetModel(args)
     x = torch.randn(batch, 3, 512, 512, device=dev) * 57
