@@ -33,6 +33,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, exact fp32
 STEP_TFLOP_PER_IMAGE = 0.959   # teacher fwd 579.3 GF + student fwd 126.7 + bwd 253.3
+# the PSP bottleneck fold (csrc/ppm.hip, SKD_PSP_FOLD=1) evaluates the priors' half of both bottleneck convolutions by
+# a small GEMM + fold kernel: 2*65*65*9*(512*2048 [teacher fwd] + 3 * 128*512 [student fwd + 2 bwd]) flop per image less
+FOLD_TFLOP_PER_IMAGE = 2 * 65 * 65 * 9 * (512 * 2048 + 3 * 128 * 512) / 1e12
 
 
 def parse():
@@ -264,8 +267,10 @@ def main():
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "losses_last_step": {k: round(float(v), 6) for k, v in
                                         zip(("G", "mc", "pi", "pa", "D"), losses)}},
-        "step_fp32_mfma_frac": round(value / world * STEP_TFLOP_PER_IMAGE / MFMA_F32_PEAK_TFLOPS, 4),
     }
+    executed = STEP_TFLOP_PER_IMAGE - (FOLD_TFLOP_PER_IMAGE if os.environ.get("SKD_PSP_FOLD", "1") == "1" else 0.0)
+    line["step_tflop_per_image"] = {"reference_algorithm": STEP_TFLOP_PER_IMAGE, "executed": round(executed, 4)}
+    line["step_fp32_mfma_frac"] = round(value / world * executed / MFMA_F32_PEAK_TFLOPS, 4)   # executed flops only
     ap = summarise(recs.get(roofline_entry, []), 8, nhwc="apply")
     if ap:
         # the dominant hand-written kernel of the step (3.9 of ~7 ms of InPlace-ABN time): ALL its launches of the timed

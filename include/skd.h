@@ -370,6 +370,21 @@ int skd_cs_transform(int B, int H0, int W0, const uint8_t *images, const uint8_t
                      const int *flip, int crop_h, int crop_w, const float *mean, int ignore_label, float *out_image,
                      int channels_last, int64_t *out_label, skd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * 12. The stem's MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=True) (networks/pspnet_combine.py:135,152 of
+ *     both networks) for channels-last tensors: x (B, H, W, C) -> y (B, OH, OW, C), C % 4 == 0; OH / OW are the
+ *     caller's (torch's pooling-shape rule; the entry checks that every window starts inside the input and that the
+ *     windows cover it).  PyTorch's selection rule: windows scanned row-major, `val > max || isnan(val)` replaces -- the
+ *     first maximum wins ties, NaN propagates.  arg (may be NULL for inference): the winner's position INSIDE its
+ *     3x3 window, ky * 3 + kx in 0..8, one byte per output element (instead of the stock int64 flat index).
+ *     backward: dx[b][y][x][c] = sum of dy over the <= 4 windows containing (y, x) whose arg points at it; every
+ *     element of dx is written (no zero-fill, no atomics).
+ * ---------------------------------------------------------------------------------- */
+int skd_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, float *y, uint8_t *arg,
+                          skd_stream_t stream);
+int skd_maxpool3x3s2_backward_nhwc(int B, int C, int H, int W, int OH, int OW, const float *dy, const uint8_t *arg,
+                                   float *dx, skd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

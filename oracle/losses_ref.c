@@ -645,6 +645,58 @@ int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const 
   return 1;
 }
 
+/* ---- stem max-pool 3x3 / stride 2 / padding 1 (ceil_mode shapes given by the caller), channels-last; PyTorch's
+ * max_pool2d_with_indices rule (val > max || isnan(val), row-major scan from the first valid position),
+ * networks/pspnet_combine.py:135,152 ---- */
+static int pool_geom_ok(int B, int C, int H, int W, int OH, int OW) {
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return 0;
+  return 2 * (OH - 1) - 1 < H && 2 * (OW - 1) - 1 < W && 2 * (OH - 1) + 1 >= H - 1 && 2 * (OW - 1) + 1 >= W - 1;
+}
+
+int skd_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, float *y, uint8_t *arg, stream_t st) {
+  (void)st;
+  if (!pool_geom_ok(B, C, H, W, OH, OW) || !x || !y) return 0;
+  for (int b = 0; b < B; ++b)
+    for (int oy = 0; oy < OH; ++oy)
+      for (int ox = 0; ox < OW; ++ox)
+        for (int c = 0; c < C; ++c) {
+          const int ys = 2 * oy - 1, xs = 2 * ox - 1;
+          const int y0 = ys < 0 ? 0 : ys, x0 = xs < 0 ? 0 : xs;
+          const int y1 = ys + 3 < H ? ys + 3 : H, x1 = xs + 3 < W ? xs + 3 : W;
+          float best = -INFINITY;
+          int a = (y0 - ys) * 3 + (x0 - xs);
+          for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+              const float v = x[(((int64_t)b * H + yy) * W + xx) * C + c];
+              if (v > best || v != v) { best = v; a = (yy - ys) * 3 + (xx - xs); }
+            }
+          const int64_t o = (((int64_t)b * OH + oy) * OW + ox) * C + c;
+          y[o] = best;
+          if (arg) arg[o] = (uint8_t)a;
+        }
+  return 1;
+}
+
+int skd_maxpool3x3s2_backward_nhwc(int B, int C, int H, int W, int OH, int OW, const float *dy, const uint8_t *arg, float *dx,
+                                   stream_t st) {
+  (void)st;
+  if (!pool_geom_ok(B, C, H, W, OH, OW) || !dy || !arg || !dx) return 0;
+  double *acc = (double *)calloc((size_t)B * H * W * C, sizeof(double));
+  if (!acc) return 0;
+  for (int b = 0; b < B; ++b)
+    for (int oy = 0; oy < OH; ++oy)
+      for (int ox = 0; ox < OW; ++ox)
+        for (int c = 0; c < C; ++c) {
+          const int64_t o = (((int64_t)b * OH + oy) * OW + ox) * C + c;
+          const int yy = 2 * oy - 1 + arg[o] / 3, xx = 2 * ox - 1 + arg[o] % 3;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) { free(acc); return 0; }
+          acc[(((int64_t)b * H + yy) * W + xx) * C + c] += (double)dy[o];
+        }
+  for (int64_t i = 0; i < (int64_t)B * H * W * C; ++i) dx[i] = (float)acc[i];
+  free(acc);
+  return 1;
+}
+
 /* ---- evaluation tail: upsample + argmax + confusion matrix, networks/evaluate.py:106-113, 136-154, 186-198 ---- */
 int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *logits, const int64_t *target,
                       int ignore_index, uint8_t *pred, int64_t *confusion, stream_t st) {

@@ -329,6 +329,55 @@ def ppm_fold_bottleneck(priors, feats, weight, cache=None):
     return _PPMFold.apply(base, sizes, *zs)
 
 
+class _MaxPool3x3s2(Function):
+    """MaxPool2d(3, 2, 1, ceil_mode) on a channels-last tensor (csrc/maxpool.hip): one byte of argmax per element."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        _lib.require_device(x)
+        b, c, h, w = x.shape
+        lib, st = _lib.get(), _lib.stream_of(x)
+        y = _new_cl(x, b, c, oh, ow)
+        need = ctx.needs_input_grad[0]
+        arg = torch.empty((b, oh, ow, c), dtype=torch.uint8, device=x.device) if need else None
+        _lib.check(lib.skd_maxpool3x3s2_nhwc(b, c, h, w, oh, ow, x.data_ptr(), y.data_ptr(), _lib.ptr(arg), st), "skd_maxpool3x3s2_nhwc")
+        ctx.geom = (b, c, h, w, oh, ow)
+        if need:
+            ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        b, c, h, w, oh, ow = ctx.geom
+        (arg,) = ctx.saved_tensors
+        gy = _cl(gy.to(torch.float32))
+        lib, st = _lib.get(), _lib.stream_of(gy)
+        dx = _new_cl(gy, b, c, h, w)
+        _lib.check(lib.skd_maxpool3x3s2_backward_nhwc(b, c, h, w, oh, ow, gy.data_ptr(), arg.data_ptr(), dx.data_ptr(), st),
+                   "skd_maxpool3x3s2_backward_nhwc")
+        return dx, None, None
+
+
+def _pool_out(n, ceil_mode):
+    o = (n + 2 - 3 + (1 if ceil_mode else 0)) // 2 + 1
+    if ceil_mode and (o - 1) * 2 >= n + 1:
+        o -= 1
+    return o
+
+
+def max_pool_stem(x, pool):
+    """``pool(x)`` for the stem's nn.MaxPool2d(3, 2, 1, ceil_mode=True) (pspnet_combine.py:135): channels-last fp32
+    tensors take csrc/maxpool.hip, anything else the stock operator."""
+    def _pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    if (x.dtype == torch.float32 and _is_cl(x) and (x.is_cuda or _lib.test_backend_active())
+            and _pair(pool.kernel_size) == (3, 3) and _pair(pool.stride) == (2, 2) and _pair(pool.padding) == (1, 1)
+            and _pair(pool.dilation) == (1, 1) and not pool.return_indices):
+        return _MaxPool3x3s2.apply(x, _pool_out(x.shape[2], pool.ceil_mode), _pool_out(x.shape[3], pool.ceil_mode))
+    return pool(x)
+
+
 def conv1x1_abn_supported(x, conv):
     """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
     input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 64 and Cout of 128."""

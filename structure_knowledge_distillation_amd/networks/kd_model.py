@@ -207,6 +207,9 @@ class NetModel():
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
         self.log_teacher_ce = os.environ.get("SKD_TEACHER_CE", "0") == "1"
+        # preds_T[1] (the teacher's deep-supervision logits) is read by nothing but the teacher CE the reference computes and
+        # discards (kd_model.py:129).  Default: computed anyway, like the reference's forward; SKD_TEACHER_DSN=0 skips it.
+        self.teacher.skip_dsn = os.environ.get("SKD_TEACHER_DSN", "1") == "0" and not self.log_teacher_ce
 
         # MIOpen find mode is opt-in: this ROCm image ships no gfx950 find/kernel database, so "find"
         # JIT-compiles every candidate solver for every convolution shape on a fresh machine.
@@ -255,7 +258,7 @@ class NetModel():
             images_T = self.images.contiguous(memory_format=torch.channels_last) if self.teacher_nhwc else self.images
             preds_T = self.parallel_teacher.eval()(images_T, parallel=args.parallel)
             # the three entries the criteria / D read are handed on in the reference's NCHW layout
-            return [t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
+            return [None if t is None else t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
 
     def _student_forward(self):
         args = self.args
@@ -284,13 +287,14 @@ class NetModel():
         self.preds_S = self._student_forward()
         main.wait_stream(side)
         for t in self.preds_T:
-            t.record_stream(main)
+            if t is not None:
+                t.record_stream(main)
 
     def student_backward(self):
         args = self.args
         temp = self.criterion(self.preds_S, self.labels, is_target_scattered=False)
         self._scalars["mc_G_loss"] = temp.detach()
-        if self.log_teacher_ce:     # kd_model.py:129 computes the teacher's CE and throws it away; off unless asked for
+        if self.log_teacher_ce and self.preds_T[1] is not None:     # kd_model.py:129 computes the teacher's CE and throws it away; off unless asked for
             self._scalars["mc_T_loss"] = self.criterion(self.preds_T, self.labels, is_target_scattered=False).detach()
         G_loss = temp
         if args.pi == True:  # noqa: E712  (flags may arrive as 0/1)

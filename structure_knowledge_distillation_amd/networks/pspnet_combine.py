@@ -208,11 +208,13 @@ class ResNet(nn.Module):
             x = self.relu1(self.bn1(self.conv1(x)))
             x = self.relu2(self.bn2(self.conv2(x)))
             x = self.relu3(self.bn3(self.conv3(x)))
-        x = self.maxpool(x)
+        x = SF.max_pool_stem(x, self.maxpool) if os.environ.get("SKD_MAXPOOL", "1") == "1" else self.maxpool(x)
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
-        x_dsn = self.dsn(x3)
+        # the deep-supervision head feeds only CriterionDSN; a frozen network whose CE nobody computes may skip it
+        # (NetModel sets skip_dsn on the teacher when SKD_TEACHER_DSN=0; default: computed, like the reference)
+        x_dsn = None if getattr(self, "skip_dsn", False) and not torch.is_grad_enabled() else self.dsn(x3)
         x4 = self.layer4(x3)
         x_feat_after_psp = self.pspmodule(x4)
         x = self.head(x_feat_after_psp)

@@ -920,3 +920,50 @@ def test_psp_module_fold_vs_concat(cfg, monkeypatch):
         pri = [F.interpolate(p.cpu().double().contiguous(), size=(H, W), mode="bilinear", align_corners=True) for p in priors]
         want = F.conv2d(torch.cat(pri + [x.cpu().double().contiguous()], 1), m.bottleneck[0].weight.cpu().double(), None, 1, 1)
     close(got, want, 2e-5, "folded bottleneck vs float64 cat+conv")
+
+
+@pytest.mark.parametrize("geom", [(8, 128, 256, 256), (2, 128, 128, 128), (1, 4, 9, 12), (2, 8, 65, 33), (1, 64, 512, 1024), (3, 12, 1, 2)])
+def test_maxpool3x3s2_nhwc(hip, ref, geom):
+    """skd_maxpool3x3s2_nhwc / _backward_nhwc (the stem's MaxPool2d(3, 2, 1, ceil_mode=True), pspnet_combine.py:135):
+    values and argmax codes bit-exact vs the plain-C oracle and vs torch (ties, -inf, NaN); backward = torch's."""
+    from structure_knowledge_distillation_amd.functional import _pool_out
+    B, C, H, W = geom
+    OH, OW = _pool_out(H, True), _pool_out(W, True)
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, H, W, C, generator=g)
+    x[torch.rand(B, H, W, C, generator=g) < 0.3] = 1.0                # ties
+    x.view(-1)[::997] = float("-inf")
+    x.view(-1)[5::1999] = float("nan")
+    small = B * H * W * C <= (1 << 24)
+    yg = torch.empty(B, OH, OW, C, device=DEV)
+    ag = torch.full((B, OH, OW, C), 255, dtype=torch.uint8, device=DEV)
+    assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(gpu(x)), P(yg), P(ag), None)
+    want, idx = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1, ceil_mode=True, return_indices=True)
+    nn = lambda t: torch.nan_to_num(t, nan=7e7)                        # noqa: E731
+    assert torch.equal(nn(yg.cpu()), nn(want.permute(0, 2, 3, 1)))
+    # argmax code -> flat h * W + w index = torch's
+    a = ag.cpu().long()
+    oy = torch.arange(OH).view(1, OH, 1, 1)
+    ox = torch.arange(OW).view(1, 1, OW, 1)
+    flat = (2 * oy - 1 + a // 3) * W + (2 * ox - 1 + a % 3)
+    assert torch.equal(flat, idx.permute(0, 2, 3, 1))
+    if small:
+        yr, ar = torch.empty(B, OH, OW, C), torch.empty(B, OH, OW, C, dtype=torch.uint8)
+        assert ref.skd_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(x), P(yr), P(ar), None)
+        assert torch.equal(nn(yg.cpu()), nn(yr)) and torch.equal(ag.cpu(), ar)
+    # inference form: no argmax written
+    y2 = torch.empty_like(yg)
+    assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(gpu(x)), P(y2), None, None)
+    assert torch.equal(nn(y2), nn(yg))
+    gy = torch.randn(B, OH, OW, C, generator=g)
+    dxg = torch.full((B, H, W, C), float("nan"), device=DEV)
+    assert hip.skd_maxpool3x3s2_backward_nhwc(B, C, H, W, OH, OW, P(gpu(gy)), P(ag), P(dxg), None)
+    xt = torch.nan_to_num(x, nan=1e9).permute(0, 3, 1, 2).clone().requires_grad_(True)   # NaN wins in torch too; keep autograd finite
+    torch.nn.functional.max_pool2d(xt, 3, 2, 1, ceil_mode=True).backward(gy.permute(0, 3, 1, 2))
+    close(dxg, xt.grad.permute(0, 2, 3, 1), 1e-6, "max-pool backward vs torch", floor=float(gy.abs().max()))
+    if small:
+        dxr = torch.empty(B, H, W, C)
+        assert ref.skd_maxpool3x3s2_backward_nhwc(B, C, H, W, OH, OW, P(gy), P(ar), P(dxr), None)
+        close(dxg, dxr, 1e-6, "max-pool backward vs oracle", floor=float(gy.abs().max()))
+    assert hip.skd_maxpool3x3s2_nhwc(B, C + 1, H, W, OH, OW, P(gpu(x)), P(yg), None, None) == 0
+    assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH + 1, OW, P(gpu(x)), P(yg), None, None) == 0

@@ -61,6 +61,29 @@ def main():
                             "fused_gemm_frac_fp32_mfma": round(flop / t_b / 1e9 / 157.3, 3), "speedup_vs_conv_plus_abn": round(t_a / t_b, 3)})
                 tot["conv_plus_abn_ms"] += count * t_a
                 tot["fused_gemm_ms"] += count * t_b
+            # (d) the BLAS library on the same GEMM (NHWC 1x1 convolution = (B*H*W, Cin) x (Cin, Cout)), BN folded into
+            #     weight / bias; with the bias + ReLU epilogue (torch._addmm_activation) where there is no residual
+            s = (w.abs() + 1e-5) / torch.sqrt(rv + 1e-5)
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)
+            w2t = (conv.weight.reshape(cout, cin) * s.view(-1, 1)).t().contiguous()      # (Cin, Cout)
+            w2 = (conv.weight.reshape(cout, cin) * s.view(-1, 1)).contiguous()           # (Cout, Cin), used as .t()
+            bf = b - rm * s
+            try:
+                row["blas_mm_us"] = round(timed(lambda: torch.mm(x2, w2.t())) * 1e3, 1)
+                row["blas_mm_kn_us"] = round(timed(lambda: torch.mm(x2, w2t)) * 1e3, 1)
+                if has_res:
+                    r2 = res.permute(0, 2, 3, 1).reshape(-1, cout)
+                    row["blas_addmm_res_us"] = round(timed(lambda: torch.addmm(r2, x2, w2.t())) * 1e3, 1)
+                else:
+                    row["blas_bias_relu_us"] = round(timed(lambda: torch._addmm_activation(bf, x2, w2.t())) * 1e3, 1)
+                    want = torch.relu(torch.mm(x2.double(), w2.t().double()) + bf.double())
+                    got = torch._addmm_activation(bf, x2, w2.t())
+                    row["blas_bias_relu_err"] = float((got.double() - want).abs().max() / want.abs().max())
+            except Exception as e:      # noqa: BLE001
+                row["blas_error"] = str(e).splitlines()[0][:100]
+            if os.environ.get("C11_SKIP_MIOPEN", "0") == "1":
+                print(json.dumps(row), flush=True)
+                continue
             try:   # MIOpen's own fusion with the BN folded into weight / bias
                 s = (w.abs() + 1e-5) / torch.sqrt(rv + 1e-5)
                 wf = (conv.weight * s.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
