@@ -378,6 +378,38 @@ def max_pool_stem(x, pool):
     return pool(x)
 
 
+def blas_1x1_bn_supported(x, conv):
+    """True when conv1x1_bn_blas takes this call: an fp32 channels-last input of a frozen network (no graph) and a plain
+    stride-1 1x1 convolution without bias."""
+    return (not torch.is_grad_enabled() and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
+            and conv.in_channels >= 128 and conv.out_channels >= 64)
+
+
+def conv1x1_bn_blas(x, conv, bn, relu):
+    """relu?(bn(conv1x1(x))) of a FROZEN network (eval-mode InPlace-ABN, pspnet_combine.py:65-72) as one library GEMM with
+    the bias (+ ReLU) epilogue: a channels-last 1x1 convolution IS the plain GEMM (B*H*W, Cin) x (Cin, Cout), the
+    eval-mode normalisation folds into it -- W' = W * s, b' = beta - mean * s, s = (|gamma| + eps) / sqrt(var + eps) -- and
+    rocBLAS / hipBLASLt run that GEMM faster than MIOpen's implicit-GEMM convolution on the teacher's reduce layers
+    (1024 -> 256 at 65 x 65, batch 8: 144 us with the epilogue vs 175 us convolution + 27 us ABN pass;
+    profiles/r02d_conv1x1_blas.jsonl), exact fp32 (no xf32 on gfx950).  The folded operands are cached on the BN module."""
+    key = tuple((t.data_ptr(), t._version) for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
+    fold = getattr(bn, "_blas_fold", None)
+    if fold is None or fold[0] != key:
+        gamma = (bn.weight.abs() + bn.eps) if bn.weight is not None else torch.ones_like(bn.running_var)
+        scale = gamma / torch.sqrt(bn.running_var + bn.eps)
+        w2 = (conv.weight.reshape(conv.out_channels, conv.in_channels) * scale.view(-1, 1)).contiguous()
+        b2 = (bn.bias if bn.bias is not None else torch.zeros_like(scale)) - bn.running_mean * scale
+        fold = (key, w2, b2.contiguous())
+        bn._blas_fold = fold
+    _, w2, b2 = fold
+    b, _, h, w = x.shape
+    x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, conv.in_channels)
+    out = torch._addmm_activation(b2, x2, w2.t()) if relu else torch.addmm(b2, x2, w2.t())
+    return out.view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
+
 def conv1x1_abn_supported(x, conv):
     """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
     input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 64 and Cout of 128."""

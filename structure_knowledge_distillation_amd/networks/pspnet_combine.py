@@ -37,6 +37,12 @@ def _gemm_tail(x):
     return (os.environ.get("SKD_TEACHER_GEMM", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
 
 
+def _blas_tail(module, x):
+    """Frozen network, fp32, SKD_TEACHER_BLAS != 0: the 1x1 reduce convolutions and stride-1 down-sample branches run as
+    library GEMMs with the folded BN (+ ReLU) in the epilogue (functional.conv1x1_bn_blas)."""
+    return not module.training and not torch.is_grad_enabled() and os.environ.get("SKD_TEACHER_BLAS", "1") == "1"
+
+
 def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
@@ -87,13 +93,22 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         if _fused(self, x):
             gemm = not self.training and _gemm_tail(x)
+            blas = _blas_tail(self, x)
             if gemm and SF.conv1x1_abn_supported(x, self.conv1):
                 out = SF.conv1x1_abn_eval(x, self.conv1.weight, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight,
                                           self.bn1.bias, self.bn1.eps, "relu")
+            elif blas and SF.blas_1x1_bn_supported(x, self.conv1):
+                out = SF.conv1x1_bn_blas(x, self.conv1, self.bn1, relu=True)
             else:
                 out = self.bn1.forward_relu(self.conv1(x))
             out = self.bn2.forward_relu(self.conv2(out))
-            residual = self.downsample(x) if self.downsample is not None else x
+            if self.downsample is None:
+                residual = x
+            elif (blas and len(self.downsample) == 2 and SF.blas_1x1_bn_supported(x, self.downsample[0])
+                  and getattr(self.downsample[1], "activation", None) == "none"):
+                residual = SF.conv1x1_bn_blas(x, self.downsample[0], self.downsample[1], relu=False)
+            else:
+                residual = self.downsample(x)
             if gemm and SF.conv1x1_abn_supported(out, self.conv3):
                 return SF.conv1x1_abn_eval(out, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
                                            self.bn3.bias, self.bn3.eps, "relu", residual=residual)
@@ -103,6 +118,16 @@ class Bottleneck(nn.Module):
         out = self.bn3(self.conv3(out))
         residual = self.downsample(x) if self.downsample is not None else x
         return self.relu_inplace(out + residual)
+
+
+def _conv1x1_as_mm(conv, x):
+    """conv(x) for a plain 1x1 convolution on a channels-last map, as one matrix product (differentiable)."""
+    if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        return conv(x)
+    b, c, h, w = x.shape
+    out = torch.mm(x.permute(0, 2, 3, 1).reshape(b * h * w, c), conv.weight.reshape(conv.out_channels, c).t())
+    return out.view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
 
 
 class PSPModule(nn.Module):
@@ -134,7 +159,12 @@ class PSPModule(nn.Module):
             # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
             # channels-last feature maps take the channels-last kernels (no layout copies); anything else the NCHW ones
             pooled = SF.ppm_pool(feats, sizes)
-            priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
+            if nhwc and os.environ.get("SKD_PSP_MM", "1") == "1":
+                # a 1x1 convolution of a (B, C, s, s) channels-last map is the GEMM (B s^2, C) x (C, Cout): one tiny
+                # rocBLAS call instead of MIOpen's ~30 us (forward) / ~100 us (backward) launch sequences per level
+                priors = [stage[2](_conv1x1_as_mm(stage[1], p)) for stage, p in zip(self.stages, pooled)]
+            else:
+                priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
             conv = self.bottleneck[0]
             if (nhwc and os.environ.get("SKD_PSP_FOLD", "1") == "1" and SF.ppm_fold_supported(feats, sizes) and conv.bias is None
                     and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)

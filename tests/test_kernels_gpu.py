@@ -967,3 +967,38 @@ def test_maxpool3x3s2_nhwc(hip, ref, geom):
         close(dxg, dxr, 1e-6, "max-pool backward vs oracle", floor=float(gy.abs().max()))
     assert hip.skd_maxpool3x3s2_nhwc(B, C + 1, H, W, OH, OW, P(gpu(x)), P(yg), None, None) == 0
     assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH + 1, OW, P(gpu(x)), P(yg), None, None) == 0
+
+
+@pytest.mark.parametrize("cfg", [(8, 1024, 256, 65, True), (2, 128, 64, 129, True), (2, 512, 128, 33, False)])
+def test_frozen_bottleneck_blas_tail(cfg, monkeypatch):
+    """Frozen-teacher Bottleneck on the GPU: the 1x1 reduce convolution + BN + ReLU (and the stride-1 down-sample branch)
+    as library GEMMs with the folded BN epilogue vs MIOpen convolution + the in-place ABN pass (pspnet_combine.py:65-84),
+    and vs plain torch ops in float64."""
+    from structure_knowledge_distillation_amd.networks.pspnet_combine import Bottleneck, BatchNorm2d
+    B, Cin, planes, HW, with_down = cfg
+    torch.manual_seed(4)
+    down = torch.nn.Sequential(torch.nn.Conv2d(Cin, planes * 4, 1, 1, bias=False), BatchNorm2d(planes * 4)) if with_down or Cin != planes * 4 else None
+    blk = Bottleneck(Cin, planes, stride=1, dilation=2, downsample=down).eval()
+    for mod in blk.modules():
+        if getattr(mod, "running_mean", None) is not None:
+            mod.running_mean.normal_(0, 0.5)
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.normal_(0, 1.0)
+            mod.bias.data.normal_(0, 0.5)
+    blk = blk.to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(B, Cin, HW, HW, device=DEV).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SKD_TEACHER_BLAS", flag)
+        with torch.no_grad():
+            outs[flag] = blk(x.clone())
+    close(outs["1"], outs["0"], 2e-5, "blas tail vs conv + abn")
+    # the reduce layer alone against float64
+    from structure_knowledge_distillation_amd import functional as SF
+    with torch.no_grad():
+        got = SF.conv1x1_bn_blas(x, blk.conv1, blk.bn1, relu=True)
+        bn = blk.bn1
+        s = ((bn.weight.abs() + bn.eps) / torch.sqrt(bn.running_var + bn.eps)).double().cpu()
+        y = torch.nn.functional.conv2d(x.double().cpu().contiguous(), blk.conv1.weight.double().cpu())
+        want = torch.relu((y - bn.running_mean.double().cpu().view(1, -1, 1, 1)) * s.view(1, -1, 1, 1) + bn.bias.double().cpu().view(1, -1, 1, 1))
+    close(got, want, 2e-5, "conv1x1_bn_blas vs float64")

@@ -90,6 +90,31 @@ EOF
         (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
         stamp "bench_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
       done ;;
+    tests_pool)
+      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
+        -k "maxpool or psp_module or config1" > $O/pytest_pool.log 2>&1
+      stamp "tests_pool rc=$?"; grep -E "passed|failed|error" $O/pytest_pool.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  " $O/pytest_pool.log | head -30 | tee -a $O/session.log ;;
+    bench_ab2)
+      for v in "SKD_MAXPOOL=1" "SKD_MAXPOOL=0" "SKD_TEACHER_DSN=0"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab2_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab2.err
+        stamp "bench_ab2 $v rc=$?"; cut -c1-260 "$O/bench_ab2_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
+    c11b)
+      C11_SKIP_MIOPEN=1 timeout 300 python tools/conv1x1_bench.py 10 > $O/conv1x1_blas.jsonl 2> $O/conv1x1_blas.err
+      stamp "c11b rc=$?"; cut -c1-400 $O/conv1x1_blas.jsonl | tee -a $O/session.log
+      C11_SKIP_MIOPEN=1 TORCH_BLAS_PREFER_HIPBLASLT=1 timeout 300 python tools/conv1x1_bench.py 10 > $O/conv1x1_blaslt.jsonl 2> $O/conv1x1_blaslt.err
+      stamp "c11b hipblaslt rc=$?"; cut -c1-400 $O/conv1x1_blaslt.jsonl | tee -a $O/session.log ;;
+    tests_blas)
+      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
+        -k "blas or psp_module or config1 or teacher" > $O/pytest_blas.log 2>&1
+      stamp "tests_blas rc=$?"; grep -E "passed|failed|error" $O/pytest_blas.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  " $O/pytest_blas.log | head -30 | tee -a $O/session.log ;;
+    bench_ab3)
+      for v in "SKD_TEACHER_BLAS=1" "SKD_TEACHER_BLAS=0" "SKD_PSP_MM=0" "SKD_TEACHER_BLAS=1 TORCH_BLAS_PREFER_HIPBLASLT=1"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab3_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab3.err
+        stamp "bench_ab3 $v rc=$?"; cut -c1-260 "$O/bench_ab3_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
