@@ -538,12 +538,13 @@ struct FoldGradPtrs {
 __device__ __forceinline__ float4 lds_get(const float4 *t, int e) { return t[e * kFoldThreads + threadIdx.x]; }
 
 __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp, float *__restrict__ out, int B, int H,
-                                                                     int W, int C4, int ychunk, Levels lv) {
-  extern __shared__ __attribute__((aligned(16))) float4 tcol[];  // [3 * lv.rows][kFoldThreads]
+                                                                     int W, int C4, int ychunk, Levels lv, int k0, int k1) {
+  extern __shared__ __attribute__((aligned(16))) float4 tcol[];  // [3 * rows of levels k0..k1-1][kFoldThreads]
   const int64_t col = (int64_t)blockIdx.x * kFoldThreads + threadIdx.x;
   if (col >= (int64_t)B * W * C4) return;
   const int q = (int)(col % C4), x = (int)((col / C4) % W), b = (int)(col / ((int64_t)C4 * W));
-  for (int k = 0; k < lv.n; ++k) {
+  const int e0 = 3 * lv.row_off[k0];
+  for (int k = k0; k < k1; ++k) {
     const int s = lv.size[k];
     const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
     const float *zk = zp.z[k] + (int64_t)b * s * s * 9 * C4 * 4 + q * 4;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp
             acc = f4fma(tx3[tx].l0, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i0 * 9 * C4 * 4), acc);
             acc = f4fma(tx3[tx].l1, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i1 * 9 * C4 * 4), acc);
           }
-        tcol[(3 * lv.row_off[k] + ty * s + jy) * kFoldThreads + threadIdx.x] = acc;
+        tcol[(3 * lv.row_off[k] - e0 + ty * s + jy) * kFoldThreads + threadIdx.x] = acc;
       }
   }
   const int y0 = blockIdx.y * ychunk, y1 = y0 + ychunk < H ? y0 + ychunk : H;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (y + u >= y1) break;
-      for (int k = 0; k < lv.n; ++k) {
+      for (int k = k0; k < k1; ++k) {
         const int s = lv.size[k];
         const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f;
 #pragma unroll
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp
           const int yp = y + u + ty - 1;
           if (yp < 0 || yp >= H) continue;
           const Tap t = tap_of(yp, sy, s);
-          const int e = 3 * lv.row_off[k] + ty * s;
+          const int e = 3 * lv.row_off[k] - e0 + ty * s;
           v[u] = f4fma(t.l0, lds_get(tcol, e + t.i0), v[u]);
           v[u] = f4fma(t.l1, lds_get(tcol, e + t.i1), v[u]);
         }
@@ -655,16 +656,27 @@ __global__ __launch_bounds__(kThreads) void ppm_fold_bwd_bins_nhwc_kernel(const 
     const int tap = item / C4, q = item - tap * C4, ty = tap / 3, tx = tap - ty * 3;
     const int e = 3 * lv.row_off[k] + ty * s + jy;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int x = 0; x < W; ++x) {
-      const int xp = x + tx - 1;
-      if (xp < 0 || xp >= W) continue;
-      const Tap t = tap_of(xp, sx, s);
-      float wt = 0.f;
-      if (t.i0 == jx) wt += t.l0;
-      if (t.i1 == jx) wt += t.l1;
-      if (wt == 0.f) continue;
-      for (int c = 0; c < chunks; ++c)
-        acc = f4fma(wt, *reinterpret_cast<const float4 *>(ws + (((((int64_t)c * B + b) * E + e) * W + x) * C4 + q) * 4), acc);
+    // columns x' = x + tx - 1 whose bilinear taps touch bin column jx: (jx - 1) / sx < x' < (jx + 1) / sx (one column of
+    // margin either side; weights outside the support are exactly zero, so the margin only costs a load)
+    int lo = 0, hi = W - 1;
+    if (s > 1) {
+      lo = (int)floorf((float)(jx - 1) / sx) - 1 - (tx - 1);
+      hi = (int)ceilf((float)(jx + 1) / sx) + 1 - (tx - 1);
+      if (lo < 0) lo = 0;
+      if (hi > W - 1) hi = W - 1;
+    }
+    for (int c = 0; c < chunks; ++c) {
+      const float *src = ws + ((((int64_t)c * B + b) * E + e) * W) * C4 * 4 + q * 4;
+#pragma unroll 4
+      for (int x = lo; x <= hi; ++x) {
+        const int xp = x + tx - 1;
+        const Tap t = tap_of(xp < 0 ? 0 : (xp >= W ? W - 1 : xp), sx, s);
+        float wt = 0.f;
+        if (t.i0 == jx) wt += t.l0;
+        if (t.i1 == jx) wt += t.l1;
+        if (xp < 0 || xp >= W) wt = 0.f;
+        acc = f4fma(wt, *reinterpret_cast<const float4 *>(src + (int64_t)x * C4 * 4), acc);
+      }
     }
     *reinterpret_cast<float4 *>(gz.z[k] + ((((int64_t)b * s + jy) * s + jx) * 9 + tap) * C4 * 4 + q * 4) = acc;
   }
@@ -852,7 +864,17 @@ int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *size
     if (!zp.z[k]) return 0;
   const int C4 = Cout / 4, chunks = fold_chunks(B, H, W, C4), ychunk = (int)cdiv(H, chunks);
   const dim3 grid((unsigned)cdiv((int64_t)B * W * C4, kFoldThreads), (unsigned)cdiv(H, ychunk));
-  ppm_fold_nhwc_kernel<<<grid, dim3(kFoldThreads), smem, as_stream(stream)>>>(zp, out, B, H, W, C4, ychunk, lv);
+  // The per-column table lives in LDS (48 bytes per level row and thread): all levels of (1, 2, 3, 6) at once would leave
+  // one wave per SIMD and, at the teacher's size, 1040 workgroups for 1024 slots.  Two launches over ~half the level rows
+  // each (here {1, 2, 3} and {6}) run two waves per SIMD in one round; the second pass over `out` costs less than that.
+  int k0 = 0;
+  while (k0 < nsizes) {
+    int k1 = k0 + 1, rows = lv.size[k0];
+    while (k1 < nsizes && (rows + lv.size[k1]) * 2 <= lv.rows + 1) rows += lv.size[k1++];
+    const size_t part = sizeof(float4) * (size_t)3 * rows * kFoldThreads;
+    ppm_fold_nhwc_kernel<<<grid, dim3(kFoldThreads), part, as_stream(stream)>>>(zp, out, B, H, W, C4, ychunk, lv, k0, k1);
+    k0 = k1;
+  }
   return ok();
 }
 
