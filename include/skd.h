@@ -313,13 +313,15 @@ int skd_ppm_concat_backward_nhwc(int B, int Cout, int Cfeat, int H, int W, int n
  *                         bilinear_{align_corners}(Z_k[b][.][.][tap][co]) at (y + ty - 1, x + tx - 1)
  * skd_ppm_fold_nhwc ADDS fold to `out` (B, H, W, Cout) in place (out holds the feature-map part of the convolution);
  * skd_ppm_fold_backward_nhwc writes gz_k = d loss / d Z_k from gout = d loss / d out (the gradient w.r.t. the
- * feature-map part is gout itself).  3x3 kernel, padding 1, stride 1, dilation 1; Cout % 4 == 0;
+ * feature-map part is gout itself).  ldz = distance in floats between consecutive (b, jy, jx) rows of every Z_k / gz_k
+ * (9 * Cout when dense; L * 9 * Cout when the caller computes all levels with ONE GEMM of the stacked priors against the
+ * stacked weight blocks and passes pointers to the diagonal blocks).  3x3 kernel, padding 1, stride 1, dilation 1; Cout % 4 == 0;
  * 3 * sum_k s_k <= 64 (LDS).  workspace: skd_ppm_fold_nhwc_workspace_floats() floats (backward only). */
 int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int nsizes, const int *sizes);
-int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
-                      skd_stream_t stream);
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, int64_t ldz,
+                      float *out, skd_stream_t stream);
 int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
-                               float *const *gz, float *workspace, skd_stream_t stream);
+                               float *const *gz, int64_t ldz, float *workspace, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 9. Whole-image evaluation tail, networks/evaluate.py:106-113, 186-206:

@@ -573,9 +573,10 @@ int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int ns
   return 4;
 }
 
-int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
-                      stream_t st) {
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, int64_t ldz,
+                      float *out, stream_t st) {
   (void)st;
+  if (ldz < 9 * (int64_t)Cout) return 0;
   if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !z || !out || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
   for (int k = 0; k < nsizes; ++k)
     if (!z[k] || sizes[k] <= 0) return 0;
@@ -588,7 +589,7 @@ int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *size
           for (int k = 0; k < nsizes; ++k) {
             const int s = sizes[k];
             const float sy = H > 1 ? (float)(s - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
-            const float *zk = z[k] + (int64_t)b * s * s * 9 * Cout;
+            const float *zk = z[k] + (int64_t)b * s * s * ldz;
             for (int ty = 0; ty < 3; ++ty)
               for (int tx = 0; tx < 3; ++tx) {
                 const int yp = y + ty - 1, xp = x + tx - 1;
@@ -597,7 +598,7 @@ int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *size
                 tap_of(yp, sy, s, &y0, &y1, &ly0, &ly1);
                 tap_of(xp, sx, s, &x0, &x1, &lx0, &lx1);
                 const int tap = ty * 3 + tx;
-#define ZAT(jy, jx) ((double)zk[(((int64_t)(jy) * s + (jx)) * 9 + tap) * Cout + c])
+#define ZAT(jy, jx) ((double)zk[((int64_t)(jy) * s + (jx)) * ldz + tap * Cout + c])
                 acc += (double)ly0 * ((double)lx0 * ZAT(y0, x0) + (double)lx1 * ZAT(y0, x1)) +
                        (double)ly1 * ((double)lx0 * ZAT(y1, x0) + (double)lx1 * ZAT(y1, x1));
 #undef ZAT
@@ -610,8 +611,9 @@ int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *size
 }
 
 int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
-                               float *const *gz, float *ws, stream_t st) {
+                               float *const *gz, int64_t ldz, float *ws, stream_t st) {
   (void)st; (void)ws;
+  if (ldz < 9 * (int64_t)Cout) return 0;
   if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !gout || !gz || nsizes <= 0 || nsizes > 4 || !sizes) return 0;
   for (int k = 0; k < nsizes; ++k) {
     if (!gz[k] || sizes[k] <= 0) return 0;
@@ -639,7 +641,8 @@ int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const 
                 }
             }
         }
-    for (int64_t i = 0; i < n; ++i) gz[k][i] = (float)acc[i];
+    for (int64_t r = 0; r < (int64_t)B * s * s; ++r)
+      for (int i = 0; i < 9 * Cout; ++i) gz[k][r * ldz + i] = (float)acc[r * 9 * Cout + i];
     free(acc);
   }
   return 1;

@@ -86,8 +86,8 @@ SIGNATURES = {
     "skd_ppm_concat_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "skd_ppm_concat_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "skd_ppm_fold_nhwc_workspace_floats": (_L, [_I, _I, _I, _I, _I, _P]),
-    "skd_ppm_fold_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "skd_ppm_fold_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "skd_ppm_fold_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P]),
+    "skd_ppm_fold_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
     "skd_maxpool3x3s2_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_maxpool3x3s2_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_seg_confusion": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

@@ -538,7 +538,8 @@ struct FoldGradPtrs {
 __device__ __forceinline__ float4 lds_get(const float4 *t, int e) { return t[e * kFoldThreads + threadIdx.x]; }
 
 __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp, float *__restrict__ out, int B, int H,
-                                                                     int W, int C4, int ychunk, Levels lv, int k0, int k1) {
+                                                                     int W, int C4, int ychunk, Levels lv, int k0, int k1,
+                                                                     int64_t ldz) {
   extern __shared__ __attribute__((aligned(16))) float4 tcol[];  // [3 * rows of levels k0..k1-1][kFoldThreads]
   const int64_t col = (int64_t)blockIdx.x * kFoldThreads + threadIdx.x;
   if (col >= (int64_t)B * W * C4) return;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp
   for (int k = k0; k < k1; ++k) {
     const int s = lv.size[k];
     const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
-    const float *zk = zp.z[k] + (int64_t)b * s * s * 9 * C4 * 4 + q * 4;
+    const float *zk = zp.z[k] + (int64_t)b * s * s * ldz + q * 4;
     Tap tx3[3];
     bool vx[3];
 #pragma unroll
@@ -562,9 +563,9 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_nhwc_kernel(FoldPtrs zp
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx)
           if (vx[tx]) {
-            const float *r = zk + ((int64_t)(jy * s) * 9 + ty * 3 + tx) * C4 * 4;
-            acc = f4fma(tx3[tx].l0, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i0 * 9 * C4 * 4), acc);
-            acc = f4fma(tx3[tx].l1, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i1 * 9 * C4 * 4), acc);
+            const float *r = zk + (int64_t)(jy * s) * ldz + (ty * 3 + tx) * C4 * 4;
+            acc = f4fma(tx3[tx].l0, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i0 * ldz), acc);
+            acc = f4fma(tx3[tx].l1, *reinterpret_cast<const float4 *>(r + (int64_t)tx3[tx].i1 * ldz), acc);
           }
         tcol[(3 * lv.row_off[k] - e0 + ty * s + jy) * kFoldThreads + threadIdx.x] = acc;
       }
@@ -643,42 +644,60 @@ __global__ __launch_bounds__(kFoldThreads) void ppm_fold_bwd_cols_nhwc_kernel(co
 }
 
 // transpose, bin pass: dZ_k[b][jy][jx][tap][c] = sum_chunks sum_x lx(x + tx - 1, jx) * TT[..][(k, ty, jy)][x][c], fixed order.
-// grid (lv.bins, B); items = 9 * C4
+// grid (lv.bins * 9, B): one workgroup per (bin, tap, image); threads = channel quads x column groups, the groups' partial
+// sums are combined through LDS in group order (deterministic)
 __global__ __launch_bounds__(kThreads) void ppm_fold_bwd_bins_nhwc_kernel(const float *__restrict__ ws, FoldGradPtrs gz,
-                                                                         int B, int W, int C4, int chunks, Levels lv) {
-  const int bin = blockIdx.x, b = blockIdx.y;
+                                                                         int B, int W, int C4, int chunks, Levels lv,
+                                                                         int64_t ldz) {
+  __shared__ float4 part[kThreads];
+  const int bin = blockIdx.x / 9, tap = blockIdx.x - bin * 9, b = blockIdx.y;
   int k = 0;
   while (k + 1 < lv.n && bin >= lv.bin_off[k + 1]) ++k;
   const int s = lv.size[k], j = bin - lv.bin_off[k], jy = j / s, jx = j - jy * s;
   const float sx = W > 1 ? (float)(s - 1) / (float)(W - 1) : 0.f;
-  const int E = 3 * lv.rows;
-  for (int item = threadIdx.x; item < 9 * C4; item += kThreads) {
-    const int tap = item / C4, q = item - tap * C4, ty = tap / 3, tx = tap - ty * 3;
-    const int e = 3 * lv.row_off[k] + ty * s + jy;
+  const int E = 3 * lv.rows, ty = tap / 3, tx = tap - ty * 3;
+  const int e = 3 * lv.row_off[k] + ty * s + jy;
+  // columns x' = x + tx - 1 whose bilinear taps touch bin column jx: (jx - 1) / sx < x' < (jx + 1) / sx (one column of
+  // margin either side; weights outside the support are exactly zero, so the margin only costs a load)
+  int lo = 0, hi = W - 1;
+  if (s > 1) {
+    lo = (int)floorf((float)(jx - 1) / sx) - 1 - (tx - 1);
+    hi = (int)ceilf((float)(jx + 1) / sx) + 1 - (tx - 1);
+    if (lo < 0) lo = 0;
+    if (hi > W - 1) hi = W - 1;
+  }
+  const int qn = C4 < kThreads ? C4 : kThreads, G = kThreads / qn;
+  const int ql = threadIdx.x % qn, xg = threadIdx.x / qn;
+  for (int q0 = 0; q0 < C4; q0 += qn) {
+    const int q = q0 + ql;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // columns x' = x + tx - 1 whose bilinear taps touch bin column jx: (jx - 1) / sx < x' < (jx + 1) / sx (one column of
-    // margin either side; weights outside the support are exactly zero, so the margin only costs a load)
-    int lo = 0, hi = W - 1;
-    if (s > 1) {
-      lo = (int)floorf((float)(jx - 1) / sx) - 1 - (tx - 1);
-      hi = (int)ceilf((float)(jx + 1) / sx) + 1 - (tx - 1);
-      if (lo < 0) lo = 0;
-      if (hi > W - 1) hi = W - 1;
-    }
-    for (int c = 0; c < chunks; ++c) {
-      const float *src = ws + ((((int64_t)c * B + b) * E + e) * W) * C4 * 4 + q * 4;
-#pragma unroll 4
-      for (int x = lo; x <= hi; ++x) {
-        const int xp = x + tx - 1;
-        const Tap t = tap_of(xp < 0 ? 0 : (xp >= W ? W - 1 : xp), sx, s);
-        float wt = 0.f;
-        if (t.i0 == jx) wt += t.l0;
-        if (t.i1 == jx) wt += t.l1;
-        if (xp < 0 || xp >= W) wt = 0.f;
-        acc = f4fma(wt, *reinterpret_cast<const float4 *>(src + (int64_t)x * C4 * 4), acc);
+    if (xg < G && q < C4)
+      for (int c = 0; c < chunks; ++c) {
+        const float *src = ws + ((((int64_t)c * B + b) * E + e) * W) * C4 * 4 + q * 4;
+        for (int x = lo + xg; x <= hi; x += G) {
+          const int xp = x + tx - 1;
+          if (xp < 0 || xp >= W) continue;
+          const Tap t = tap_of(xp, sx, s);
+          float wt = 0.f;
+          if (t.i0 == jx) wt += t.l0;
+          if (t.i1 == jx) wt += t.l1;
+          acc = f4fma(wt, *reinterpret_cast<const float4 *>(src + (int64_t)x * C4 * 4), acc);
+        }
       }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (xg == 0 && q < C4) {
+      float4 sum = part[ql];
+      for (int g = 1; g < G; ++g) {
+        const float4 v = part[g * qn + ql];
+        sum.x += v.x;
+        sum.y += v.y;
+        sum.z += v.z;
+        sum.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(gz.z[k] + (((int64_t)b * s + jy) * s + jx) * ldz + tap * C4 * 4 + q * 4) = sum;
     }
-    *reinterpret_cast<float4 *>(gz.z[k] + ((((int64_t)b * s + jy) * s + jx) * 9 + tap) * C4 * 4 + q * 4) = acc;
+    __syncthreads();
   }
 }
 
@@ -852,10 +871,11 @@ int64_t skd_ppm_fold_nhwc_workspace_floats(int B, int Cout, int H, int W, int ns
   return (int64_t)fold_chunks(B, H, W, Cout / 4) * B * 3 * lv.rows * W * Cout;
 }
 
-int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, float *out,
-                      skd_stream_t stream) {
+int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *const *z, int64_t ldz,
+                      float *out, skd_stream_t stream) {
   Levels lv;
   if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !z || !out || !make_levels(nsizes, sizes, lv)) return 0;
+  if (ldz < 9 * (int64_t)Cout || (ldz & 3)) return 0;
   const size_t smem = sizeof(float4) * (size_t)3 * lv.rows * kFoldThreads;
   if (smem > 64 * 1024) return 0;
   FoldPtrs zp;
@@ -872,16 +892,17 @@ int skd_ppm_fold_nhwc(int B, int Cout, int H, int W, int nsizes, const int *size
     int k1 = k0 + 1, rows = lv.size[k0];
     while (k1 < nsizes && (rows + lv.size[k1]) * 2 <= lv.rows + 1) rows += lv.size[k1++];
     const size_t part = sizeof(float4) * (size_t)3 * rows * kFoldThreads;
-    ppm_fold_nhwc_kernel<<<grid, dim3(kFoldThreads), part, as_stream(stream)>>>(zp, out, B, H, W, C4, ychunk, lv, k0, k1);
+    ppm_fold_nhwc_kernel<<<grid, dim3(kFoldThreads), part, as_stream(stream)>>>(zp, out, B, H, W, C4, ychunk, lv, k0, k1, ldz);
     k0 = k1;
   }
   return ok();
 }
 
 int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const int *sizes, const float *gout,
-                               float *const *gz, float *workspace, skd_stream_t stream) {
+                               float *const *gz, int64_t ldz, float *workspace, skd_stream_t stream) {
   Levels lv;
   if (B <= 0 || Cout <= 0 || (Cout & 3) || H <= 0 || W <= 0 || !gout || !gz || !workspace) return 0;
+  if (ldz < 9 * (int64_t)Cout || (ldz & 3)) return 0;
   if (!make_levels(nsizes, sizes, lv) || B > 65535) return 0;
   const size_t smem = sizeof(float4) * (size_t)3 * lv.rows * kFoldThreads;
   if (smem > 64 * 1024) return 0;
@@ -894,7 +915,7 @@ int skd_ppm_fold_backward_nhwc(int B, int Cout, int H, int W, int nsizes, const 
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)cdiv((int64_t)B * W * C4, kFoldThreads), (unsigned)chunks);
   ppm_fold_bwd_cols_nhwc_kernel<<<grid, dim3(kFoldThreads), smem, st>>>(gout, workspace, B, H, W, C4, ychunk, lv);
-  ppm_fold_bwd_bins_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, gp, B, W, C4, chunks, lv);
+  ppm_fold_bwd_bins_nhwc_kernel<<<dim3((unsigned)lv.bins * 9, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, gp, B, W, C4, chunks, lv, ldz);
   return ok();
 }
 

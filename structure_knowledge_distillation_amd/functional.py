@@ -17,6 +17,8 @@ All are first-order only (``once_differentiable``), like the reference's native 
 derivatives of the discriminator's stock convolutions; the spectral-norm node is traversed once,
 by the final ``d_loss.backward()``.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -260,25 +262,37 @@ def ppm_concat(priors, feats):
     return _PPMConcat.apply(feats, *priors)
 
 
+def _fold_block_ptrs(z_all, b, cout, sizes):
+    """Device addresses of the diagonal blocks of Z_all: rows of level k start at B * sum_{j<k} s_j^2, its columns at
+    k * 9 * Cout."""
+    ptrs, row = [], 0
+    ld = z_all.shape[1]
+    for k, s_ in enumerate(sizes):
+        ptrs.append(z_all.data_ptr() + 4 * (row * ld + k * 9 * cout))
+        row += b * s_ * s_
+    return (ctypes.c_void_p * len(ptrs))(*ptrs), ld
+
+
 class _PPMFold(Function):
-    """base += fold(Z_1 .. Z_L) (include/skd.h section 8), in place on the channels-last convolution output `base`."""
+    """base += fold(Z_1 .. Z_L) (include/skd.h section 8), in place on the channels-last convolution output `base`.
+    z_all: (B * sum_k s_k^2, L * 9 * Cout), the product of the stacked priors with the stacked weight blocks; level k's Z
+    is its k-th diagonal block (the off-diagonal blocks are never read, and receive zero gradient)."""
 
     @staticmethod
-    def forward(ctx, base, sizes, *zs):
-        _lib.require_device(base, *zs)
+    def forward(ctx, base, sizes, z_all):
+        _lib.require_device(base, z_all)
         b, cout, h, w = base.shape
         if cout % 4 or not base.is_contiguous(memory_format=torch.channels_last) or base.dtype != torch.float32:
             raise ValueError("ppm_fold: base must be a float32 channels-last (B, Cout, H, W) tensor")
-        if len(zs) != len(sizes):
-            raise ValueError("ppm_fold: one Z per pyramid level")
-        for z, s_ in zip(zs, sizes):
-            if z.dtype != torch.float32 or not z.is_contiguous() or z.numel() != b * s_ * s_ * 9 * cout:
-                raise ValueError("ppm_fold: Z_k must be a contiguous float32 (B*s*s, 9*Cout) tensor")
+        rows = b * sum(s_ * s_ for s_ in sizes)
+        if z_all.dtype != torch.float32 or not z_all.is_contiguous() or tuple(z_all.shape) != (rows, len(sizes) * 9 * cout):
+            raise ValueError("ppm_fold: Z must be a contiguous float32 (B * sum s^2, L * 9 * Cout) tensor")
         lib, st = _lib.get(), _lib.stream_of(base)
-        _lib.check(lib.skd_ppm_fold_nhwc(b, cout, h, w, len(sizes), _lib.int_array(sizes), _lib.ptr_array(list(zs)),
-                                         base.data_ptr(), st), "skd_ppm_fold_nhwc")
+        ptrs, ld = _fold_block_ptrs(z_all, b, cout, sizes)
+        _lib.check(lib.skd_ppm_fold_nhwc(b, cout, h, w, len(sizes), _lib.int_array(sizes), ptrs, ld, base.data_ptr(), st),
+                   "skd_ppm_fold_nhwc")
         ctx.geom = (b, cout, h, w, tuple(sizes))
-        ctx.zshapes = [z.shape for z in zs]
+        ctx.zshape = z_all.shape
         ctx.mark_dirty(base)
         return base
 
@@ -287,15 +301,16 @@ class _PPMFold(Function):
     def backward(ctx, gout):
         b, cout, h, w, sizes = ctx.geom
         gout = _cl(gout.to(torch.float32))
-        gzs = [None] * len(sizes)
-        if any(ctx.needs_input_grad[2:]):
+        gz = None
+        if ctx.needs_input_grad[2]:
             lib, st = _lib.get(), _lib.stream_of(gout)
             arr = _lib.int_array(sizes)
-            gzs = [gout.new_empty(shape) for shape in ctx.zshapes]
+            gz = gout.new_zeros(ctx.zshape)
+            ptrs, ld = _fold_block_ptrs(gz, b, cout, sizes)
             ws = gout.new_empty((max(1, lib.skd_ppm_fold_nhwc_workspace_floats(b, cout, h, w, len(sizes), arr)),))
-            _lib.check(lib.skd_ppm_fold_backward_nhwc(b, cout, h, w, len(sizes), arr, gout.data_ptr(), _lib.ptr_array(gzs),
+            _lib.check(lib.skd_ppm_fold_backward_nhwc(b, cout, h, w, len(sizes), arr, gout.data_ptr(), ptrs, ld,
                                                       ws.data_ptr(), st), "skd_ppm_fold_backward_nhwc")
-        return (gout if ctx.needs_input_grad[0] else None, None) + tuple(gzs)
+        return gout if ctx.needs_input_grad[0] else None, None, gz
 
 
 def ppm_fold_supported(feats, sizes):
@@ -319,14 +334,17 @@ def ppm_fold_bottleneck(priors, feats, weight, cache=None):
     mats = cache.get("mats") if cache is not None and cache.get("key") == key else None
     if mats is None:
         wf = weight[:, n_prior:].contiguous(memory_format=torch.channels_last)
-        wk = [weight[:, k * cm:(k + 1) * cm].permute(1, 2, 3, 0).reshape(cm, 9 * cout) for k in range(len(priors))]
-        mats = (wf, wk)
+        # (Cout, L, Cm, 3, 3) -> (Cm, L, 3, 3, Cout): column block k of the (Cm, L * 9 * Cout) matrix is level k's weights
+        w_all = weight[:, :n_prior].reshape(cout, len(priors), cm, 3, 3).permute(2, 1, 3, 4, 0).reshape(cm, len(priors) * 9 * cout)
+        mats = (wf, w_all)
         if cache is not None and not (torch.is_grad_enabled() and weight.requires_grad):
             cache["key"], cache["mats"] = key, mats
-    wf, wk = mats
+    wf, w_all = mats
     base = F.conv2d(feats, wf, None, 1, 1)
-    zs = [torch.mm(_cl(p).permute(0, 2, 3, 1).reshape(-1, cm), m) for p, m in zip(priors, wk)]
-    return _PPMFold.apply(base, sizes, *zs)
+    # ONE GEMM of all levels' priors against all levels' weight blocks (only the diagonal blocks are used: 4x the
+    # necessary flops of a 2 GFLOP product, but a single well-shaped library call instead of four skinny ones)
+    p_all = torch.cat([_cl(p).permute(0, 2, 3, 1).reshape(-1, cm) for p in priors], 0)
+    return _PPMFold.apply(base, sizes, torch.mm(p_all, w_all))
 
 
 class _MaxPool3x3s2(Function):

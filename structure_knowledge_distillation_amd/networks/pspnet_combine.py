@@ -246,10 +246,12 @@ class ResNet(nn.Module):
         x3 = self.layer3(x2)
         # the deep-supervision head feeds only CriterionDSN; a frozen network whose CE nobody computes may skip it
         # (NetModel sets skip_dsn on the teacher when SKD_TEACHER_DSN=0; default: computed, like the reference)
-        mm_heads = os.environ.get("SKD_HEAD_MM", "1") == "1"
+        # the 19-class 1x1 classifiers as skinny GEMMs: measured SLOWER than MIOpen here (rocBLAS picks a 311 us kernel for
+        # the 19 x 128 weight gradient over 33800 rows; 67.5 vs 67.2 ms per step), so off unless asked for
+        mm_heads = os.environ.get("SKD_HEAD_MM", "0") == "1"
         if getattr(self, "skip_dsn", False) and not torch.is_grad_enabled():
             x_dsn = None
-        elif mm_heads:     # the 19-channel classifier as one skinny GEMM (MIOpen: 37 us forward + 95 us backward for 0.2 GFLOP)
+        elif mm_heads:
             x_dsn = _conv1x1_as_mm(self.dsn[3], self.dsn[2](self.dsn[1](self.dsn[0](x3))))
         else:
             x_dsn = self.dsn(x3)

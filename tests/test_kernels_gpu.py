@@ -837,37 +837,59 @@ def test_ppm_fold(hip, ref, geom):
     B, Cout, H, W, sizes = geom
     L = len(sizes)
     arr = (ctypes.c_int * L)(*sizes)
+    LD = 9 * Cout                                                     # dense rows; the strided form is checked below
     g = torch.Generator().manual_seed(Cout + H + W)
     zs = [torch.randn(B * s * s, 9 * Cout, generator=g) for s in sizes]
     base = torch.randn(B, H, W, Cout, generator=g)
     out_r = base.clone()
-    assert ref.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zs]), P(out_r), None)
+    assert ref.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zs]), LD, P(out_r), None)
     zg = [gpu(z) for z in zs]
     out_g = gpu(base)
-    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), LD, P(out_g), None)
     close(out_g, out_r, 2e-5, "fold forward")
     # a second call accumulates on top (in-place += contract)
-    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), LD, P(out_g), None)
     close(out_g, 2 * out_r - base, 2e-5, "fold forward accumulates")
     gout = torch.randn(B, H, W, Cout, generator=g)
     gr = [torch.full_like(z, float("nan")) for z in zs]
-    assert ref.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gout), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gr]), P(torch.empty(8)), None)
+    assert ref.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gout), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gr]), LD, P(torch.empty(8)), None)
     nws = hip.skd_ppm_fold_nhwc_workspace_floats(B, Cout, H, W, L, arr)
     assert nws > 0
     ws = torch.full((nws,), float("nan"), device=DEV)
     gg = [torch.full_like(z, float("nan")) for z in zg]
-    assert hip.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gpu(gout)), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gg]), P(ws), None)
+    assert hip.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gpu(gout)), (ctypes.c_void_p * L)(*[t.data_ptr() for t in gg]), LD, P(ws), None)
     for k in range(L):
         close(gg[k], gr[k], 2e-5, "fold backward level %d" % sizes[k], floor=float(gout.abs().max()))
     # transpose identity at full precision: <fold(Z), G> == <Z, fold^T(G)>
     zero = torch.zeros(B, H, W, Cout, device=DEV)
-    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(zero), None)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), LD, P(zero), None)
     lhs = float((zero.double() * gpu(gout).double()).sum())
     rhs = sum(float((zg[k].double() * gg[k].double()).sum()) for k in range(L))
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), float(zero.double().norm() * gout.double().norm()) * 1e-2), (lhs, rhs)
     # rejected: channel count not a multiple of 4, missing pointers
-    assert hip.skd_ppm_fold_nhwc(B, Cout + 1, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), P(out_g), None) == 0
-    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, None, P(out_g), None) == 0
+    assert hip.skd_ppm_fold_nhwc(B, Cout + 1, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), LD, P(out_g), None) == 0
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, None, LD, P(out_g), None) == 0
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*[z.data_ptr() for z in zg]), LD - 4, P(out_g), None) == 0
+    # strided rows: the levels as diagonal blocks of one (sum B s^2, L * 9 * Cout) matrix whose other blocks hold NaN
+    rows = [B * s * s for s in sizes]
+    z_all = torch.full((sum(rows), L * LD), float("nan"), device=DEV)
+    g_all = torch.zeros_like(z_all)
+    zp, gp, r0 = [], [], 0
+    for k in range(L):
+        z_all[r0:r0 + rows[k], k * LD:(k + 1) * LD] = zg[k]
+        zp.append(z_all.data_ptr() + 4 * (r0 * L * LD + k * LD))
+        gp.append(g_all.data_ptr() + 4 * (r0 * L * LD + k * LD))
+        r0 += rows[k]
+    out_s = gpu(base)
+    assert hip.skd_ppm_fold_nhwc(B, Cout, H, W, L, arr, (ctypes.c_void_p * L)(*zp), L * LD, P(out_s), None)
+    close(out_s, out_r, 2e-5, "fold forward, strided Z")
+    assert hip.skd_ppm_fold_backward_nhwc(B, Cout, H, W, L, arr, P(gpu(gout)), (ctypes.c_void_p * L)(*gp), L * LD, P(ws), None)
+    r0 = 0
+    for k in range(L):
+        assert torch.equal(g_all[r0:r0 + rows[k], k * LD:(k + 1) * LD], gg[k])
+        g_all[r0:r0 + rows[k], k * LD:(k + 1) * LD] = 0
+        r0 += rows[k]
+    assert float(g_all.abs().max()) == 0.0                            # nothing written outside the diagonal blocks
 
 
 @pytest.mark.parametrize("cfg", [(2, 512, 128, 65, 65, True), (2, 2048, 512, 33, 33, False), (1, 64, 16, 129, 257, False)])
