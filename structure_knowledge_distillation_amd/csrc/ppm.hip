@@ -342,9 +342,11 @@ __global__ __launch_bounds__(kThreads) void ppm_cells_nhwc_kernel(const float *_
   }
 }
 
-// pooled level k, (B, s, s, C): mean over the bin = sum of its cells / area.   grid (bins, B)
+// pooled level k, (B, s, s, C): mean over the bin = sum of its cells / area.   grid (bins, B, ceil(C4 / 64)): a wave of
+// channel quads x four groups that split the bin's cell list; the groups' sums meet in LDS in group order
 __global__ __launch_bounds__(kThreads) void ppm_bins_nhwc_kernel(const float *__restrict__ cells, float *__restrict__ pooled,
                                                                 int B, int H, int W, int C4, Cuts cu, Levels lv) {
+  __shared__ float4 part[kThreads];
   const int bin = blockIdx.x, b = blockIdx.y;
   int k = 0;
   while (k + 1 < lv.n && bin >= lv.bin_off[k + 1]) ++k;
@@ -361,10 +363,20 @@ __global__ __launch_bounds__(kThreads) void ppm_bins_nhwc_kernel(const float *__
   const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
   const float *src = cells + (int64_t)b * cu.ny * cu.nx * C4 * 4;
   float *dst = pooled + ((int64_t)B * lv.bin_off[k] + ((int64_t)b * s * s + local)) * C4 * 4;
-  for (int q = threadIdx.x; q < C4; q += kThreads) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int v = va; v < vb; ++v)
-      for (int u = ua; u < ub; ++u) acc = f4add(acc, *reinterpret_cast<const float4 *>(src + ((int64_t)v * cu.nx + u) * C4 * 4 + q * 4));
+  constexpr int kGroups = kThreads / 64;
+  const int ql = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int q = blockIdx.z * 64 + ql;
+  const int nu = ub - ua, n = (vb - va) * nu;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < C4)
+    for (int c = g; c < n; c += kGroups) {
+      const int v = va + c / nu, u = ua + c % nu;
+      acc = f4add(acc, *reinterpret_cast<const float4 *>(src + ((int64_t)v * cu.nx + u) * C4 * 4 + q * 4));
+    }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (g == 0 && q < C4) {
+    for (int r = 1; r < kGroups; ++r) acc = f4add(acc, part[r * 64 + ql]);
     *reinterpret_cast<float4 *>(dst + q * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
 }
@@ -803,7 +815,7 @@ int skd_ppm_pool_nhwc(int B, int C, int H, int W, int nsizes, const int *sizes, 
   if (!make_levels(nsizes, sizes, lv) || !make_cuts(H, W, lv, cu)) return 0;
   hipStream_t st = as_stream(stream);
   ppm_cells_nhwc_kernel<<<dim3((unsigned)(cu.ny * cu.nx), (unsigned)B), dim3(kThreads), 0, st>>>(x, workspace, H, W, C / 4, cu);
-  ppm_bins_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B), dim3(kThreads), 0, st>>>(workspace, pooled, B, H, W, C / 4, cu, lv);
+  ppm_bins_nhwc_kernel<<<dim3((unsigned)lv.bins, (unsigned)B, (unsigned)cdiv(C / 4, 64)), dim3(kThreads), 0, st>>>(workspace, pooled, B, H, W, C / 4, cu, lv);
   return ok();
 }
 
