@@ -228,7 +228,8 @@ def main():
     timed = ["skd_abn_apply_nhwc", "skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
              "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx",
              "skd_abn_forward_train_nhwc", "skd_abn_backward_reduce_nhwc", "skd_abn_backward_dx_nhwc",
-             "skd_abn_relu_backward_reduce_nhwc", "skd_abn_relu_backward_dx_nhwc"]
+             "skd_abn_relu_backward_reduce_nhwc", "skd_abn_relu_backward_dx_nhwc",
+             "skd_abn_relu_backward_reduce_nhwc_x", "skd_abn_relu_backward_dx_nhwc_x"]
     # Inside the timed region only the ROOFLINE entry is bracketed with HIP events (111 calls per step; bracketing all
     # ~700 hand-written calls costs 1.4 ms = 1.8 % of the step -- measured, profiles/r02 notes); the table of the other
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
@@ -299,6 +300,8 @@ def main():
             "skd_abn_forward_train_nhwc (channels-last student: stats+finalize+apply, >=12 B/elem)": summarise(recs.get("skd_abn_forward_train_nhwc", []), 12, nhwc="train"),
             "skd_abn_relu_backward_reduce_nhwc (12 B/elem)": summarise(recs.get("skd_abn_relu_backward_reduce_nhwc", []), 12, nhwc="train"),
             "skd_abn_relu_backward_dx_nhwc (>=16 B/elem)": summarise(recs.get("skd_abn_relu_backward_dx_nhwc", []), 16, nhwc="train"),
+            "skd_abn_relu_backward_reduce_nhwc_x (no residual: mask from x, 8 B/elem)": summarise(recs.get("skd_abn_relu_backward_reduce_nhwc_x", []), 8, nhwc="train"),
+            "skd_abn_relu_backward_dx_nhwc_x (no residual: mask from x, 12 B/elem)": summarise(recs.get("skd_abn_relu_backward_dx_nhwc_x", []), 12, nhwc="train"),
             "skd_abn_backward_reduce_nhwc (leaky ABN, 8 B/elem)": summarise(recs.get("skd_abn_backward_reduce_nhwc", []), 8, nhwc="train"),
             "skd_abn_backward_dx_nhwc (leaky ABN, 12 B/elem)": summarise(recs.get("skd_abn_backward_dx_nhwc", []), 12, nhwc="train"),
         }

@@ -151,6 +151,16 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
                                   const float *mean, const float *var, const float *weight, const float *edz,
                                   const float *eydz, float *dx, float *dres, float *dweight, float *dbias,
                                   float eps, int accumulate, skd_stream_t stream);
+/* The same two passes for a forward WITHOUT residual: the ReLU mask is then a function of x alone
+ * (((x - mean) * invStd) * gamma + beta > 0, evaluated with the forward pass's own expression), so `out` is not read:
+ * 8 instead of 12 bytes per element in the reduce pass, 12 instead of 16 in the dx pass. */
+int skd_abn_relu_backward_reduce_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                        const float *var, const float *weight, const float *bias, float *edz,
+                                        float *eydz, float eps, float *workspace, skd_stream_t stream);
+int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                    const float *var, const float *weight, const float *bias, const float *edz,
+                                    const float *eydz, float *dx, float *dweight, float *dbias, float eps,
+                                    int accumulate, skd_stream_t stream);
 /* cross-replica combine in one launch (functions.py:196-197, 208-209): gathered is (G, 2, C) = every rank's
  * [mean, var]; writes the combined mean / var and, when the running buffers are given, updates them.
  * weights == NULL: the reference rule (equal per-rank sample counts), n = the POOLED count.

@@ -477,6 +477,37 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
   return r;
 }
 
+/* forward WITHOUT residual: the ReLU mask is a function of x alone, so `out` need not be read -- here it is simply
+ * re-created with the oracle's own forward expression and handed to the entries above */
+static float *relu_out_from_x(int64_t rows, int C, const float *x, const float *mean, const float *var, const float *weight,
+                              const float *bias, float eps) {
+  float *out = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (out && !skd_abn_apply_nhwc_to(rows, C, x, NULL, out, mean, var, weight, bias, eps, ACT_RELU, 0.f, NULL)) { free(out); out = NULL; }
+  return out;
+}
+
+int skd_abn_relu_backward_reduce_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                        const float *var, const float *weight, const float *bias, float *edz, float *eydz,
+                                        float eps, float *ws, stream_t st) {
+  if (!nhwc_ok(rows, C) || !x || !dout) return 0;
+  float *out = relu_out_from_x(rows, C, x, mean, var, weight, bias, eps);
+  const int r = out ? skd_abn_relu_backward_reduce_nhwc(rows, C, x, out, dout, mean, var, edz, eydz, eps, ws, st) : 0;
+  free(out);
+  return r;
+}
+
+int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                    const float *var, const float *weight, const float *bias, const float *edz,
+                                    const float *eydz, float *dx, float *dweight, float *dbias, float eps, int accumulate,
+                                    stream_t st) {
+  if (!nhwc_ok(rows, C) || !x || !dout || !dx) return 0;
+  float *out = relu_out_from_x(rows, C, x, mean, var, weight, bias, eps);
+  const int r = out ? skd_abn_relu_backward_dx_nhwc(rows, C, x, out, dout, mean, var, weight, edz, eydz, dx, NULL, dweight,
+                                                    dbias, eps, accumulate, st) : 0;
+  free(out);
+  return r;
+}
+
 /* ---- cross-replica combine, libs/functions.py:196-197 + 208-209 ----
  * weights == NULL is the reference rule; weights (w_g = n_g / sum n) the pooled statistics of unequal shards. */
 int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var,

@@ -924,6 +924,12 @@ static bool make_nhwc_geom(int64_t rows, int C, NhwcGeom &g) {
   return true;
 }
 
+// The pre-activation of the fused BN (+ residual) + ReLU, as ONE expression shared by the forward pass and by the backward
+// passes that recompute the ReLU mask from x instead of reading `out` (MODE 2): same instructions, same bits, same sign.
+__device__ __forceinline__ float bn_pre(float x, float m, float is, float gm, float b) {
+  return __builtin_fmaf((x - m) * is, gm, b);
+}
+
 // K2 (NHWC), out of place or in place: out = act(bn(x) [+ residual]) with given mean / var
 template <int ACT, bool HAS_RES>
 __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_train_kernel(const float *x, const float *res, float *out,
@@ -958,16 +964,17 @@ __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_train_kernel(const fl
     const int64_t r = r0 + (int64_t)u * g.rpp;
     if (r < rows) {
       float4 z;
-      z.x = act_fwd<ACT>(((v[u].x - m[0]) * is[0]) * gm[0] + b[0] + (HAS_RES ? r4[u].x : 0.f), slope);
-      z.y = act_fwd<ACT>(((v[u].y - m[1]) * is[1]) * gm[1] + b[1] + (HAS_RES ? r4[u].y : 0.f), slope);
-      z.z = act_fwd<ACT>(((v[u].z - m[2]) * is[2]) * gm[2] + b[2] + (HAS_RES ? r4[u].z : 0.f), slope);
-      z.w = act_fwd<ACT>(((v[u].w - m[3]) * is[3]) * gm[3] + b[3] + (HAS_RES ? r4[u].w : 0.f), slope);
+      z.x = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].x, m[0], is[0], gm[0], b[0]) + r4[u].x : bn_pre(v[u].x, m[0], is[0], gm[0], b[0]), slope);
+      z.y = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].y, m[1], is[1], gm[1], b[1]) + r4[u].y : bn_pre(v[u].y, m[1], is[1], gm[1], b[1]), slope);
+      z.z = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].z, m[2], is[2], gm[2], b[2]) + r4[u].z : bn_pre(v[u].z, m[2], is[2], gm[2], b[2]), slope);
+      z.w = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].w, m[3], is[3], gm[3], b[3]) + r4[u].w : bn_pre(v[u].w, m[3], is[3], gm[3], b[3]), slope);
       *reinterpret_cast<float4 *>(out + (r << (g.log2C4 + 2)) + cq * 4) = z;
     }
   }
 }
 
-// K4 (NHWC): dx (and dres for MODE 1), dweight / dbias by workgroup 0
+// K4 (NHWC): dx (and dres for MODE 1), dweight / dbias by workgroup 0.  MODE 2 = MODE 1 for a forward WITHOUT residual:
+// inputs (x, dout), the ReLU mask is recomputed from x (bn_pre > 0) -- 4 bytes per element less than reading `out`.
 template <int ACT, int MODE, bool WRITE_RES>
 __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
     const float *a_, const float *b_, const float *c_, const float *__restrict__ mean,
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
     float *dbias, float eps, float slope, int64_t rows, NhwcGeom g, int accumulate) {
   const int t = threadIdx.x;
   const int cq = t & (g.C4 - 1), rsub = t >> g.log2C4;
-  float p0[4], p1[4], e[4], ey[4], mul[4];
+  float p0[4], p1[4], e[4], ey[4], mul[4], gm[4], bt[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = cq * 4 + k;
@@ -988,6 +995,8 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
       p0[k] = mean[c];
       p1[k] = is;
     }
+    gm[k] = gam;
+    bt[k] = MODE == 2 ? beta_of(bias, c) : 0.f;
     e[k] = edz[c];
     ey[k] = eydz[c];
     mul[k] = gam * is;
@@ -1022,8 +1031,11 @@ __global__ __launch_bounds__(kThreads) void abn_grad_dx_nhwc_kernel(
           dz = B[k];
           act_undo<ACT>(zv, dz, slope, inv_slope);
           y = (zv - p0[k]) / p1[k];
-        } else {
+        } else if (MODE == 1) {
           dz = B[k] > 0.f ? Cc[k] : 0.f;
+          y = (A[k] - p0[k]) * p1[k];
+        } else {
+          dz = bn_pre(A[k], p0[k], p1[k], gm[k], bt[k]) > 0.f ? B[k] : 0.f;   // (x, dout)
           y = (A[k] - p0[k]) * p1[k];
         }
         D[k] = (dz - e[k] - y * ey[k]) * mul[k];
@@ -1285,6 +1297,7 @@ __global__ __launch_bounds__(kRedThreads) void abn_stats_nhwc2_kernel(
 
 // K3 (NHWC): edz / eydz.  MODE 0: y from the saved OUTPUT z (activation ACT undone in registers, the in-place ABN);
 // MODE 1: fused BN+ReLU: inputs (x, out, dout), y from x, mask = out > 0.
+// MODE 2: the same for a forward without residual: inputs (x, dout), mask = bn_pre(x) > 0 recomputed.
 template <int ACT, int MODE, int U>
 __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
     const float *__restrict__ a_, const float *__restrict__ b_, const float *__restrict__ c_,
@@ -1298,7 +1311,7 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
   const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
   const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
   const int col = (cb * g.CW4 + cq) * 4;
-  float p0[4], p1[4];  // MODE 0: beta, gamma   MODE 1: mean, inv_std
+  float p0[4], p1[4], gm[4], bt[4];  // MODE 0: beta, gamma   MODE 1 / 2: mean, inv_std (+ gamma, beta for the mask in MODE 2)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (MODE == 0) {
@@ -1308,6 +1321,8 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
       p0[k] = mean[col + k];
       p1[k] = inv_std_of(var[col + k], eps);
     }
+    gm[k] = MODE == 2 ? gamma_of(weight, col + k, eps) : 0.f;
+    bt[k] = MODE == 2 ? beta_of(bias, col + k) : 0.f;
   }
   const float inv_slope = 1.f / slope;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1340,8 +1355,11 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
             dz = B[k];
             act_undo<ACT>(zv, dz, slope, inv_slope);
             y = (zv - p0[k]) / p1[k];
-          } else {
+          } else if (MODE == 1) {
             dz = B[k] > 0.f ? Cc[k] : 0.f;          // (x, out, dout)
+            y = (A[k] - p0[k]) * p1[k];
+          } else {
+            dz = bn_pre(A[k], p0[k], p1[k], gm[k], bt[k]) > 0.f ? B[k] : 0.f;   // (x, dout)
             y = (A[k] - p0[k]) * p1[k];
           }
           s1[k] += dz;
@@ -1750,6 +1768,34 @@ int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const
   if (cnt == nullptr) return 0;
   abn_grad_nhwc2_kernel<SKD_ACT_NONE, 1, kGrad1U><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
       x, out, dout, mean, var, nullptr, nullptr, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
+  return ok();
+}
+
+int skd_abn_relu_backward_reduce_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                        const float *var, const float *weight, const float *bias, float *edz, float *eydz,
+                                        float eps, float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !dout || !mean || !var || !edz || !eydz || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(dout)) return 0;
+  hipStream_t st = as_stream(stream);
+  RedGeom rg;
+  if (!make_red_geom(rows, C, kGrad0U, rg)) return 0;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  abn_grad_nhwc2_kernel<SKD_ACT_NONE, 2, kGrad0U><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
+      x, dout, nullptr, mean, var, weight, bias, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
+  return ok();
+}
+
+int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean,
+                                    const float *var, const float *weight, const float *bias, const float *edz,
+                                    const float *eydz, float *dx, float *dweight, float *dbias, float eps, int accumulate,
+                                    skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || !x || !dout || !mean || !var || !edz || !eydz || !dx) return 0;
+  if (!aligned16(x) || !aligned16(dout) || !aligned16(dx) || (dweight && !weight)) return 0;
+  abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 2, false><<<dim3((unsigned)g.P), dim3(kThreads), 0, as_stream(stream)>>>(
+      x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight, dbias, eps, 0.f, rows, g, accumulate);
   return ok();
 }
 

@@ -17,6 +17,8 @@ comm.gather / broadcast_coalesced inside one process) is replaced by one-process
 collectives on a torch.distributed group (RCCL over xGMI): all_gather of [mean, var] followed by
 the reference's combine rule, and an averaged all_reduce of [edz, eydz].
 """
+import os
+
 import torch
 import torch.autograd as autograd
 import torch.distributed as dist
@@ -168,12 +170,24 @@ class _Geom:
                       edz.data_ptr(), eydz.data_ptr(), _lib.ptr(dx), _lib.ptr(dweight), _lib.ptr(dbias), eps, act, slope,
                       st), "skd_abn_backward_dx")
 
-    def relu_backward_reduce(self, lib, x, out, dout, mean, var, edz, eydz, eps, ws, st):
+    def relu_backward_reduce(self, lib, x, out, dout, mean, var, edz, eydz, eps, ws, st, weight=None, bias=None):
+        if out is None:      # channels-last forward without residual: the mask is recomputed from x (4 B/element less)
+            _lib.check(lib.skd_abn_relu_backward_reduce_nhwc_x(self.rows, self.c, x.data_ptr(), dout.data_ptr(), mean.data_ptr(),
+                                                               var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(),
+                                                               eydz.data_ptr(), eps, ws.data_ptr(), st),
+                       "skd_abn_relu_backward_reduce_nhwc_x")
+            return
         fn = lib.skd_abn_relu_backward_reduce_nhwc if self.nhwc else lib.skd_abn_relu_backward_reduce
         _lib.check(fn(*self._d(), x.data_ptr(), out.data_ptr(), dout.data_ptr(), mean.data_ptr(), var.data_ptr(),
                       edz.data_ptr(), eydz.data_ptr(), eps, ws.data_ptr(), st), "skd_abn_relu_backward_reduce")
 
-    def relu_backward_dx(self, lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, st):
+    def relu_backward_dx(self, lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, st, bias=None):
+        if out is None:
+            _lib.check(lib.skd_abn_relu_backward_dx_nhwc_x(self.rows, self.c, x.data_ptr(), dout.data_ptr(), mean.data_ptr(),
+                                                           var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(),
+                                                           eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dweight), _lib.ptr(dbias),
+                                                           eps, 0, st), "skd_abn_relu_backward_dx_nhwc_x")
+            return
         if self.nhwc:
             _lib.check(lib.skd_abn_relu_backward_dx_nhwc(self.rows, self.c, x.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                                          mean.data_ptr(), var.data_ptr(), _lib.ptr(weight), edz.data_ptr(),
@@ -344,13 +358,16 @@ class _ABNRelu(autograd.Function):
             mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
             geo.apply_to(lib, x, residual, out, mean, var, weight, bias, ctx.eps, relu, 0.0, st)
         ctx.has_residual = residual is not None
-        ctx.save_for_backward(x, out, weight, mean, var)
+        # without a residual the ReLU mask is a function of x alone: the channels-last backward recomputes it instead of
+        # reading `out` (which stays alive anyway as the next layer's input, but is not touched again here)
+        ctx.mask_from_x = geo.nhwc and residual is None and os.environ.get("SKD_ABN_MASK_FROM_X", "1") == "1"
+        ctx.save_for_backward(x, None if ctx.mask_from_x else out, weight, bias, mean, var)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        x, out, weight, mean, var = ctx.saved_tensors
+        x, out, weight, bias, mean, var = ctx.saved_tensors
         need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
         need_res = ctx.has_residual and ctx.needs_input_grad[5]
         geo = _Geom(x)
@@ -366,10 +383,10 @@ class _ABNRelu(autograd.Function):
         stat = x.new_empty((2, c))
         edz, eydz = stat[0], stat[1]
         ws = geo.workspace(lib, x)
-        geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st)
+        geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st, weight=weight, bias=bias)
         if ctx.group is not None:
             _sync_grad_stats(stat, ctx.group)
-        geo.relu_backward_dx(lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, ctx.eps, st)
+        geo.relu_backward_dx(lib, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, ctx.eps, st, bias=bias)
         return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
 
 

@@ -279,6 +279,21 @@ def test_abn_nhwc_training(hip, ref, rows, C, act):
         close(dwg, dwr, 5e-5, "relu dweight", floor=1e-6); close(dbg, dbr, 5e-5, "relu dbias", floor=1e-6)
         if res is not None:
             assert torch.equal(drg.cpu(), drr)
+        else:
+            # forward without residual: the `_x` entries recompute the ReLU mask from x with the forward pass's own
+            # expression -- exactly the mask of the forward's output (out2), so dx is bit-identical to the entry that reads it
+            dzg, mrg, vrg, wg_, bg_ = gpu(dz), gpu(mr), gpu(vr), gpu(w), gpu(b)
+            ea, eya, eb, eyb = (torch.empty(C, device=DEV) for _ in range(4))
+            assert hip.skd_abn_relu_backward_reduce_nhwc(rows, C, P(xg), P(out2), P(dzg), P(mrg), P(vrg), P(ea), P(eya), 1e-5, P(ws_g), None)
+            assert hip.skd_abn_relu_backward_reduce_nhwc_x(rows, C, P(xg), P(dzg), P(mrg), P(vrg), P(wg_), P(bg_), P(eb), P(eyb), 1e-5, P(ws_g), None)
+            close(eb, ea, 2e-6, "edz, mask from x", floor=1e-3); close(eyb, eya, 2e-6, "eydz, mask from x", floor=1e-3)
+            dxa, dxb = torch.empty(rows, C, device=DEV), torch.full((rows, C), float("nan"), device=DEV)
+            dwa, dba, dwb, dbb = (torch.full((C,), float("nan"), device=DEV) for _ in range(4))
+            assert hip.skd_abn_relu_backward_dx_nhwc(rows, C, P(xg), P(out2), P(dzg), P(mrg), P(vrg), P(wg_), P(ea), P(eya), P(dxa), None, P(dwa), P(dba), 1e-5, 0, None)
+            assert hip.skd_abn_relu_backward_dx_nhwc_x(rows, C, P(xg), P(dzg), P(mrg), P(vrg), P(wg_), P(bg_), P(ea), P(eya), P(dxb), P(dwb), P(dbb), 1e-5, 0, None)
+            assert torch.equal(dxa, dxb) and torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+            assert ref.skd_abn_relu_backward_reduce_nhwc_x(rows, C, P(x), P(dz), P(mr), P(vr), P(w), P(b), P(er), P(eyr), 1e-5, P(ws_r), None)
+            close(eb, er, 5e-5, "edz, mask from x vs oracle"); close(eyb, eyr, 5e-5, "eydz, mask from x vs oracle")
     assert hip.skd_abn_nhwc_workspace_floats(100, 48) == 0     # not a power of two: caller must use NCHW
 
 

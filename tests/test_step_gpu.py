@@ -524,3 +524,39 @@ def test_channels_last_abn_any_channel_count(C):
         outs.append((y.detach(), xi.grad, ri.grad, mod.weight.grad, mod.bias.grad, z.detach(), e, mod.running_var.clone()))
     for a, b in zip(*outs):
         assert rel(a, b) < 1e-5
+
+
+def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
+    """NetModel.optimize_parameters() with the D step on its own HIP stream (default) against the strictly serial order of
+    kd_model.py:167-173 -- three consecutive steps from the same seed, so that a D step released too early (before the student
+    loss has back-propagated through D) or a student step reading a half-updated D would show up in the following steps'
+    losses and in the parameters.  Differences allowed: MIOpen's atomic split-K weight gradients (run-to-run noise)."""
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SKD_D_STREAM", flag)
+        torch.manual_seed(99)
+        args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
+        model = NetModel(args)
+        assert (model._d_stream is not None) == (flag == "1")
+        with torch.no_grad():
+            model.D_model.attn1.gamma.fill_(0.25)
+            model.D_model.attn2.gamma.fill_(-0.5)
+        losses = []
+        for step in range(3):
+            images, labels = O.synthetic_batch(2, 512, 512, seed=step)
+            model.gp_alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step)).to(DEV)
+            model.adjust_learning_rate(args.lr_g, model.G_solver, step)
+            model.adjust_learning_rate(args.lr_d, model.D_solver, step)
+            torch.manual_seed(500 + step)                       # Dropout2d masks
+            model.set_input((images, labels, None, None))
+            model.optimize_parameters()
+            losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
+        torch.cuda.synchronize()
+        outs[flag] = (losses, cpu_sd(model.student), cpu_sd(model.D_model))
+    for step in range(3):
+        for a, b in zip(outs["1"][0][step], outs["0"][0][step]):
+            assert abs(a - b) <= 2e-5 * max(abs(b), 1e-2), (step, outs["1"][0][step], outs["0"][0][step])
+    for which in (1, 2):
+        for k, v in outs["0"][which].items():
+            if v.dtype.is_floating_point:
+                assert rel(outs["1"][which][k], v) < 2e-5, (k, rel(outs["1"][which][k], v))

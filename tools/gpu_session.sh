@@ -125,6 +125,16 @@ EOF
         (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab4_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab4.err
         stamp "bench_ab4 $v rc=$?"; cut -c1-260 "$O/bench_ab4_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
       done ;;
+    tests_mask)
+      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
+        -k "nhwc_training or full_step_vs_oracle or config1 or d_stream or relu" > $O/pytest_mask.log 2>&1
+      stamp "tests_mask rc=$?"; grep -E "passed|failed|error" $O/pytest_mask.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  " $O/pytest_mask.log | head -30 | tee -a $O/session.log ;;
+    bench_ab5)
+      for v in "SKD_ABN_MASK_FROM_X=1" "SKD_ABN_MASK_FROM_X=0"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab5_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab5.err
+        stamp "bench_ab5 $v rc=$?"; cut -c1-260 "$O/bench_ab5_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err

@@ -56,6 +56,10 @@ def build_cases(lib, torch, dev, st):
             lib.skd_abn_backward_dx_nhwc(rows, C, p(x), p(dz), p(v), p(w), p(b), p(e), p(ey), p(dx), p(dw), p(db), 1e-5, 1, 0.01, 0, st), 12 * n)
         add("relu_backward_reduce_nhwc", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, e=e, ey=ey, ws=ws, rows=rows, C=C:
             lib.skd_abn_relu_backward_reduce_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(e), p(ey), 1e-5, p(ws), st), 12 * n)
+        add("relu_backward_reduce_nhwc_x(mask from x)", sh, lambda x=x, dz=dz, m=rm, v=rv, w=w, b=b, e=e, ey=ey, ws=ws, rows=rows, C=C:
+            lib.skd_abn_relu_backward_reduce_nhwc_x(rows, C, p(x), p(dz), p(m), p(v), p(w), p(b), p(e), p(ey), 1e-5, p(ws), st), 8 * n)
+        add("relu_backward_dx_nhwc_x(mask from x)", sh, lambda x=x, dz=dz, m=rm, v=rv, w=w, b=b, e=e, ey=ey, dx=dx, dw=dw, db=db, rows=rows, C=C:
+            lib.skd_abn_relu_backward_dx_nhwc_x(rows, C, p(x), p(dz), p(m), p(v), p(w), p(b), p(e), p(ey), p(dx), p(dw), p(db), 1e-5, 0, st), 12 * n)
         add("relu_backward_dx_nhwc", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, e=e, ey=ey, dx=dx, dw=dw, db=db, rows=rows, C=C:
             lib.skd_abn_relu_backward_dx_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(e), p(ey), p(dx), None, p(dw), p(db), 1e-5, 0, st), 16 * n)
         add("relu_backward_dx_nhwc(+dres)", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, e=e, ey=ey, dx=dx, dres=dres, dw=dw, db=db, rows=rows, C=C:
