@@ -530,9 +530,10 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
     """NetModel.optimize_parameters() with the D step on its own HIP stream (default) against the strictly serial order of
     kd_model.py:167-173 -- three consecutive steps from the same seed, so that a D step released too early (before the student
     loss has back-propagated through D) or a student step reading a half-updated D would show up in the following steps'
-    losses and in the parameters.  Differences allowed: MIOpen's atomic split-K weight gradients (run-to-run noise)."""
-    outs = {}
-    for flag in ("0", "1"):
+    losses and in the parameters.  MIOpen's atomic split-K weight gradients make two IDENTICAL serial runs differ a little
+    (and SGD carries that forward), so the yard-stick is measured: the serial order is run twice, and the two-stream run
+    must be as close to a serial run as the serial runs are to each other (x4, with a small floor)."""
+    def run(flag):
         monkeypatch.setenv("SKD_D_STREAM", flag)
         torch.manual_seed(99)
         args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
@@ -552,11 +553,19 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
             model.optimize_parameters()
             losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
         torch.cuda.synchronize()
-        outs[flag] = (losses, cpu_sd(model.student), cpu_sd(model.D_model))
+        return losses, cpu_sd(model.student), cpu_sd(model.D_model)
+
+    serial_a, serial_b, stream = run("0"), run("0"), run("1")
+    names = ("G", "mc", "pi", "pa", "D")
     for step in range(3):
-        for a, b in zip(outs["1"][0][step], outs["0"][0][step]):
-            assert abs(a - b) <= 2e-5 * max(abs(b), 1e-2), (step, outs["1"][0][step], outs["0"][0][step])
+        for n, a, b, c in zip(names, serial_a[0][step], serial_b[0][step], stream[0][step]):
+            noise = abs(a - b)
+            tol = max(4 * noise, 2e-5 * max(abs(a), 1e-2))
+            print("step %d %-2s serial %.8g / %.8g  two-stream %.8g  (serial-vs-serial %.2e, stream-vs-serial %.2e)"
+                  % (step, n, a, b, c, noise, min(abs(c - a), abs(c - b))))
+            assert min(abs(c - a), abs(c - b)) <= tol, (step, n, a, b, c)
     for which in (1, 2):
-        for k, v in outs["0"][which].items():
+        for k, v in serial_a[which].items():
             if v.dtype.is_floating_point:
-                assert rel(outs["1"][which][k], v) < 2e-5, (k, rel(outs["1"][which][k], v))
+                noise = rel(serial_b[which][k], v)
+                assert rel(stream[which][k], v) <= max(4 * noise, 2e-5), (k, rel(stream[which][k], v), noise)
