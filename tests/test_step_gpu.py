@@ -530,9 +530,12 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
     """NetModel.optimize_parameters() with the D step on its own HIP stream (default) against the strictly serial order of
     kd_model.py:167-173 -- three consecutive steps from the same seed, so that a D step released too early (before the student
     loss has back-propagated through D) or a student step reading a half-updated D would show up in the following steps'
-    losses and in the parameters.  MIOpen's atomic split-K weight gradients make two IDENTICAL serial runs differ a little
-    (and SGD carries that forward), so the yard-stick is measured: the serial order is run twice, and the two-stream run
-    must be as close to a serial run as the serial runs are to each other (x4, with a small floor)."""
+    losses and in the parameters.  The critic's convolutions run on the deterministic im2col + rocBLAS path here
+    (torch.backends.cudnn.flags(enabled=False) around D only): MIOpen's split-K weight-gradient kernels combine with float
+    atomics whose order changes when another stream shares the chip, which alone moves the critic's cancelling gradients by
+    1e-3 and the next step's D loss by 1e-5 (measured) -- noise that would hide exactly the ordering bugs this test is for.
+    Yard-stick: the serial order is run twice; the two-stream run must be as close to a serial run as the serial runs are to
+    each other (x4, floor 2e-6 relative)."""
     def run(flag):
         monkeypatch.setenv("SKD_D_STREAM", flag)
         torch.manual_seed(99)
@@ -542,6 +545,13 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
         with torch.no_grad():
             model.D_model.attn1.gamma.fill_(0.25)
             model.D_model.attn2.gamma.fill_(-0.5)
+        d_forward = model.D_model.forward
+
+        def deterministic_d(*a, **k):
+            with torch.backends.cudnn.flags(enabled=False):
+                return d_forward(*a, **k)
+
+        model.D_model.forward = deterministic_d
         losses = []
         for step in range(3):
             images, labels = O.synthetic_batch(2, 512, 512, seed=step)
@@ -560,7 +570,7 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
     for step in range(3):
         for n, a, b, c in zip(names, serial_a[0][step], serial_b[0][step], stream[0][step]):
             noise = abs(a - b)
-            tol = max(4 * noise, 2e-5 * max(abs(a), 1e-2))
+            tol = max(4 * noise, 2e-6 * max(abs(a), 1e-2))
             print("step %d %-2s serial %.8g / %.8g  two-stream %.8g  (serial-vs-serial %.2e, stream-vs-serial %.2e)"
                   % (step, n, a, b, c, noise, min(abs(c - a), abs(c - b))))
             assert min(abs(c - a), abs(c - b)) <= tol, (step, n, a, b, c)
@@ -568,4 +578,4 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
         for k, v in serial_a[which].items():
             if v.dtype.is_floating_point:
                 noise = rel(serial_b[which][k], v)
-                assert rel(stream[which][k], v) <= max(4 * noise, 2e-5), (k, rel(stream[which][k], v), noise)
+                assert rel(stream[which][k], v) <= max(4 * noise, 2e-6), (k, rel(stream[which][k], v), noise)
