@@ -47,6 +47,10 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
     model.eval()
     model.to(device)
     confusion = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=device)
+    # a network whose weights NetModel keeps channels-last (kd_model.py of this package) is fed channels-last images, so the
+    # whole-image forward (features 129 x 257 at 1024 x 2048) stays on the NHWC ABN / pyramid / fold kernels
+    w4 = [p for p in model.parameters() if p.dim() == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1]
+    cl_model = device.type == "cuda" and bool(w4) and all(p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() for p in w4)
     with torch.no_grad():
         for batch in loader:
             image, label, size = batch[0], batch[1], batch[2]
@@ -59,6 +63,8 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
             label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).long().to(device)
             sz = np.asarray(size[0] if (torch.is_tensor(size) or isinstance(size, (list, tuple))) else size).reshape(-1)
             hh, ww = int(sz[0]), int(sz[1])
+            if cl_model and image.dim() == 4:
+                image = image.contiguous(memory_format=torch.channels_last)   # keep the network on its channels-last kernels
             logits = model(image)
             if isinstance(logits, (list, tuple)):
                 logits = logits[0]
