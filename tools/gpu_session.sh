@@ -135,6 +135,9 @@ EOF
         (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab5_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab5.err
         stamp "bench_ab5 $v rc=$?"; cut -c1-260 "$O/bench_ab5_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
       done ;;
+    bench_tstream)
+      (SKD_TEACHER_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_tstream.json 2>> $O/bench_tstream.err
+      stamp "bench_tstream rc=$?"; cut -c1-260 $O/bench_tstream.json | tee -a $O/session.log ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
