@@ -470,3 +470,27 @@ def test_frozen_bottleneck_blas_tail_equals_conv_plus_abn(monkeypatch):
     monkeypatch.setenv("SKD_TEACHER_BLAS", "1")
     y = blk(x.clone().requires_grad_(True))
     assert y.requires_grad
+
+
+def test_teacher_dsn_head_is_optional_and_everything_else_unchanged(monkeypatch):
+    """SKD_TEACHER_DSN=0 skips the frozen teacher's deep-supervision head -- read by nothing but the teacher CE the reference
+    computes and discards (kd_model.py:129): preds_T[1] is None, every loss of the step is bit-identical to the default."""
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel
+    vals = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SKD_TEACHER_DSN", flag)
+        torch.manual_seed(3)
+        model = NetModel(_tiny_args(batch_size=2, ho=False))
+        x, y = O.synthetic_batch(2, 96, 96)
+        torch.manual_seed(17)
+        model.set_input((x, y, None, None))
+        model.optimize_parameters()
+        assert (model.preds_T[1] is None) == (flag == "0")
+        vals[flag] = [model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss]
+    assert vals["0"] == vals["1"], vals
+    monkeypatch.setenv("SKD_TEACHER_DSN", "0")
+    monkeypatch.setenv("SKD_TEACHER_CE", "1")                 # asking for the teacher CE keeps the head
+    model = NetModel(_tiny_args(batch_size=2, ho=False))
+    model.set_input((x, y, None, None))
+    model.optimize_parameters()
+    assert model.preds_T[1] is not None and model.mc_T_loss > 0
