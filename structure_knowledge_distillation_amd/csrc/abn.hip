@@ -1380,14 +1380,35 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
 
 constexpr int kStatsU = 8, kGrad0U = 8, kGrad1U = 4;
 
+// Rows in flight per thread and trip (U): the tuned maximum for large tensors; halved while the launch would leave
+// workgroup slots unused -- (8, 128, 65, 65) at U = 8 gives 134 workgroups for 256 CUs, at U = 4 it gives 256.
+static int pick_u(int64_t rows, int C, int umax, RedGeom &g) {
+  int u = umax;
+  if (!make_red_geom(rows, C, u, g)) return 0;
+  while (u > 2 && (int64_t)g.RG * g.CB < kRedMaxWG) {
+    RedGeom h;
+    if (!make_red_geom(rows, C, u / 2, h) || h.RG == g.RG) break;
+    u /= 2;
+    g = h;
+  }
+  return u;
+}
+#define SKD_RED_DISPATCH(U_, KERNEL_EXPR)                   \
+  switch (U_) {                                             \
+    case 8: { constexpr int UU = 8; KERNEL_EXPR; } break;   \
+    case 4: { constexpr int UU = 4; KERNEL_EXPR; } break;   \
+    default: { constexpr int UU = 2; KERNEL_EXPR; } break;  \
+  }
+
 static int launch_stats_nhwc2(int64_t rows, int C, const float *x, float *mean, float *var, float *running_mean,
                               float *running_var, float momentum, float *workspace, hipStream_t st) {
   RedGeom g;
-  if (!make_red_geom(rows, C, kStatsU, g)) return 0;
+  const int u = pick_u(rows, C, kStatsU, g);
+  if (u == 0) return 0;
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
-  abn_stats_nhwc2_kernel<kStatsU><<<dim3((unsigned)(g.RG * g.CB)), dim3(kRedThreads), 0, st>>>(
-      x, workspace, cnt, mean, var, running_mean, running_var, rows, g, momentum, (float)rows);
+  SKD_RED_DISPATCH(u, (abn_stats_nhwc2_kernel<UU><<<dim3((unsigned)(g.RG * g.CB)), dim3(kRedThreads), 0, st>>>(
+      x, workspace, cnt, mean, var, running_mean, running_var, rows, g, momentum, (float)rows)));
   return ok();
 }
 
@@ -1716,19 +1737,20 @@ int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const floa
   if (!aligned16(z) || !aligned16(dz) || activation == SKD_ACT_RELU) return 0;
   hipStream_t st = as_stream(stream);
   RedGeom rg;
-  if (!make_red_geom(rows, C, kGrad0U, rg)) return 0;
+  const int u = pick_u(rows, C, kGrad0U, rg);
+  if (u == 0) return 0;
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
   const dim3 grid((unsigned)(rg.RG * rg.CB)), block(kRedThreads);
   switch (activation) {
     case SKD_ACT_LEAKY_RELU:
-      abn_grad_nhwc2_kernel<SKD_ACT_LEAKY_RELU, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
+      SKD_RED_DISPATCH(u, (abn_grad_nhwc2_kernel<SKD_ACT_LEAKY_RELU, 0, UU><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg)));
       break;
     case SKD_ACT_ELU:
-      abn_grad_nhwc2_kernel<SKD_ACT_ELU, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
+      SKD_RED_DISPATCH(u, (abn_grad_nhwc2_kernel<SKD_ACT_ELU, 0, UU><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg)));
       break;
     default:
-      abn_grad_nhwc2_kernel<SKD_ACT_NONE, 0, kGrad0U><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg);
+      SKD_RED_DISPATCH(u, (abn_grad_nhwc2_kernel<SKD_ACT_NONE, 0, UU><<<grid, block, 0, st>>>(z, dz, nullptr, nullptr, nullptr, weight, bias, workspace, cnt, edz, eydz, eps, slope, rows, rg)));
   }
   return ok();
 }
@@ -1763,11 +1785,16 @@ int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const
   if (!aligned16(x) || !aligned16(out) || !aligned16(dout)) return 0;
   hipStream_t st = as_stream(stream);
   RedGeom rg;
-  if (!make_red_geom(rows, C, kGrad1U, rg)) return 0;
+  const int u = pick_u(rows, C, kGrad1U, rg);
+  if (u == 0) return 0;
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
-  abn_grad_nhwc2_kernel<SKD_ACT_NONE, 1, kGrad1U><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
-      x, out, dout, mean, var, nullptr, nullptr, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
+  if (u == 4)
+    abn_grad_nhwc2_kernel<SKD_ACT_NONE, 1, 4><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
+        x, out, dout, mean, var, nullptr, nullptr, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
+  else
+    abn_grad_nhwc2_kernel<SKD_ACT_NONE, 1, 2><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
+        x, out, dout, mean, var, nullptr, nullptr, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
   return ok();
 }
 
@@ -1779,11 +1806,12 @@ int skd_abn_relu_backward_reduce_nhwc_x(int64_t rows, int C, const float *x, con
   if (!aligned16(x) || !aligned16(dout)) return 0;
   hipStream_t st = as_stream(stream);
   RedGeom rg;
-  if (!make_red_geom(rows, C, kGrad0U, rg)) return 0;
+  const int u = pick_u(rows, C, kGrad0U, rg);
+  if (u == 0) return 0;
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
-  abn_grad_nhwc2_kernel<SKD_ACT_NONE, 2, kGrad0U><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
-      x, dout, nullptr, mean, var, weight, bias, workspace, cnt, edz, eydz, eps, 0.f, rows, rg);
+  SKD_RED_DISPATCH(u, (abn_grad_nhwc2_kernel<SKD_ACT_NONE, 2, UU><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, st>>>(
+      x, dout, nullptr, mean, var, weight, bias, workspace, cnt, edz, eydz, eps, 0.f, rows, rg)));
   return ok();
 }
 
