@@ -579,7 +579,9 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
                   % (step, n, a, b, c, noise, min(abs(c - a), abs(c - b))))
             assert min(abs(c - a), abs(c - b)) <= tol, (step, n, a, b, c)
     worst = {}
-    for which, what, floor in ((0, "student", 1e-4), (1, "D", 2e-6)):     # student: MIOpen split-K noise x lr (1.3e-5 seen)
+    # student floor = GRAD_FLOOR: a zero-initialised bias IS -lr x gradient after one step, and MIOpen's split-K noise on
+    # the student's gradients is what GRAD_FLOOR measures (bn1.bias differed by 4.3e-4 between two modes of the SAME order)
+    for which, what, floor in ((0, "student", GRAD_FLOOR), (1, "D", 2e-6)):
         for k, v in serial_a[1][which].items():
             if v.dtype.is_floating_point:
                 noise = rel(serial_b[1][which][k], v)
