@@ -215,8 +215,9 @@ def test_networks_forward_vs_oracle():
 
 @pytest.mark.parametrize("ho", [False, True])
 def test_full_step_vs_oracle(ho):
-    """BASELINE configs 2 / 3 at B=2 (512x512, Pi+Pa[+Ho]); two consecutive steps (momentum, u/v and
-    running statistics carried over)."""
+    """BASELINE configs 2 / 3 at B=2 (512x512, Pi+Pa[+Ho]); with Ho two consecutive steps (momentum, u/v and running
+    statistics carried over), without it one (the CPU oracle dominates this test's two minutes; the single Pi / Pi+Pa step is
+    also pinned by the config-1 golden tests below)."""
     torch.manual_seed(1234)
     B = 2
     args = default_args(batch_size=B, device=DEV, ho=ho, weight_decay=5e-4, lambda_pa=0.5)
@@ -229,7 +230,7 @@ def test_full_step_vs_oracle(ho):
     PS64, PT64, PD64 = (cpu_sd(m, torch.float64) for m in (model.student, model.teacher, model.D_model))
     cfg = O.StepConfig(ho=ho, weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
     st32, st64 = {"G": {}, "D": {}}, {"G": {}, "D": {}}
-    for step in range(2):
+    for step in range(2 if ho else 1):
         images, labels = O.synthetic_batch(B, 512, 512, seed=step)
         alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step))
         lr_g = model.adjust_learning_rate(args.lr_g, model.G_solver, step)
