@@ -396,6 +396,7 @@ __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_kernel(float *x, cons
                                                                  const float *__restrict__ bias, float eps,
                                                                  float slope, int64_t quads, int C4) {
   constexpr int U = 8;
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * U);
   float m[NSETS][4], is[NSETS][4], g[NSETS][4], b[NSETS][4];
 #pragma unroll
   for (int s = 0; s < NSETS; ++s) {
@@ -408,31 +409,27 @@ __global__ __launch_bounds__(kThreads) void abn_apply_nhwc_kernel(float *x, cons
       b[s][k] = beta_of(bias, c + k);
     }
   }
-  // a slab is 256 * 8 quads, a multiple of C4: the thread's channel quads are the same in every slab, so large tensors
-  // give a workgroup several slabs (grid capped by the launcher) and the 16 .. 64 parameter loads + rsqrt are paid once
-  for (int64_t base = (int64_t)blockIdx.x * (kThreads * U); base < quads; base += (int64_t)gridDim.x * (kThreads * U)) {
-    float4 v[U], r[U];
+  float4 v[U], r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t q = base + u * kThreads + threadIdx.x;
-      if (q < quads) {
-        v[u] = *reinterpret_cast<const float4 *>(x + 4 * q);
-        if (HAS_RES) r[u] = *reinterpret_cast<const float4 *>(res + 4 * q);
-      }
+  for (int u = 0; u < U; ++u) {
+    const int64_t q = base + u * kThreads + threadIdx.x;
+    if (q < quads) {
+      v[u] = *reinterpret_cast<const float4 *>(x + 4 * q);
+      if (HAS_RES) r[u] = *reinterpret_cast<const float4 *>(res + 4 * q);
     }
+  }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t q = base + u * kThreads + threadIdx.x;
-      if (q < quads) {
-        constexpr int dummy = 0;
-        const int s = NSETS == 1 ? dummy : (u % NSETS);
-        float4 z;
-        z.x = act_fwd<ACT>(((v[u].x - m[s][0]) * is[s][0]) * g[s][0] + b[s][0] + (HAS_RES ? r[u].x : 0.f), slope);
-        z.y = act_fwd<ACT>(((v[u].y - m[s][1]) * is[s][1]) * g[s][1] + b[s][1] + (HAS_RES ? r[u].y : 0.f), slope);
-        z.z = act_fwd<ACT>(((v[u].z - m[s][2]) * is[s][2]) * g[s][2] + b[s][2] + (HAS_RES ? r[u].z : 0.f), slope);
-        z.w = act_fwd<ACT>(((v[u].w - m[s][3]) * is[s][3]) * g[s][3] + b[s][3] + (HAS_RES ? r[u].w : 0.f), slope);
-        *reinterpret_cast<float4 *>(x + 4 * q) = z;
-      }
+  for (int u = 0; u < U; ++u) {
+    const int64_t q = base + u * kThreads + threadIdx.x;
+    if (q < quads) {
+      constexpr int dummy = 0;
+      const int s = NSETS == 1 ? dummy : (u % NSETS);
+      float4 z;
+      z.x = act_fwd<ACT>(((v[u].x - m[s][0]) * is[s][0]) * g[s][0] + b[s][0] + (HAS_RES ? r[u].x : 0.f), slope);
+      z.y = act_fwd<ACT>(((v[u].y - m[s][1]) * is[s][1]) * g[s][1] + b[s][1] + (HAS_RES ? r[u].y : 0.f), slope);
+      z.z = act_fwd<ACT>(((v[u].z - m[s][2]) * is[s][2]) * g[s][2] + b[s][2] + (HAS_RES ? r[u].z : 0.f), slope);
+      z.w = act_fwd<ACT>(((v[u].w - m[s][3]) * is[s][3]) * g[s][3] + b[s][3] + (HAS_RES ? r[u].w : 0.f), slope);
+      *reinterpret_cast<float4 *>(x + 4 * q) = z;
     }
   }
 }
@@ -846,17 +843,6 @@ static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x
   }
 }
 
-// grid cap of the channels-last apply pass (SKD_APPLY_GRID_CAP, default 2048 = 8 workgroups per CU)
-static int64_t apply_nhwc_grid_cap() {
-  static int64_t cap = -1;
-  if (cap < 0) {
-    const char *e = getenv("SKD_APPLY_GRID_CAP");
-    cap = e != nullptr ? atoll(e) : 2048;
-    if (cap < 256) cap = 256;
-  }
-  return cap;
-}
-
 template <int ACT, bool HAS_RES>
 static void launch_apply_nhwc_act(int64_t quads, int C4, float *x, const float *res, const float *mean,
                                   const float *var, const float *weight, const float *bias, float eps, float slope,
@@ -864,10 +850,7 @@ static void launch_apply_nhwc_act(int64_t quads, int C4, float *x, const float *
   const dim3 block(kThreads);
   const bool pow2 = (C4 & (C4 - 1)) == 0;
   if (pow2 && C4 <= 4 * kThreads) {
-    int64_t slabs = cdiv(quads, (int64_t)kThreads * 8);
-    const int64_t cap = apply_nhwc_grid_cap();   // above ~8 workgroups per CU the launch gains nothing: loop instead
-    if (slabs > cap) slabs = cdiv(slabs, cdiv(slabs, cap));   // equal trip counts: ceil(slabs / trips) workgroups
-    const dim3 grid((unsigned)slabs);
+    const dim3 grid((unsigned)cdiv(quads, (int64_t)kThreads * 8));
     if (C4 <= kThreads)
       abn_apply_nhwc_kernel<ACT, HAS_RES, 1><<<grid, block, 0, st>>>(x, res, mean, var, weight, bias, eps, slope, quads, C4);
     else if (C4 == 2 * kThreads)
