@@ -24,6 +24,9 @@ What each function follows (all paths relative to the reference root):
   criterion_adv         utils/criterion.py:146-166
   criterion_gp          utils/criterion.py:98-120
   distillation_step     networks/kd_model.py:119-173 (+ SGD of kd_model.py:74-75)
+  distillation_step_sharded   the same step under the reference's multi-GPU semantics: utils/parallel.py:106,142,155
+                        (scatter, per-replica criteria, mean of the replica losses), libs/functions.py:185-209
+                        (whole-batch student BN statistics), sagan_models.py:148 (D's BatchNorm stays local)
 Pinned against the reference's own Python by tests/test_oracle_vs_reference.py (runs where
 /root/reference exists) and by the fixtures in tests/golden/ (made by tests/golden/make_golden.py).
 """
@@ -424,6 +427,115 @@ def distillation_step(PS, PT, PD, images, labels, cfg, state=None, alpha=None, d
     if PD is not None:
         require_grad(PD, False)
     return out
+
+
+def distillation_step_sharded(PS, PT, PD, images, labels, cfg, shards, alphas=None, lr_g=None, lr_d=None,
+                              apply_updates=True):
+    """BASELINE configs[3]: the step of ``distillation_step`` as the reference's multi-GPU mode defines it.
+
+    ``nn.DataParallel`` scatters the minibatch (utils/parallel.py:106,142); every replica computes ITS shard's
+    criteria and ``Reduce.apply(*outputs) / len(outputs)`` averages them (parallel.py:155), so the quantity that
+    is differentiated is the MEAN over shards of the per-shard losses.  What crosses shards:
+      * the student's InPlaceABNSync statistics (libs/functions.py:185-209): whole-batch mean / variance, which
+        for equal shards is exactly batch norm over the concatenated batch -- so the student runs ONCE here on
+        the whole batch and its outputs are sliced;
+      * the gradient sum (ReduceAddCoalesced of the replicas), i.e. autograd of the mean loss.
+    What does NOT: the discriminator's ``nn.BatchNorm2d`` (sagan_models.py:148) sees only its replica's shard,
+    Pi is a per-shard sum (criterion.py:225), Pa divides by the shard's batch (utils.py:181), CE averages over
+    the shard's valid pixels.  Spectral-norm u, v advance once per D forward of a replica (spectral.py:30-31):
+    they depend on the weights only, so every replica holds the same values -- each shard gets its own copy of
+    ``PD`` here and the copies' u, v must come out identical (checked by the caller).
+
+    ``shards``: list of slices of the batch dimension; ``alphas``: per-shard (b,1,1,1) WGAN-GP coefficients.
+    Returns per-shard scalars, the averaged student / D gradients, and (apply_updates) updates PS / PD in place
+    with them; ``PD_shards`` are the per-replica D states after the step (BN running statistics differ)."""
+    lr_g = cfg.lr_g if lr_g is None else lr_g
+    lr_d = cfg.lr_d if lr_d is None else lr_d
+    G = len(shards)
+    require_grad(PS, True)
+    with torch.no_grad():
+        preds_T = pspnet_forward(PT, images, TEACHER, False)
+    preds_S = pspnet_forward(PS, images, STUDENT, True, cfg.dropout_p)
+    PDs = []
+    if cfg.ho:
+        for _ in range(G):
+            P = {k: v.detach().clone() for k, v in PD.items()}
+            PDs.append(require_grad(P, True))
+    total = 0.0
+    out = {"shards": []}
+    for r, sl in enumerate(shards):
+        s, t = [p[sl] for p in preds_S], [p[sl] for p in preds_T]
+        rec = {}
+        mc = criterion_dsn(s, labels[sl])
+        g_loss = mc
+        rec["mc_G_loss"] = float(mc.detach())
+        rec["pi_G_loss"] = rec["pa_G_loss"] = 0.0
+        if cfg.pi:
+            pi = cfg.lambda_pi * criterion_pixel_wise(s, t)
+            rec["pi_G_loss"] = float(pi.detach())
+            g_loss = g_loss + pi
+        if cfg.pa:
+            pa = criterion_pair_wise(s, t, cfg.pool_scale, -5)
+            rec["pa_G_loss"] = float(pa.detach())
+            g_loss = g_loss + cfg.lambda_pa * pa
+        if cfg.ho:
+            g_loss = g_loss + cfg.lambda_d * criterion_adv_for_g(discriminator_forward(PDs[r], s[0]), cfg.adv_loss_type)
+        rec["G_loss"] = float(g_loss.detach())
+        out["shards"].append(rec)
+        total = total + g_loss / G
+    s_keys = learnable_keys(PS)
+    out["grads_S"] = dict(zip(s_keys, torch.autograd.grad(total, [PS[k] for k in s_keys], allow_unused=True)))
+    out["preds_S"] = [t.detach() for t in preds_S]
+    out["preds_T"] = preds_T
+    state = {"G": {}, "D": {}}
+    if apply_updates:
+        sgd_step(PS, out["grads_S"], state["G"], lr_g, cfg.momentum, cfg.weight_decay)
+    if cfg.ho:
+        d_keys = learnable_keys(PD)
+        acc = {k: None for k in d_keys}
+        for r, sl in enumerate(shards):
+            P = PDs[r]
+            pS, pT = preds_S[0][sl].detach(), preds_T[0][sl].detach()
+            d_t = discriminator_forward(P, pT)
+            d_s = discriminator_forward(P, pS)
+            d_loss = cfg.lambda_d * criterion_adv(d_s, d_t, cfg.adv_loss_type)
+            if cfg.adv_loss_type == "wgan-gp":
+                d_loss = d_loss + cfg.lambda_d * criterion_gp(P, [pS], [pT], cfg.lambda_gp, alphas[r])
+            out["shards"][r]["D_loss"] = float(d_loss.detach())
+            for k, g in zip(d_keys, torch.autograd.grad(d_loss, [P[k] for k in d_keys], allow_unused=True)):
+                if g is not None:
+                    acc[k] = g / G if acc[k] is None else acc[k] + g / G
+            require_grad(P, False)
+        out["grads_D"] = acc
+        out["PD_shards"] = PDs
+        if apply_updates:
+            require_grad(PD, True)
+            sgd_step(PD, acc, state["D"], lr_d, cfg.momentum, cfg.weight_decay)
+            require_grad(PD, False)
+            with torch.no_grad():
+                for k in PD:
+                    if k.endswith(("weight_u", "weight_v")):
+                        PD[k].copy_(PDs[0][k])
+    require_grad(PS, False)
+    return out
+
+
+def discriminator_step(P, logits_S, logits_T, cfg, alpha, g_step_forward=True):
+    """The discriminator's part of one step on GIVEN logits (kd_model.py:148, 153-165): the G step's critic forward
+    (advances u, v only), D(T), D(S), adversarial loss + WGAN-GP.  Mutates u, v / BN statistics in ``P``.
+    Returns (d_loss as float, {key: gradient})."""
+    require_grad(P, True)
+    pS, pT = logits_S.detach(), logits_T.detach()
+    if g_step_forward:
+        discriminator_forward(P, pS)
+    d_t, d_s = discriminator_forward(P, pT), discriminator_forward(P, pS)
+    d_loss = cfg.lambda_d * criterion_adv(d_s, d_t, cfg.adv_loss_type)
+    if cfg.adv_loss_type == "wgan-gp":
+        d_loss = d_loss + cfg.lambda_d * criterion_gp(P, [pS], [pT], cfg.lambda_gp, alpha)
+    keys = learnable_keys(P)
+    grads = dict(zip(keys, torch.autograd.grad(d_loss, [P[k] for k in keys], allow_unused=True)))
+    require_grad(P, False)
+    return float(d_loss.detach()), grads
 
 
 def synthetic_batch(B, H, W, num_classes=19, seed=0, dtype=torch.float32):

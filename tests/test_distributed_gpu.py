@@ -92,28 +92,152 @@ def test_sync_abn_two_ranks_hip_kernels():
         assert rel(outs[0][kind]["db"] + outs[1][kind]["db"], bo.grad) < 1e-4, kind
 
 
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[3] (DP + SyncABN + Ho) on two ranks sharing the MI355X: the whole optimize_parameters()
+# with the discriminator step, against the sharded oracle (oracle.step_torch.distillation_step_sharded =
+# utils/parallel.py:155 + libs/functions.py:185-209 + sagan_models.py:148 semantics).
+GRAD_BOUND, GRAD_FLOOR = 3.0, 5e-3        # the ONE gradient bound of tests/test_step_gpu.py (reason stated there)
+_B = 2
+
+
+def _snap(mod):
+    return {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()}
+
+
 def _netmodel_step(rank, world):
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     from oracle import step_torch as O
     dev = torch.device("cuda", 0)
-    torch.manual_seed(10 + rank)
-    model = NetModel(default_args(batch_size=2, ho=False, device=dev, weight_decay=5e-4, lambda_pa=0.5))
+    torch.manual_seed(10 + rank)           # different init per rank: construction must broadcast rank 0's weights
+    model = NetModel(default_args(batch_size=_B * world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
+    assert (model._d_stream is not None) == (os.environ.get("SKD_D_STREAM", "1") == "1")
     for m in model.student.modules():
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0.0
-    x, y = O.synthetic_batch(4, 128, 128, seed=3)
-    sl = slice(rank * 2, rank * 2 + 2)
+    with torch.no_grad():
+        model.D_model.attn1.gamma.fill_(0.25)
+        model.D_model.attn2.gamma.fill_(-0.5)
+    init, teacher, d_init = _snap(model.student), _snap(model.teacher), _snap(model.D_model)
+    x, y = O.synthetic_batch(_B * world, 512, 512, seed=3)
+    alpha = torch.rand(_B * world, 1, 1, 1, generator=torch.Generator().manual_seed(17))
+    sl = slice(rank * _B, (rank + 1) * _B)
+    model.gp_alpha = alpha[sl].to(dev)
     model.set_input((x[sl], y[sl], None, None))
-    model.optimize_parameters()
-    return {"after": {k: v.detach().cpu() for k, v in model.student.state_dict().items()},
-            "losses": (model.mc_G_loss, model.pi_G_loss, model.pa_G_loss)}
+    model.optimize_parameters()            # two-stream or serial per SKD_D_STREAM; D's all-reduces start inside its stream
+    torch.cuda.synchronize()
+    assert all(p.requires_grad for p in model._d_params)
+    return {"init": init, "teacher": teacher, "d_init": d_init,
+            "grads": {k: p.grad.detach().cpu() for k, p in model.student.named_parameters()},
+            "d_grads": {k: p.grad.detach().cpu() for k, p in model.D_model.named_parameters() if p.grad is not None},
+            "losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")},
+            "logits": (model.preds_S[0].detach().cpu(), model.preds_T[0].detach().cpu()),
+            "after": _snap(model.student), "d_after": _snap(model.D_model)}
 
 
-def test_netmodel_step_replicas_stay_identical():
+_ORACLE = {}
+
+
+def _sharded_oracle(outs):
+    """fp64 and fp32 CPU oracles of the sharded step, computed once per session from the replicas' common start."""
+    if "o64" in _ORACLE:
+        return _ORACLE
+    from oracle import step_torch as O
+    x, y = O.synthetic_batch(_B * 2, 512, 512, seed=3)
+    alpha = torch.rand(_B * 2, 1, 1, 1, generator=torch.Generator().manual_seed(17))
+    shards = [slice(r * _B, (r + 1) * _B) for r in range(2)]
+    cfg = O.StepConfig(weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
+    for name, dt in (("o64", torch.float64), ("o32", torch.float32)):
+        cast = lambda P: {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+        PS, PT, PD = cast(outs[0]["init"]), cast(outs[0]["teacher"]), cast(outs[0]["d_init"])
+        _ORACLE[name] = O.distillation_step_sharded(PS, PT, PD, x.to(dt), y, cfg, shards, [alpha[sl].to(dt) for sl in shards])
+        _ORACLE[name + "_after"] = (PS, PD)
+    _ORACLE.update(cfg=cfg, alpha=alpha, shards=shards, init=outs[0]["init"], d_init=outs[0]["d_init"])
+    return _ORACLE
+
+
+def _bound_report(what, rows, bound, floor):
+    scored = sorted(((err / (bound * base + floor * norm + 1e-7), k, err, base, norm) for k, err, base, norm in rows), reverse=True)
+    print("%s: %d tensors, bound err <= %.1f x base + %.0e x |g|; worst three (fraction of the bound, key, err/|g|, base/|g|):"
+          % (what, len(scored), bound, floor))
+    for frac, k, err, base, norm in scored[:3]:
+        print("    %.3f  %-40s %.2e  %.2e" % (frac, k, err / (norm + 1e-30), base / (norm + 1e-30)))
+    bad = [(k, frac) for frac, k, _, _, _ in scored if frac > 1.0]
+    assert not bad, (what, bad[:10])
+
+
+@pytest.mark.parametrize("d_stream", ["0", "1"])
+def test_netmodel_ho_step_two_ranks_vs_sharded_oracle(d_stream, monkeypatch):
+    """Pi + Pa + Ho, two ranks, real HIP kernels: SyncABN in every student BN, the student's AND the discriminator's
+    bucketed gradient all-reduce (the latter issued from hooks that fire inside the D stream when SKD_D_STREAM=1),
+    D's requires_grad toggle around the G step's critic forward, local D BatchNorm, spectral-norm u / v."""
+    from oracle import step_torch as O
+    monkeypatch.setenv("SKD_D_STREAM", d_stream)
     outs = _run("_netmodel_step")
+    for name in ("init", "d_init"):
+        for k in outs[0][name]:
+            assert torch.equal(outs[0][name][k], outs[1][name][k]), "replicas must start identical: %s" % k
+    orc = _sharded_oracle(outs)
+    for k in orc["init"]:
+        assert torch.equal(orc["init"][k], outs[0]["init"][k]), "same seeds, same start in both parametrisations"
+    o64, o32, cfg = orc["o64"], orc["o32"], orc["cfg"]
+    for r in range(2):
+        for k, ref in o64["shards"][r].items():
+            got = outs[r]["losses"][k]
+            print("D_STREAM=%s rank %d %-10s hip %.8g  sharded oracle %.8g  rel %.2e" % (d_stream, r, k, got, ref, abs(got - ref) / abs(ref)))
+            assert abs(got - ref) <= 1e-4 * abs(ref), (r, k, got, ref)
+    assert outs[0]["losses"] != outs[1]["losses"]
+    # averaged gradients: bit-identical on both ranks, student within the ONE bound of the fp64 sharded oracle
+    rows = []
+    for k, g in o64["grads_S"].items():
+        g0, g1 = outs[0]["grads"][k], outs[1]["grads"][k]
+        assert torch.equal(g0, g1), "averaged student gradients must be identical on every rank: %s" % k
+        rows.append((k, float((g0.double() - g).norm()), float((o32["grads_S"][k].double() - g).norm()), float(g.norm())))
+    _bound_report("D_STREAM=%s student gradients (2 ranks, averaged)" % d_stream, rows, GRAD_BOUND, GRAD_FLOOR)
+    rows = []
+    for k, g in o64["grads_D"].items():
+        if g is None:
+            continue
+        g0, g1 = outs[0]["d_grads"][k], outs[1]["d_grads"][k]
+        assert torch.equal(g0, g1), "averaged discriminator gradients must be identical on every rank: %s" % k
+        if float(g.norm()) > 1e-12:
+            rows.append((k, float((g0.double() - g).norm()), float((o32["grads_D"][k].double() - g).norm()), float(g.norm())))
+    # end to end the critic amplifies the student's / teacher's logit differences (tests/test_step_gpu.py): informative bound
+    _bound_report("D_STREAM=%s discriminator gradients end to end" % d_stream, rows, 10.0, 2e-2)
+    # ... and the D step itself on the very logits each rank produced, per shard, averaged: the ONE bound
+    ref = {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        acc = {}
+        for r, sl in enumerate(orc["shards"]):
+            P = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in orc["d_init"].items()}
+            pS, pT = outs[r]["logits"]
+            loss, grads = O.discriminator_step(P, pS.to(dt), pT.to(dt), cfg, orc["alpha"][sl].to(dt))
+            if name == "f64":
+                assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-5 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
+            for k, g in grads.items():
+                if g is not None:
+                    acc[k] = acc.get(k, 0.0) + g / 2
+        ref[name] = acc
+    _bound_report("D_STREAM=%s discriminator step on the ranks' own logits (averaged over the 2 shards)" % d_stream,
+                  [(k, float((outs[0]["d_grads"][k].double() - g).norm()), float((ref["f32"][k].double() - g).norm()), float(g.norm()))
+                   for k, g in ref["f64"].items() if float(g.norm()) > 1e-12], GRAD_BOUND, GRAD_FLOOR)
+    # replicas after the step
+    PS64, PD64 = orc["o64_after"]
     for k in outs[0]["after"]:
-        assert torch.equal(outs[0]["after"][k], outs[1]["after"][k]), "replicas diverged: %s" % k
-    assert outs[0]["losses"] != outs[1]["losses"]      # different shards, different local losses
+        assert torch.equal(outs[0]["after"][k], outs[1]["after"][k]), "student replicas diverged: %s" % k
+        if "running" in k:
+            assert rel(outs[0]["after"][k], PS64[k]) < 1e-4, k
+    local_bn = 0
+    for k in outs[0]["d_after"]:
+        a, b = outs[0]["d_after"][k], outs[1]["d_after"][k]
+        if k.startswith("preprocess_additional.running"):
+            local_bn += int(not torch.equal(a, b))            # sagan_models.py:148: plain BatchNorm2d, not synchronised
+            for r in range(2):
+                assert rel(outs[r]["d_after"][k], o64["PD_shards"][r][k]) < 1e-4, (r, k)
+            continue
+        assert torch.equal(a, b), "discriminator replicas diverged: %s" % k     # incl. weight_u / weight_v, bit for bit
+        if k.endswith(("weight_u", "weight_v")):
+            assert rel(a, PD64[k]) < 1e-4, k
+    assert local_bn == 2, "the discriminator's BatchNorm statistics must stay local to the replica"
 
 
 def test_bench_under_torchrun_two_ranks_over_gloo():
