@@ -94,3 +94,65 @@ class cpu_cuda_identity:
         import torch
         torch.Tensor.cuda = self._orig
         return False
+
+
+def load_reference_evaluate(abn_module_factory):
+    """The reference's networks/evaluate.py (confusion matrix, whole-image prediction, mIoU), imported from where it lies
+    with stubs for what this image lacks: ``cv2`` (only the out-of-scope dataset readers call it), ``torchvision`` /
+    ``torchvision.models`` (imported, unused), ``libs`` (as in load_reference).  scipy.ndimage and PIL are installed.
+    Returns the module; the caller wraps calls in ``evaluate_shims()`` (numpy 2 dropped ``np.int``, evaluate.py:194;
+    ``.cuda()`` on a CPU-only box, evaluate.py:108,166)."""
+    if "evaluate" in _loaded:
+        return _loaded["evaluate"]
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    sys.dont_write_bytecode = True
+    names = ("cv2", "torchvision", "torchvision.models", "torchvision.transforms", "tensorboardX", "libs", "networks", "dataset",
+             "utils", "networks.evaluate", "networks.pspnet_combine", "dataset.datasets")
+    saved = {k: sys.modules.get(k) for k in names}
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    libs = types.ModuleType("libs")
+    libs.InPlaceABN = abn_module_factory.InPlaceABN
+    libs.InPlaceABNSync = abn_module_factory.InPlaceABNSync
+    for k in names:
+        sys.modules.pop(k, None)
+    sys.modules.update({"cv2": types.ModuleType("cv2"), "torchvision": tv, "torchvision.models": tv.models,
+                        "torchvision.transforms": tv.transforms, "libs": libs})
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import importlib
+        mod = importlib.import_module("networks.evaluate")
+    finally:
+        sys.path.remove(REF_ROOT)
+        for k in names:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+    _loaded["evaluate"] = mod
+    return mod
+
+
+class evaluate_shims(cpu_cuda_identity):
+    """cpu_cuda_identity + nn.Module.cuda identity + ``np.int`` for the duration of a call into the reference's evaluate.py."""
+
+    def __enter__(self):
+        import numpy as np
+        import torch
+        super().__enter__()
+        self._mod_cuda = torch.nn.Module.cuda
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        self._had_int = hasattr(np, "int")
+        if not self._had_int:
+            np.int = int
+        return self
+
+    def __exit__(self, *exc):
+        import numpy as np
+        import torch
+        torch.nn.Module.cuda = self._mod_cuda
+        if not self._had_int:
+            del np.int
+        return super().__exit__(*exc)

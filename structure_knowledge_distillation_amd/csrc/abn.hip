@@ -8,8 +8,8 @@
 //   * work is cut into contiguous runs of <= kChunk floats of ONE (n, c) row, so a launch has
 //     N*C*pieces workgroups (4096 for an (8,512,65,65) tensor) that each stream 16-32 KiB with
 //     16-byte loads -- the kernels are HBM-bound and sized to cover all 256 CUs several times;
-//   * statistics are ONE pass: sums of (x-K) and (x-K)^2 around a per-channel pivot K = x[0,c,0]
-//     (shifted-data variance; no catastrophic cancellation, no second read of x);
+//   * statistics are ONE pass: sums of (x-K) and (x-K)^2 around a per-channel pivot K = median of three samples of
+//     the channel (shifted-data variance; no catastrophic cancellation, no second read of x);
 //   * per-workgroup partials are combined by a tiny finalize kernel in double precision in a
 //     fixed order (deterministic, no atomics), which also performs the running-stat update;
 //   * normalise + affine(|w|+eps) + activation is one in-place pass; backward undoes the
@@ -129,6 +129,21 @@ __device__ __forceinline__ float inv_std_of(float var, float eps) {
 // NaN / inf; here n == 1 keeps the (zero) biased variance instead -- the one deliberate deviation, see DESIGN.md.
 __device__ __forceinline__ float unbiased_of(float var, float n) { return n > 1.f ? var * n / (n - 1.f) : var; }
 
+// Pivot of the one-pass (shifted) statistics: the MEDIAN of three samples of the channel -- first, middle and last element
+// of the tensor's channel.  The shifted variance loses ~k^2 * 2^-24 of relative accuracy when the pivot sits k sigma from
+// the mean (bn.cu:125-138 is two-pass and has no such term); a single sample as pivot makes that k the tail of the data
+// (one outlier element 100 sigma off: 6e-4), the median of three needs TWO outliers among the three probes.  NaN-free
+// ordering: fminf / fmaxf return the non-NaN operand, and a NaN anywhere in the channel poisons the sums regardless.
+__device__ __forceinline__ float median3(float a, float b, float c) {
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+__device__ __forceinline__ float pivot_nchw(const float *x, int c, int N, int C, int S) {
+  const float a = x[(int64_t)c * S];
+  const float b = x[((int64_t)(N / 2) * C + c) * S + S / 2];
+  const float d = x[((int64_t)(N - 1) * C + c) * S + (S - 1)];
+  return median3(a, b, d);
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, float slope) {
   if (ACT == SKD_ACT_LEAKY_RELU) return z < 0.f ? z * slope : z;        // bn.cu:302-315
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void abn_stats_partial_kernel(const float
   __shared__ float red[2 * kWavesPerWG];
   const Item it = decode(blockIdx.x, N, C, S, pl);
   StatsOp op;
-  op.K = x[(int64_t)it.c * S];  // pivot: first element of channel c in sample 0 (uniform load)
+  op.K = pivot_nchw(x, it.c, N, C, S);  // per-channel pivot (three uniform loads)
   op.s1 = 0.f;
   op.s2 = 0.f;
   for (int n = it.n0; n < it.n1; ++n) {
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void abn_stats_finalize_kernel(
   s2 = wave_sum(s2);
   if (lane == 0) {
     const double cnt = (double)N * (double)S;
-    const double K = (double)x[(int64_t)c * S];
+    const double K = (double)pivot_nchw(x, c, N, C, S);
     const double d = s1 / cnt;
     double v = s2 / cnt - d * d;
     if (v < 0.0) v = 0.0;
@@ -1246,7 +1261,7 @@ __device__ __forceinline__ bool red_finish(float (&s1)[4], float (&s2)[4], float
   return true;
 }
 
-// K1 (NHWC): shifted sums of (x - K), (x - K)^2 with K = x[0][c]; mean / biased var (+ running update) by the last arriver
+// K1 (NHWC): shifted sums of (x - K), (x - K)^2 with K = median3 of the channel; mean / biased var (+ running update) by the last arriver
 template <int U>
 __global__ __launch_bounds__(kRedThreads) void abn_stats_nhwc2_kernel(
     const float *__restrict__ x, float *__restrict__ part, unsigned *counters, float *__restrict__ mean,
@@ -1259,7 +1274,13 @@ __global__ __launch_bounds__(kRedThreads) void abn_stats_nhwc2_kernel(
   const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
   const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
   const int col = (cb * g.CW4 + cq) * 4;
-  const float4 K = *reinterpret_cast<const float4 *>(x + col);
+  float4 K;   // per-channel pivot: median of the channel's first / middle / last row (median3 above)
+  {
+    const float4 ka = *reinterpret_cast<const float4 *>(x + col);
+    const float4 kb = *reinterpret_cast<const float4 *>(x + ((rows / 2) << (g.log2C4 + 2)) + col);
+    const float4 kc = *reinterpret_cast<const float4 *>(x + ((rows - 1) << (g.log2C4 + 2)) + col);
+    K = make_float4(median3(ka.x, kb.x, kc.x), median3(ka.y, kb.y, kc.y), median3(ka.z, kb.z, kc.z), median3(ka.w, kb.w, kc.w));
+  }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t slab = (int64_t)g.rpp * U;
   for (int64_t base = (int64_t)rg * slab + rsub; base < rows; base += (int64_t)g.RG * slab) {
@@ -1287,7 +1308,9 @@ __global__ __launch_bounds__(kRedThreads) void abn_stats_nhwc2_kernel(
     const double d = fin[(t >> 2) * 8 + (t & 3)] / cnt;
     double v = fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt - d * d;
     if (v < 0.0) v = 0.0;
-    const float m_f = (float)((double)x[c] + d), v_f = (float)v;
+    const int64_t ldr = (int64_t)g.C4 * 4;
+    const double Kc = (double)median3(x[c], x[(rows / 2) * ldr + c], x[(rows - 1) * ldr + c]);   // the same pivot as above
+    const float m_f = (float)(Kc + d), v_f = (float)v;
     mean[c] = m_f;
     var[c] = v_f;
     if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;

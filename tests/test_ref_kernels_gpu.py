@@ -120,6 +120,36 @@ def test_bn_entries_three_way(libs, shape):
     close(dw2_h, dw2_n, 1e-6, "dweight only", floor=1.0)
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 4225), (8, 128, 4225), (2, 16, 16641), (3, 8, 36)])
+def test_mean_var_with_an_outlier_where_the_old_pivot_sat(libs, shape):
+    """K1 robustness: the product's statistics are ONE pass around a per-channel pivot; the reference
+    is two-pass (bn.cu:125-138).  One element 300 sigma off the channel mean at (n, h, w) = (0, 0, 0) -- the element the
+    single-sample pivot of rounds 1-2 used -- cost 6e-4 of relative accuracy on the variance; the median-of-three pivot
+    (csrc/abn.hip: median3) keeps it at the fp32 level, for the NCHW entry and the channels-last entry alike."""
+    nat, ref, hip = libs
+    N, C, S = shape
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, S, generator=g) * 3.0 + torch.randn(1, C, 1, generator=g) * 5.0
+    x[0, :, 0] += 900.0                                             # 300 sigma
+    want_m, want_v = x.double().mean((0, 2)), x.double().var((0, 2), unbiased=False)
+    xg = x.to(DEV)
+    m_n, v_n, m_h, v_h = (torch.empty(C, device=DEV) for _ in range(4))
+    assert nat._bn_mean_var_cuda(N, C, S, P(xg), P(m_n), P(v_n), None)
+    assert hip.skd_bn_mean_var(N, C, S, P(xg), P(m_h), P(v_h), None)
+    rel = lambda a, b: float(((a.cpu().double() - b) / b).abs().max())
+    print("outlier pivot %s: var rel err  reference kernel %.2e  product NCHW %.2e" % (shape, rel(v_n, want_v), rel(v_h, want_v)), end="")
+    assert rel(v_n, want_v) < 2e-5, "reference kernel vs fp64"
+    assert rel(v_h, want_v) < 2e-5 and float((m_h.cpu().double() - want_m).abs().max()) < 2e-5 * 10
+    if C % 4 == 0 and not (C & (C - 1)):
+        xl = x.permute(0, 2, 1).contiguous().to(DEV)                 # (rows = N*S, C): same element is row 0
+        m_l, v_l = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ws = torch.empty(max(1, hip.skd_abn_nhwc_workspace_floats(N * S, C)), device=DEV)
+        assert hip.skd_abn_stats_nhwc(N * S, C, P(xl), P(m_l), P(v_l), P(ws), None)
+        print("  product NHWC %.2e" % rel(v_l, want_v), end="")
+        assert rel(v_l, want_v) < 2e-5 and float((m_l.cpu().double() - want_m).abs().max()) < 2e-5 * 10
+    print()
+
+
 @pytest.mark.parametrize("n", [1, 63, 4097, 1 << 20])
 def test_activation_entries_three_way(libs, n):
     """K5-K9 (bn.cu:302-377): in-place leaky-ReLU / ELU forward, their gradient rewrites, ELU inverse."""
