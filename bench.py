@@ -76,21 +76,22 @@ def cpu_baseline(seconds, size):
     state = {"G": {}, "D": {}}
     x, y = O.synthetic_batch(B, size, size)
     O.distillation_step(PS, PT, PD, x, y, cfg, state)            # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
+    times, t_all = [], time.perf_counter()
+    while True:                                                    # >= 3 steps, more while the budget lasts (<= 5): MEDIAN step
+        t0 = time.perf_counter()
         O.distillation_step(PS, PT, PD, x, y, cfg, state)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 3:
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 5 or (len(times) >= 3 and time.perf_counter() - t_all >= seconds):
             break
+    n, el = len(times), statistics.median(times) * len(times)    # value = B / median step time
     try:
         with open("/proc/cpuinfo") as fh:
             model = [l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
     return {"value": round(B * n / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d timed steps (+1 warm-up) of the full Pi+Pa+Ho step at batch %d, %dx%d, fp32, torch CPU "
-                      "(oracle/step_torch.py); host CPU: %s" % (n, B, size, size, model),
+            "sample": "median of %d timed steps (+1 warm-up; step times %s s) of the full Pi+Pa+Ho step at batch %d, %dx%d, fp32, "
+                      "torch CPU (oracle/step_torch.py); host CPU: %s" % (n, "/".join("%.1f" % t for t in times), B, size, size, model),
             "config1": {"value": round(B / statistics.median(t1), 4), "unit": "images/sec",
                         "sample": "median of 3 steps (+1 warm-up), BASELINE configs[0]: Pi only, batch 2, 256x256"}}
 

@@ -36,16 +36,22 @@ def _miopen_db_version():
 
 
 def _private_miopen_db():
+    """Copy of the shipped db in a per-user directory keyed by the db's content hash, the rank and the job (MASTER_PORT when
+    torchrun set one): two jobs on one host, or eight ranks of one job, never append to the same files.  Other copies
+    (superseded databases, finished jobs) that have not been touched for a week are pruned when a new copy is made."""
     import hashlib
     import shutil
     import tempfile
+    import time
     tag = hashlib.sha1()
     for root, _, files in sorted(_os.walk(MIOPEN_DB_DIR)):
         for f in sorted(files):
             tag.update(f.encode())
             with open(_os.path.join(root, f), "rb") as fh:
                 tag.update(fh.read())
-    name = "miopen_db_%s_r%s" % (tag.hexdigest()[:12], _os.environ.get("LOCAL_RANK", "0"))
+    digest = tag.hexdigest()[:12]
+    job = _os.environ.get("MASTER_PORT")
+    name = "miopen_db_%s_r%s%s" % (digest, _os.environ.get("LOCAL_RANK", "0"), "_j" + job if job else "")
     bases = [_os.environ.get("SKD_MIOPEN_CACHE"), _os.path.join(_os.path.expanduser("~"), ".cache", "skd_amd"),
              _os.path.join(tempfile.gettempdir(), "skd_amd_%d" % _os.getuid())]
     for base in bases:
@@ -62,6 +68,11 @@ def _private_miopen_db():
                 except OSError:
                     pass
                 shutil.rmtree(tmp, ignore_errors=True)
+                for other in _os.listdir(base):                    # garbage-collect copies of superseded databases
+                    path = _os.path.join(base, other)
+                    if (other.startswith("miopen_db_") and path != dst and _os.path.isdir(path)
+                            and time.time() - _os.path.getmtime(path) > 7 * 86400):
+                        shutil.rmtree(path, ignore_errors=True)
             if _os.path.isdir(dst) and _os.access(dst, _os.W_OK):
                 return dst
         except OSError:
@@ -74,6 +85,7 @@ def check_miopen_db(warn=True):
     silently ignores the database (its file names carry the version) and falls back to untuned immediate-mode
     heuristics -- 58-70 instead of 107-137 TFLOP/s on the dilated 3x3 convolutions of this step -- so it WARNS loudly;
     re-run tools/miopen_tune.py on the new build."""
+    configure_miopen()
     if MIOPEN_DB_VERSION is None:
         return True
     try:
@@ -92,18 +104,31 @@ def check_miopen_db(warn=True):
     return have == MIOPEN_DB_VERSION
 
 
-# MIOpen's fp32 Winograd solvers are OFF by default.  They lose about three decimal digits (measured on MI355X,
-# tests/diagnostics/diag_dstep.py: 2.6e-4 relative error on the discriminator's backward-data convolutions with them,
-# 6e-7 without; the same kernels put 1.8e-3 on the student's DSN weight gradient at 256 x 256), which the WGAN critic's
-# cancelling gradients amplify to per cent, they are NCHW-only (each call is wrapped in layout transposes), and whether
-# immediate mode picks them varied between otherwise identical runs.  The step is not slower without them (76.9 vs
-# 77.1 ms).  SKD_MIOPEN_WINOGRAD=1 leaves MIOpen's choice alone.
-if _os.environ.get("SKD_MIOPEN_WINOGRAD", "0") != "1":
-    _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+_configured = False
 
-if _os.path.isdir(MIOPEN_DB_DIR):
-    MIOPEN_DB_VERSION = _miopen_db_version()
-    if "MIOPEN_USER_DB_PATH" not in _os.environ:
-        _dst = _private_miopen_db() or MIOPEN_DB_DIR
-        _os.environ["MIOPEN_USER_DB_PATH"] = _dst
-        _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(_dst, "cache"))
+
+def configure_miopen(force=False):
+    """Point MIOpen at (a private copy of) the shipped find-db / kernel cache and switch its fp32 Winograd solvers off.
+    Process-wide, therefore EXPLICIT: importing the package changes nothing; ``NetModel.__init__``, ``bench.py``, the tools
+    and tests/conftest.py call this before their first convolution (MIOpen reads the variables when its handle is created,
+    so call it before running any convolution in the process; variables the user already set are left alone).
+
+    Winograd: MIOpen's fp32 Winograd solvers lose about three decimal digits (measured on MI355X,
+    tests/diagnostics/diag_dstep.py: 2.6e-4 relative error on the discriminator's backward-data convolutions with them,
+    6e-7 without; the same kernels put 1.8e-3 on the student's DSN weight gradient at 256 x 256), which the WGAN critic's
+    cancelling gradients amplify to per cent, they are NCHW-only (each call is wrapped in layout transposes), and whether
+    immediate mode picks them varied between otherwise identical runs.  The step is not slower without them (76.9 vs
+    77.1 ms).  SKD_MIOPEN_WINOGRAD=1 leaves MIOpen's choice alone."""
+    global _configured, MIOPEN_DB_VERSION
+    if _configured and not force:
+        return _os.environ.get("MIOPEN_USER_DB_PATH")
+    _configured = True
+    if _os.environ.get("SKD_MIOPEN_WINOGRAD", "0") != "1":
+        _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+    if _os.path.isdir(MIOPEN_DB_DIR):
+        MIOPEN_DB_VERSION = _miopen_db_version()
+        if "MIOPEN_USER_DB_PATH" not in _os.environ:
+            dst = _private_miopen_db() or MIOPEN_DB_DIR
+            _os.environ["MIOPEN_USER_DB_PATH"] = dst
+            _os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _os.path.join(dst, "cache"))
+    return _os.environ.get("MIOPEN_USER_DB_PATH")

@@ -97,11 +97,52 @@ class CSTrainTransform:
         return (out, lab) if labels is not None else out
 
 
+_TRANSFORMS = {}
+
+
+def _transform_for(cfg, device):
+    """One CSTrainTransform per (configuration, device) and process, built on first use -- i.e. in the process that calls
+    it, never in a loader worker."""
+    key = (cfg, str(torch.device(device)))
+    tf = _TRANSFORMS.get(key)
+    if tf is None:
+        crop, mean, scale, mirror, ignore = cfg
+        tf = _TRANSFORMS[key] = CSTrainTransform(crop, mean, scale, mirror, ignore, device)
+    return tf
+
+
+class RawBatch:
+    """What ``CSDataSet.collate`` hands from a DataLoader WORKER to the training process: the decoded uint8 images and
+    raw-id labels of a batch stacked on the host, the per-sample random draws (taken in the worker, where the reference
+    takes them: ``__getitem__`` runs there, datasets.py:158,198-199,206), and the transform's configuration.  Holds no
+    device tensor, so it pickles through the worker queues under fork and spawn alike; ``to_device`` -- called by
+    ``NetModel.set_input`` in the process that owns the GPU -- runs the one-kernel transform."""
+
+    def __init__(self, images, labels, params, cfg):
+        self.images, self.labels, self.params, self.cfg = images, labels, params, cfg
+
+    def pin_memory(self):                       # DataLoader(pin_memory=True) calls this on custom batch objects
+        self.images, self.labels = self.images.pin_memory(), self.labels.pin_memory()
+        return self
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def to_device(self, device):
+        """-> (images (B,3,h,w) fp32 channels-last, labels (B,h,w) int64) on ``device``."""
+        return _transform_for(self.cfg, device)(self.images, self.labels, self.params)
+
+
 class CSDataSet(torch.utils.data.Dataset):
     """Same constructor as the reference's ``CSDataSet`` (datasets.py:122-150).  ``__getitem__`` only READS: it returns
     the decoded uint8 image (H, W, 3) BGR, the raw-id label (H, W), ``size`` and ``name``; the transform -- everything
-    the reference does between imread and the return (:176-210) -- is applied per batch by ``CSTrainTransform`` on the
-    device (``collate`` + ``transform`` below).  Decoding needs cv2, like the reference; nothing else here does."""
+    the reference does between imread and the return (:176-210) -- is applied per batch on the device.  Decoding needs
+    cv2, like the reference; nothing else here does.
+
+        loader = DataLoader(ds, batch_size=b, collate_fn=ds.collate, num_workers=4, pin_memory=True)
+        for data in loader: model.set_input(data)      # data[0] is a RawBatch; set_input runs the device transform
+
+    ``collate`` is host-only (it runs in the forked / spawned workers, which must not touch the GPU)."""
 
     def __init__(self, root, list_path, max_iters=None, crop_size=(321, 321), mean=(128, 128, 128), scale=True, mirror=True,
                  ignore_label=255, device="cuda"):
@@ -116,7 +157,14 @@ class CSDataSet(torch.utils.data.Dataset):
             name = osp.splitext(osp.basename(label_path))[0]
             self.files.append({"img": osp.join(self.root, image_path), "label": osp.join(self.root, label_path), "name": name})
         self.id_to_trainid = dict(ID_TO_TRAINID)
-        self.transform = CSTrainTransform(crop_size, mean, scale, mirror, ignore_label, device)
+        self.device = device
+        self._cfg = ((int(self.crop_h), int(self.crop_w)), tuple(float(m) for m in np.asarray(mean).reshape(3)), bool(scale),
+                     bool(mirror), int(ignore_label))
+
+    @property
+    def transform(self):
+        """The device transform of this dataset's configuration (built on first use, in the calling process)."""
+        return _transform_for(self._cfg, self.device)
 
     def __len__(self):
         return len(self.files)
@@ -129,9 +177,11 @@ class CSDataSet(torch.utils.data.Dataset):
         return torch.from_numpy(image), torch.from_numpy(label), np.array(image.shape), datafiles["name"]
 
     def collate(self, batch):
-        """``collate_fn`` for the DataLoader: stacks the raw samples and runs the device transform; returns the
-        reference's batch tuple (images, labels, size, name) with images / labels already on the GPU."""
+        """``collate_fn`` for the DataLoader -- HOST ONLY: stacks the raw samples and draws the per-sample random numbers.
+        Returns the reference's batch tuple (images, labels, size, name) with ``images`` a ``RawBatch`` (and ``labels``
+        None: they travel inside it); ``NetModel.set_input`` turns it into device tensors."""
         images = torch.stack([b[0] for b in batch])
         labels = torch.stack([b[1] for b in batch])
-        out, lab = self.transform(images, labels)
-        return out, lab, np.stack([b[2] for b in batch]), [b[3] for b in batch]
+        H0, W0 = images.shape[1], images.shape[2]
+        params = [draw_sample_params(H0, W0, self.crop_h, self.crop_w, self.scale, self.is_mirror) for _ in batch]
+        return RawBatch(images, labels, params, self._cfg), None, np.stack([b[2] for b in batch]), [b[3] for b in batch]

@@ -398,14 +398,28 @@ def _nhwc_unsupported(x):
     return c < 4 or c > 1024 or bool(c & (c - 1))
 
 
-def _via_nchw(fn, x, *rest, residual=None):
+_warned_via_nchw = False
+
+
+def _via_nchw(fn, x, *rest, residual=None, inplace=False):
     """Run ``fn`` on an NCHW copy and hand the result back channels-last.  The reference accepts any channel count
     (libs/functions.py:70-162); the channels-last kernels do not, so odd widths (and the teacher's 2048-channel layers
-    when somebody trains or differentiates it) take the NCHW kernels through two layout copies instead of failing.
-    Costs the in-place property for that call, nothing else."""
+    when somebody trains or differentiates it) take the NCHW kernels through two layout copies instead of failing
+    (a RuntimeWarning says so once).  ``inplace``: the caller's contract is "mutates and returns x" (inplace_abn /
+    inplace_abn_sync, libs/functions.py:100-108): the result is copied back INTO x (a differentiable copy_, so autograd
+    still reaches ``fn``'s backward) and x is returned, for callers that ignore the return value."""
+    global _warned_via_nchw
+    if not _warned_via_nchw:
+        _warned_via_nchw = True
+        import warnings
+        warnings.warn("InPlace-ABN on a channels-last tensor with %d channels (not a power of two in [4, 1024]): NCHW kernels "
+                      "through two layout copies" % x.shape[1], RuntimeWarning)
     if residual is not None:
         residual = residual.contiguous()
     out = fn(x.contiguous(), *rest) if residual is None else fn(x.contiguous(), *rest, residual)
+    if inplace:
+        x.copy_(out)
+        return x
     return out.contiguous(memory_format=torch.channels_last)
 
 
@@ -486,7 +500,7 @@ def inplace_abn(x, weight, bias, running_mean, running_var, training=True, momen
     """Signature of libs/functions.py:70-73 (InPlaceABN.apply)."""
     if _nhwc_unsupported(x):
         return _via_nchw(lambda xc: _InPlaceABN.apply(xc, weight, bias, running_mean, running_var, training, momentum, eps,
-                                                      activation, slope, None), x)
+                                                      activation, slope, None), x, inplace=True)
     return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
                              activation, slope, None)
 
@@ -508,6 +522,6 @@ def inplace_abn_sync(x, weight, bias, running_mean, running_var, extra=None, tra
         group = dist.group.WORLD
     if _nhwc_unsupported(x):
         return _via_nchw(lambda xc: _InPlaceABN.apply(xc, weight, bias, running_mean, running_var, training, momentum, eps,
-                                                      activation, slope, group), x)
+                                                      activation, slope, group), x, inplace=True)
     return _InPlaceABN.apply(x, weight, bias, running_mean, running_var, training, momentum, eps,
                              activation, slope, group)

@@ -33,9 +33,13 @@ def iou_from_confusion(confusion_matrix):
     return float(iu.mean()), iu
 
 
-def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, recurrence=1, type="val"):
+def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, recurrence=1, type="val", rank=0, world=1,
+                  group=None):
     """Returns (mean_IU, IU_array) like evaluate.py:156-206.  ``loader`` yields (image (1,3,H,W) float, label (1,H,W),
-    size, name) like CSDataSet (dataset/datasets.py:121-210); ``size[0][:2]`` is the valid (h, w) of the label."""
+    size, name) like CSDataSet (dataset/datasets.py:121-210); ``size[0][:2]`` is the valid (h, w) of the label.
+    ``rank`` / ``world`` (one process per GPU): every rank walks the same loader but evaluates only the batches with
+    ``index % world == rank``; the integer confusion matrices are summed over ``group`` with one all-reduce, so every
+    rank returns the identical result of the whole validation set (the reference's single process evaluated alone)."""
     if not whole:
         raise NotImplementedError("sliding-window evaluation (evaluate.py:62-104) is not part of the MI355X path; "
                                   "train_and_eval.py evaluates with whole=True")
@@ -52,7 +56,9 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
     w4 = [p for p in model.parameters() if p.dim() == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1]
     cl_model = device.type == "cuda" and bool(w4) and all(p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() for p in w4)
     with torch.no_grad():
-        for batch in loader:
+        for index, batch in enumerate(loader):
+            if index % world != rank:
+                continue
             image, label, size = batch[0], batch[1], batch[2]
             lab_np = np.asarray(label) if not torch.is_tensor(label) else label.numpy() if label.device.type == "cpu" else None
             if lab_np is not None and bool(((lab_np != ignore_label) & ((lab_np < 0) | (lab_np >= num_classes))).any()):
@@ -74,4 +80,6 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
             SF.seg_confusion(logits.float(), full, ignore_label, confusion, want_pred=False)
     if was_training:
         model.train()
+    if world > 1:
+        torch.distributed.all_reduce(confusion, group=group)           # exact: int64 counts
     return iou_from_confusion(confusion.cpu().numpy())

@@ -137,6 +137,8 @@ class NetModel():
     def __init__(self, args):
         self.args = args
         device = args.device
+        from .. import configure_miopen
+        configure_miopen()                           # tuned find-db + kernel cache, Winograd off (process-wide, explicit)
         torch.backends.cudnn.enabled = True          # MIOpen
         student = Res_pspnet(BasicBlock, [2, 2, 2, 2], num_classes=args.classes_num)
         load_S_model(args, student, False)
@@ -239,6 +241,10 @@ class NetModel():
     def set_input(self, data):
         images, labels, _, _ = data
         dev = self.args.device
+        if hasattr(images, "to_device") and hasattr(images, "params"):
+            # dataset.CSDataSet.collate: decoded uint8 batch + random draws from a loader worker; the reference's whole
+            # per-sample transform (dataset/datasets.py:176-210) runs here, in the process that owns the GPU, as one kernel
+            images, labels = images.to_device(dev)
         self.images = images.to(dev, non_blocking=True)
         self.labels = labels.long().to(dev, non_blocking=True)
         parallel_old.set_replica_batch(self.images.shape[0], self.images.device)   # InPlaceABNSync pools by sample count
@@ -335,6 +341,12 @@ class NetModel():
         self.D_solver.step()
 
     def optimize_parameters(self):
+        try:
+            self._optimize_parameters()
+        finally:
+            parallel_old.clear_replica_batch()     # the per-rank sample weights belong to THIS step (set_input)
+
+    def _optimize_parameters(self):
         self.forward()
         self.G_solver.zero_grad()
         ho = self.args.ho == True  # noqa: E712
@@ -373,18 +385,12 @@ class NetModel():
         main.wait_stream(side)
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
-        """networks/evaluate.py via kd_model.py:178-181.  One process per GPU: rank 0 evaluates (the replicas are
-        identical), the others wait at the barrier and receive the result -- the reference's single process evaluated
-        once, eight ranks must not each walk the validation set and race on the checkpoint file."""
+        """networks/evaluate.py via kd_model.py:178-181.  One process per GPU: the replicas are identical, so the validation
+        set is SHARDED over the ranks (batch i on rank i % world) and the integer confusion matrices are all-reduced --
+        every rank returns the same (mean_IU, IU_array), nobody idles at a barrier while rank 0 walks 500 images."""
         from .evaluate import evaluate_main
-        world = parallel_old.world_size()
-        result = [None, None]
-        if parallel_old.rank() == 0:
-            result = list(evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size,
-                                        num_classes=num_classes, whole=whole))
-        if world > 1:
-            torch.distributed.broadcast_object_list(result, src=0)
-        return result[0], result[1]
+        return tuple(evaluate_main(model=model, loader=loader, gpu_id=gpu_id, input_size=input_size, num_classes=num_classes,
+                                   whole=whole, rank=parallel_old.rank(), world=parallel_old.world_size()))
 
     def print_info(self, epoch, step):
         logging.info("step:{:5d} G_lr:{:.6f} G_loss:{:.5f}(mc:{:.5f} pixelwise:{:.5f} pairwise:{:.5f}) "

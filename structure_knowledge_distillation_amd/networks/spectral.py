@@ -1,21 +1,40 @@
-"""Spectral normalisation wrapper backed by csrc/spectral.hip.
+"""Spectral normalisation of a wrapped layer's weight, evaluated by csrc/spectral.hip.
 
-Same wrapper contract as the reference's networks/spectral.py:14-68: wraps a module, replaces its
-``weight`` Parameter by ``weight_bar`` (learnable) plus ``weight_u`` / ``weight_v``
-(``requires_grad=False`` Parameters, so they appear in the state dict under the same keys), and on
-EVERY forward runs ``power_iterations`` power steps that overwrite u and v, then sets
-``module.weight = weight_bar / sigma`` with a differentiable sigma = u^T W v.
-The ~12 stock launches per layer of the reference become 3 kernel launches (functional.py).
+Drop-in for the wrapper the reference's discriminator is built from (networks/spectral.py:14-68, used at
+networks/sagan_models.py:117-136).  What a caller can observe is kept:
+
+  * ``SpectralNorm(layer, name="weight", power_iterations=1)``; the wrapped layer is reachable as ``.module``;
+  * the layer loses its ``weight`` Parameter and gains three: ``weight_bar`` (trainable, the raw weight) and
+    ``weight_u`` / ``weight_v`` (``requires_grad=False``), so state dicts carry ``module.weight_bar/_u/_v`` exactly
+    like checkpoints written by the reference; u is drawn before v, both N(0, 1) then scaled to unit length, so a
+    seeded construction yields the same vectors;
+  * EVERY forward -- training or not, graph or no graph -- advances u and v by ``power_iterations`` power steps
+    (written through ``.data``: no autograd version bump, which is what lets the D step of kd_model.py:156-164 run three
+    forwards before one backward) and then installs ``weight = weight_bar / sigma`` on the layer as a plain tensor,
+    sigma = u . (W v) differentiable with respect to ``weight_bar`` only.
+
+How it is computed differs: the reference issues ~12 small torch ops per layer and forward; here the last power step,
+sigma and the division are three launches of one fused kernel family with a hand-written backward
+(``functional.spectral_normalize``), earlier power steps (``power_iterations > 1``) use its u / v-only entry.
 """
 import torch
 from torch import nn
-from torch.nn import Parameter
 
 from .. import functional as SF
 
+_SUFFIXES = ("_u", "_v", "_bar")
+
 
 def l2normalize(v, eps=1e-12):
+    """v / (|v| + eps) (spectral.py:10-11); exported because callers of the reference module import it."""
     return v / (v.norm() + eps)
+
+
+def _unit_gaussian(like, n):
+    """A fresh N(0, 1) vector of length n on ``like``'s device / dtype, scaled to unit length, as a frozen Parameter."""
+    p = nn.Parameter(like.new_empty(n).normal_(0, 1), requires_grad=False)
+    p.data = l2normalize(p.data)
+    return p
 
 
 class SpectralNorm(nn.Module):
@@ -24,34 +43,27 @@ class SpectralNorm(nn.Module):
         self.module = module
         self.name = name
         self.power_iterations = power_iterations
-        if not self._made_params():
-            self._make_params()
+        if not all(hasattr(module, name + s) for s in _SUFFIXES):     # wrapping an already-wrapped layer is a no-op
+            self._split_weight()
 
-    def _update_u_v(self):
-        u = getattr(self.module, self.name + "_u")
-        v = getattr(self.module, self.name + "_v")
-        w = getattr(self.module, self.name + "_bar")
-        for _ in range(self.power_iterations - 1):
-            SF.spectral_power_iteration(w, u.data, v.data)
-        setattr(self.module, self.name, SF.spectral_normalize(w, u.data, v.data))
+    def _split_weight(self):
+        """weight -> (weight_u, weight_v, weight_bar), registered in that order (the reference's state-dict order)."""
+        layer, name = self.module, self.name
+        raw = layer._parameters.pop(name)
+        rows = raw.shape[0]
+        cols = raw.numel() // rows
+        layer.register_parameter(name + "_u", _unit_gaussian(raw.data, rows))
+        layer.register_parameter(name + "_v", _unit_gaussian(raw.data, cols))
+        layer.register_parameter(name + "_bar", nn.Parameter(raw.data))
 
-    def _made_params(self):
-        return all(hasattr(self.module, self.name + s) for s in ("_u", "_v", "_bar"))
-
-    def _make_params(self):
-        w = getattr(self.module, self.name)
-        height = w.data.shape[0]
-        width = w.view(height, -1).data.shape[1]
-        u = Parameter(w.data.new(height).normal_(0, 1), requires_grad=False)
-        v = Parameter(w.data.new(width).normal_(0, 1), requires_grad=False)
-        u.data = l2normalize(u.data)
-        v.data = l2normalize(v.data)
-        w_bar = Parameter(w.data)
-        del self.module._parameters[self.name]
-        self.module.register_parameter(self.name + "_u", u)
-        self.module.register_parameter(self.name + "_v", v)
-        self.module.register_parameter(self.name + "_bar", w_bar)
+    def _parts(self):
+        layer, name = self.module, self.name
+        return getattr(layer, name + "_bar"), getattr(layer, name + "_u"), getattr(layer, name + "_v")
 
     def forward(self, *args):
-        self._update_u_v()
+        w_bar, u, v = self._parts()
+        for _ in range(self.power_iterations - 1):
+            SF.spectral_power_iteration(w_bar, u.data, v.data)
+        # the final power step, sigma and w_bar / sigma in one fused op; u.data / v.data are overwritten in place
+        setattr(self.module, self.name, SF.spectral_normalize(w_bar, u.data, v.data))
         return self.module.forward(*args)

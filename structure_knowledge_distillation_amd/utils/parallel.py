@@ -24,7 +24,7 @@ import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
            "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
-           "replica_weights"]
+           "clear_replica_batch", "replica_weights"]
 
 
 def init_distributed(backend=None):
@@ -74,8 +74,11 @@ _REPLICA = {"weights": None, "key": None}
 def set_replica_batch(local_batch, device, group=None):
     """Tell InPlaceABNSync how many samples THIS rank holds in the current step.  The reference's combine rule
     (libs/functions.py:196-197) silently assumes equal shards; here the per-rank counts are all-gathered (one tiny
-    collective per step, no host sync) and the statistics are pooled with weights n_g / sum(n) -- identical to the
-    reference when the shards are equal, exact when a loader hands out a short last batch."""
+    collective per step, no host sync) and the BN STATISTICS are pooled with weights n_g / sum(n) -- identical to the
+    reference when the shards are equal, exact batch statistics when a loader hands out a short last batch.  Only the
+    statistics: the LOSS stays the reference's plain mean over replicas of the per-replica losses (Reduce / len(outputs),
+    utils/parallel.py:155), so GradientAllReducer averages with 1 / G whatever the shard sizes -- for ragged shards that
+    is the reference's own weighting of the samples, not a sample-uniform one.  Valid until ``clear_replica_batch``."""
     if world_size(group) <= 1:
         _REPLICA["weights"] = None
         return None
@@ -84,6 +87,13 @@ def set_replica_batch(local_batch, device, group=None):
     dist.all_gather_into_tensor(counts, mine, group=group)
     _REPLICA["weights"] = counts / counts.sum()
     return _REPLICA["weights"]
+
+
+def clear_replica_batch():
+    """Forget the per-rank sample weights: ``NetModel.optimize_parameters`` calls this when the step is over, so a
+    synchronised forward that was NOT announced by ``set_replica_batch`` (another model, a direct forward) pools with the
+    reference's equal-shard rule instead of with a previous step's stale weights."""
+    _REPLICA["weights"] = None
 
 
 def replica_weights():

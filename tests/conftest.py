@@ -15,6 +15,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs the read-only reference tree at /root/reference")
 
 
+def pytest_sessionstart(session):
+    # the shipped MIOpen find-db / kernel cache (explicit since round 3: importing the package no longer sets it up)
+    import structure_knowledge_distillation_amd as S
+    S.configure_miopen()
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     has_gpu = torch.cuda.is_available()

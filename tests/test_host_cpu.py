@@ -357,9 +357,16 @@ def test_miopen_db_is_private_writable_copy_and_version_guard(tmp_path, monkeypa
     monkeypatch.delenv("MIOPEN_CUSTOM_CACHE_DIR", raising=False)
     monkeypatch.setenv("SKD_MIOPEN_CACHE", str(tmp_path))
     monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("MASTER_PORT", "29611")
     S = importlib.reload(S)
+    assert "MIOPEN_USER_DB_PATH" not in os.environ, "importing the package must not touch the process environment (ADVICE r02)"
+    stale = tmp_path / "miopen_db_000000000000_r0"          # a copy of a superseded database, untouched for 8 days: pruned
+    stale.mkdir()
+    os.utime(stale, (0, __import__("time").time() - 8 * 86400))
+    assert S.configure_miopen() == os.environ["MIOPEN_USER_DB_PATH"]
     dst = os.environ["MIOPEN_USER_DB_PATH"]
-    assert dst.startswith(str(tmp_path)) and dst.endswith("_r3") and os.path.isdir(os.path.join(dst, "cache"))
+    assert dst.startswith(str(tmp_path)) and dst.endswith("_r3_j29611") and os.path.isdir(os.path.join(dst, "cache"))
+    assert not stale.exists() and os.environ["MIOPEN_DEBUG_CONV_WINOGRAD"] == "0"
     assert sorted(os.listdir(dst)) == sorted(os.listdir(S.MIOPEN_DB_DIR))
     assert S.MIOPEN_DB_VERSION == (3, 5, 0) and S.check_miopen_db() is True
     monkeypatch.setattr(S, "MIOPEN_DB_VERSION", (9, 9, 9))

@@ -107,3 +107,47 @@ def test_random_draws_follow_the_reference_order():
     flip = np.random.choice(2) * 2 - 1                                        # :206
     assert got == (f, dh, dw, h_off, w_off, int(flip))
     assert D.draw_sample_params(300, 400, 512, 512, scale=False, mirror=False) == (1.0, 300, 400, 0, 0, 1)
+
+
+def test_collate_runs_in_dataloader_workers(ref, tmp_path, monkeypatch):
+    """``DataLoader(ds, collate_fn=ds.collate, num_workers>0)`` -- the documented recipe -- runs
+    collate_fn in forked worker processes, where nothing may touch the GPU.  collate is host-only now (stack + random
+    draws -> RawBatch); the device transform runs in the consuming process (NetModel.set_input / RawBatch.to_device).
+    cv2 is absent here: a stub ``imread`` decodes seeded arrays (the workers inherit it through fork)."""
+    import sys
+    import types
+    H0, W0 = 64, 96
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_COLOR, cv2.IMREAD_GRAYSCALE = 1, 0
+
+    def imread(path, flag):
+        g = np.random.RandomState(abs(hash(path)) % (2 ** 31))
+        return g.randint(0, 256, (H0, W0, 3)).astype(np.uint8) if flag == 1 else g.randint(0, 34, (H0, W0)).astype(np.uint8)
+
+    cv2.imread = imread
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    lst = tmp_path / "train.lst"
+    lst.write_text("".join("img/%d.png lab/%d.png\n" % (i, i) for i in range(6)))
+    ds = D.CSDataSet(str(tmp_path), str(lst), crop_size=(48, 40), mean=MEAN, device="cpu")
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, collate_fn=ds.collate, num_workers=2, shuffle=False)
+    _lib.install_test_backend(ref)
+    try:
+        seen = 0
+        for data in loader:
+            raw, none, size, names = data
+            assert isinstance(raw, D.RawBatch) and none is None and len(names) == 3 and tuple(size.shape) == (3, 3)
+            assert raw.images.dtype == torch.uint8 and tuple(raw.images.shape) == (3, H0, W0, 3) and not raw.images.is_cuda
+            assert len(raw.params) == 3 and all(len(p) == 6 for p in raw.params)
+            img, lab = raw.to_device("cpu")
+            want_img, want_lab = D.CSTrainTransform((48, 40), MEAN, device="cpu")(raw.images, raw.labels, raw.params)
+            assert torch.equal(img, want_img) and torch.equal(lab, want_lab)
+            assert tuple(img.shape) == (3, 3, 48, 40) and lab.dtype == torch.int64
+            seen += 1
+        assert seen == 2
+        # NetModel.set_input's branch: anything with to_device + params is transformed in the calling process
+        from structure_knowledge_distillation_amd.networks.kd_model import NetModel
+        holder = types.SimpleNamespace(args=types.SimpleNamespace(device=torch.device("cpu")))
+        NetModel.set_input(holder, data)
+        assert torch.equal(holder.images, img) and torch.equal(holder.labels, lab)
+    finally:
+        _lib.install_test_backend(None)

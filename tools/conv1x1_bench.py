@@ -22,6 +22,8 @@ SHAPES = [  # (Cin, Cout, HW, count per teacher forward, residual?)
 
 def main():
     import torch
+    import structure_knowledge_distillation_amd as _skd
+    _skd.configure_miopen()
     from structure_knowledge_distillation_amd import _lib, functional as SF
     import importlib
     IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
