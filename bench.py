@@ -244,14 +244,31 @@ def main():
     fence()
     el = time.perf_counter() - t0
     recs = _lib.disable_kernel_timing() if (not a.no_kernel_timing and rank == 0) else {}
-    if not a.no_kernel_timing and world == 1:
+    comm = None
+    if not a.no_kernel_timing:
         # kernel rates are a statement about the kernel, so these three steps run the D step serially (in the timed steps
-        # it shares the chip with the student's backward passes on a second stream, which stretches both)
+        # it shares the chip with the student's backward passes on a second stream, which stretches both).  Every rank
+        # steps (the collectives need all of them); rank 0 brackets its hand-written kernels, and -- N > 1 -- the spans its
+        # compute stream spends blocked on collectives (P.comm_timer: SyncABN exchanges, gradient all-reduce waits).
         d_stream, model._d_stream = model._d_stream, None
-        _lib.enable_kernel_timing([n for n in timed if n != roofline_entry])
+        if rank == 0:
+            _lib.enable_kernel_timing([n for n in timed if n != roofline_entry])
+            if world > 1:
+                P.comm_timer.enable()
         for i in range(3):
             step(a.warmup + a.steps + i)
-        recs.update(_lib.disable_kernel_timing())
+        if rank == 0:
+            recs.update(_lib.disable_kernel_timing())
+            if world > 1:
+                spans = P.comm_timer.disable()
+                sa, wa = spans.get("syncabn", (0.0, 0)), spans.get("allreduce_wait", (0.0, 0))
+                nb = len(model._s_reducer.buckets) + len(model._d_reducer.buckets)
+                mb = sum(b.flat.numel() * 4 for r in (model._s_reducer, model._d_reducer) for b in r.buckets) / 1e6
+                comm = {"syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": sa[1] // 3,
+                        "allreduce_wait_ms": round(wa[0] / 3, 3), "buckets": nb, "gradient_MB": round(mb, 1),
+                        "backend": dist.get_backend(),
+                        "note": "per step, from 3 extra untimed steps with the D step serial: time rank 0's compute stream was "
+                                "blocked in the SyncABN all-gather / all-reduce calls and in GradientAllReducer.finish() waits"}
         model._d_stream = d_stream
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -312,6 +329,8 @@ def main():
             worst = min(line["kernels"].items(), key=lambda kv: kv[1]["achieved_GBs"] if kv[1]["avg_elems"] >= (1 << 20) else 1e9)
             line["roofline"]["worst_other_kernel"] = {"entry": worst[0], "achieved_GBs": worst[1]["achieved_GBs"],
                                                       "frac": round(worst[1]["achieved_GBs"] / HBM_PEAK_GBS, 4)}
+    if comm is not None:
+        line["comm"] = comm
     if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:

@@ -212,9 +212,12 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
     """Cross-replica statistics (libs/functions.py:185-209): all_gather [mean, var], the reference combine rule
     (pooled with the per-rank sample weights when utils.parallel.set_replica_batch announced them), running-stat
     update with the pooled n.  Returns contiguous (mean, var)."""
+    from ..utils.parallel import comm_timer
     g = _group_size(group)
     gathered = stat.new_empty((g, 2, c))
+    tok = comm_timer.begin("syncabn", stat)
     dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=group)
+    comm_timer.end(tok)
     out = stat.new_empty((2, c))
     w = _replica_weights(group)
     _lib.check(lib.skd_abn_combine_stats(g, c, gathered.data_ptr(), _lib.ptr(w), dist.get_rank(group) if w is not None else 0,
@@ -227,12 +230,14 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
 def _sync_grad_stats(stat, group):
     """libs/functions.py:271-272: [edz, eydz] are averaged over the replicas -- weighted by the per-rank sample
     counts when they are known (the pooled expectation), plain mean otherwise."""
+    from ..utils.parallel import comm_timer
     w = _replica_weights(group)
     if w is not None:
         stat.mul_(w[dist.get_rank(group)])
-        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
-    else:
-        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+    tok = comm_timer.begin("syncabn", stat)
+    dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+    comm_timer.end(tok)
+    if w is None:
         stat.div_(_group_size(group))
 
 

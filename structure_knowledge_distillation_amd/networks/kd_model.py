@@ -140,6 +140,16 @@ class NetModel():
         from .. import configure_miopen
         configure_miopen()                           # tuned find-db + kernel cache, Winograd off (process-wide, explicit)
         torch.backends.cudnn.enabled = True          # MIOpen
+        # SKD_DETERMINISTIC=1: run-to-run bit-reproducible steps.  Every hand-written kernel already is (fixed-order
+        # reductions, no float atomics); what is not by default are MIOpen's fastest fp32 weight-gradient / backward-data
+        # solvers (split-K with atomic adds) and rocBLAS kernels with atomics.  The mode sets MIOpen's DETERMINISTIC
+        # convolution attribute (torch.backends.cudnn.deterministic) and PyTorch's deterministic-algorithms switch (which
+        # also puts rocBLAS into atomics-not-allowed mode); warn_only because a few stock backward ops have no
+        # deterministic variant and are not on this path.  Cost: DESIGN.md section 9 (profiles/r03*_determinism.json).
+        self.deterministic = os.environ.get("SKD_DETERMINISTIC", "0") == "1"
+        if self.deterministic:
+            torch.backends.cudnn.deterministic = True
+            torch.use_deterministic_algorithms(True, warn_only=True)
         student = Res_pspnet(BasicBlock, [2, 2, 2, 2], num_classes=args.classes_num)
         load_S_model(args, student, False)
         print_model_parm_nums(student, "student_model")

@@ -110,6 +110,59 @@ def broadcast_module(module, src=0, group=None):
             dist.broadcast(t.data, src, group=group)
 
 
+class CommTimer:
+    """Optional accounting of the time the COMPUTE stream spends blocked on collectives (bench.py --gpus N: the ``comm``
+    object of the JSON line).  A span is bracketed by two events on the current stream -- one recorded before the
+    collective (or the wait for an asynchronous one) is issued, one after -- so its duration is what the collective
+    exposed to the critical path, not its own length.  Off unless ``enable()`` was called; CPU tensors (gloo tests) use
+    the host clock."""
+
+    def __init__(self):
+        self.on = False
+        self.spans = []
+
+    def enable(self):
+        self.on, self.spans = True, []
+
+    def begin(self, tag, ref):
+        if not self.on:
+            return None
+        if ref.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(ref.device))
+            return (tag, e0, ref.device)
+        import time
+        return (tag, time.perf_counter(), None)
+
+    def end(self, tok):
+        if tok is None:
+            return
+        tag, t0, dev = tok
+        if dev is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(dev))
+            self.spans.append((tag, t0, e1))
+        else:
+            import time
+            self.spans.append((tag, None, time.perf_counter() - t0))
+
+    def disable(self):
+        """-> {tag: (total milliseconds, spans)}; synchronises the device once."""
+        self.on = False
+        if any(t0 is not None for _, t0, _ in self.spans) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {}
+        for tag, t0, t1 in self.spans:
+            ms = t0.elapsed_time(t1) if t0 is not None else 1e3 * t1
+            tot, n = out.get(tag, (0.0, 0))
+            out[tag] = (tot + ms, n + 1)
+        self.spans = []
+        return out
+
+
+comm_timer = CommTimer()
+
+
 class _Bucket:
     __slots__ = ("params", "flat", "pending", "work", "offsets")
 
@@ -203,7 +256,9 @@ class GradientAllReducer:
         inv = 1.0 / self.world
         with torch.no_grad():
             for b in self.buckets:
+                tok = comm_timer.begin("allreduce_wait", b.flat)
                 b.work.wait()
+                comm_timer.end(tok)
                 b.flat.mul_(inv)
                 dsts, srcs = [], []
                 for p, o in zip(b.params, b.offsets):

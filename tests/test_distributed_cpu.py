@@ -58,12 +58,16 @@ def _sync_abn(rank, world):
     x = torch.randn(4, 6, 5, 3, generator=g) * 2 + 1
     gz = torch.randn(4, 6, 5, 3, generator=g)
     w, b = torch.randn(6, generator=g), torch.randn(6, generator=g)
+    from structure_knowledge_distillation_amd.utils import parallel as P
     mod = libs.InPlaceABNSync(6, activation="leaky_relu").train()
     with torch.no_grad():
         mod.weight.copy_(w); mod.bias.copy_(b)
     xs = x[rank * 2:(rank + 1) * 2].clone().requires_grad_(True)
+    P.comm_timer.enable()
     z = mod(xs * 1.0)
     (z * gz[rank * 2:(rank + 1) * 2]).sum().backward()
+    spans = P.comm_timer.disable()
+    assert spans["syncabn"][1] == 2 and spans["syncabn"][0] >= 0.0      # one exchange forward, one backward (bench.py "comm")
     return {"z": z.detach(), "dx": xs.grad, "dw": mod.weight.grad, "db": mod.bias.grad,
             "rm": mod.running_mean.clone(), "rv": mod.running_var.clone()}
 

@@ -261,3 +261,8 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     assert out["value"] > 0 and abs(out["value"] - 4 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
     for k, v in out["config"]["losses_last_step"].items():
         assert v == v and abs(v) < 1e6, (k, v)          # finite
+    # the N > 1 line explains its own efficiency: roofline stays, comm breakdown added
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    comm = out["comm"]
+    assert comm["syncabn_collectives"] == 58 and comm["syncabn_ms"] > 0           # 29 training ABN layers, forward + backward
+    assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"

@@ -423,6 +423,53 @@ def test_full_step_b8_vs_golden():
         assert err <= GRAD_BOUND * rec["base"] + 1e-5 * rec["norm"] + 1e-7, ("student_after", k, err, rec["base"])
 
 
+DET_GRAD_FLOOR = 5e-4
+
+
+def test_full_step_b8_deterministic_mode_bit_equal_and_tight_bound(monkeypatch):
+    """SKD_DETERMINISTIC=1 (MIOpen's deterministic convolution attribute + rocBLAS without atomics): the SAME batch-8 step
+    executed twice from the same state gives bit-identical losses and gradients (student and discriminator), and -- with
+    the split-K atomics noise gone -- every student gradient tensor meets the ONE bound with a floor of 5e-4 instead of
+    5e-3.  The cost of the mode is measured by tools/determinism_probe.py (profiles/)."""
+    monkeypatch.setenv("SKD_DETERMINISTIC", "1")
+    try:
+        gold = torch.load(os.path.join(GOLDEN_DIR, "step_b8_oracle.pt"), weights_only=False)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_golden_step_b8", os.path.join(GOLDEN_DIR, "make_golden_step_b8.py"))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+        B, H, W = gold["shape"]
+        PS, PT, PD = gen.init(torch.float32)
+        args = default_args(batch_size=B, device=DEV, weight_decay=gold["cfg"]["weight_decay"], lambda_pa=gold["cfg"]["lambda_pa"])
+        model = NetModel(args)
+        assert model.deterministic and torch.backends.cudnn.deterministic
+        no_dropout(model.student)
+        images, labels = O.synthetic_batch(B, H, W, seed=gold["seeds"]["batch"])
+        alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(gold["seeds"]["alpha"]))
+        runs = []
+        for rep in range(2):
+            _load_oracle_weights(model, PS, PT, PD)
+            model.G_solver.state.clear()
+            model.D_solver.state.clear()
+            model.gp_alpha = alpha.to(DEV)
+            model.set_input((images, labels, None, None))
+            model.optimize_parameters()                            # incl. the D step on its own stream
+            torch.cuda.synchronize()
+            gS = {k: p.grad.detach().clone() for k, p in model.student.named_parameters()}
+            gD = {k: p.grad.detach().clone() for k, p in model.D_model.named_parameters() if p.grad is not None}
+            runs.append((gS, gD, [model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss]))
+        assert runs[0][2] == runs[1][2], ("losses differ between two identical deterministic steps", runs[0][2], runs[1][2])
+        diff = [k for which in (0, 1) for k in runs[0][which] if not torch.equal(runs[0][which][k], runs[1][which][k])]
+        assert not diff, "gradients differ between two identical deterministic steps: %s" % diff[:10]
+        for k, want in gold["losses64"].items():
+            got = getattr(model, k)
+            assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
+        _check_grads(runs[0][0], gold["grads_S"], "B=8 student gradients, deterministic mode", bound=GRAD_BOUND, floor=DET_GRAD_FLOOR)
+    finally:
+        torch.backends.cudnn.deterministic = False
+        torch.use_deterministic_algorithms(False)
+
+
 def _config1_step(pa):
     """BASELINE configs[0] shape (batch 2, 256x256, 33x33 maps; Ho impossible at that size) on the GPU with the
     weights / inputs of tests/golden/reference_vectors.pt["step_config1_pa"] (seeds 41, 42, 43)."""
