@@ -211,7 +211,8 @@ int skd_pixelwise_loss(int N, int C, int HW, const float *logits_s, const float 
  *      norm   : Fhat[b,c,m] = F[b,c,m] / (sqrt(sum_c F^2) + 1e-8)      (utils.py:170-176)
  *      gram   : G[b] = Fhat_T[b]^T Fhat_T[b] - Fhat_S[b]^T Fhat_S[b]  (M x M, fp32 MFMA);
  *               loss = sum G^2 / M^2 / B                               (utils.py:178-183)
- *      bwd    : dFhat_S = -4 * gscale / (M^2 B) * Fhat_S G ; dP = dFhat_S / norm
+ *      bwd    : dFhat_S = -4 * gscale / (M^2 B) * Fhat_S G ; dP = dFhat_S / norm   (autograd of the above with
+ *               the norm a constant, utils.py:175)
  *      unpool : scatter dP through the argmax into a dense (B,C,H,W) gradient
  * ---------------------------------------------------------------------------------- */
 int skd_maxpool_argmax(int planes, int H, int W, int kh, int kw, const float *x,
@@ -229,10 +230,14 @@ int64_t skd_pairwise_workspace_floats(int B, int M);
 int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *fhat_s,
                            const float *fhat_t, float *G, float *loss, float *workspace,
                            skd_stream_t stream);
-/* fhat_s_t (B, ldm, ldc); grad_loss [1] on the device; dpooled (B, Cs, ldm) */
-int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t,
+/* fhat_s (B, Cs, ldm): the normalised student panel the forward already holds (no node-major copy since round 3: the
+ * kernel transposes it on the way into LDS); grad_loss [1] on the device; dpooled (B, Cs, ldm), columns >= M zero.
+ * The contraction over the nodes is split over workgroups for large M; the partials are combined in a fixed order
+ * (deterministic).  workspace: skd_pairwise_backward_workspace_floats(B, Cs, M) floats, 16-byte aligned. */
+int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M);
+int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s,
                           const float *G, const float *norm_s, const float *grad_loss,
-                          float *dpooled, skd_stream_t stream);
+                          float *dpooled, float *workspace, skd_stream_t stream);
 /* Small graphs (M <= 64; the reference default --pool-scale 0.5 gives M = 9): norm + both Grams + loss (+ gradient)
  * of one image in one workgroup, no padding to MFMA tiles.  pooled_s (B, Cs, M), pooled_t (B, Ct, M);
  * loss[0] = sum (A_T - A_S)^2 / M^2 / B; dpooled (B, Cs, M) or NULL = d loss / d pooled_s for an upstream gradient

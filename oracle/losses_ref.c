@@ -177,10 +177,12 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   return 1;
 }
 
-int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fst, const float *G,
-                          const float *norm_s, const float *grad_loss, float *dpooled, stream_t st) {
-  (void)st;
-  if (B <= 0 || Cs <= 0 || M <= 0 || !fst || !G || !norm_s || !grad_loss || !dpooled) return 0;
+int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M) { (void)B; (void)Cs; (void)M; return 1; }
+
+int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fs, const float *G,
+                          const float *norm_s, const float *grad_loss, float *dpooled, float *ws, stream_t st) {
+  (void)st; (void)ws;
+  if (B <= 0 || Cs <= 0 || M <= 0 || !fs || !G || !norm_s || !grad_loss || !dpooled) return 0;
   /* L = sum G^2/(M^2 B), G = A_T - A_S, A_S = Fh^T Fh  =>  dL/dFh = -4/(M^2 B) Fh G ; dP = dFh / norm */
   const double coef = -4.0 / ((double)M * (double)M * (double)B) * (double)grad_loss[0];
   for (int b = 0; b < B; ++b) {
@@ -190,8 +192,8 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *f
       if (m < M)
         for (int n = 0; n < M; ++n) {                                /* G is symmetric in exact arithmetic; index as written */
           const double g = (double)G[((int64_t)b * ldm + n) * ldm + m];
-          const float *frow = fst + ((int64_t)b * ldm + n) * ldc;
-          for (int c = 0; c < Cs; ++c) acc[c] += (double)frow[c] * g;
+          const float *fcol = fs + (int64_t)b * Cs * ldm + n;          /* Fhat_S[b][c][n], channel-major */
+          for (int c = 0; c < Cs; ++c) acc[c] += (double)fcol[(int64_t)c * ldm] * g;
         }
       for (int c = 0; c < Cs; ++c)
         dpooled[((int64_t)b * Cs + c) * ldm + m] = m < M ? (float)(acc[c] * coef / (double)norm_s[(int64_t)b * M + m]) : 0.f;
@@ -215,7 +217,7 @@ int skd_pairwise_small(int B, int Cs, int Ct, int M, const float *ps, const floa
   r = r && skd_channel_l2_normalise(B, Cs, M, ps, fs, ldm, fst, ldc, nrm, st) && skd_channel_l2_normalise(B, Ct, M, pt, ft, ldm, NULL, 0, NULL, st);
   r = r && skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, fs, ft, G, loss, NULL, st);
   if (r && dpooled) {
-    r = skd_pairwise_backward(B, Cs, M, ldm, ldc, fst, G, nrm, &one, dp, st);
+    r = skd_pairwise_backward(B, Cs, M, ldm, fs, G, nrm, &one, dp, NULL, st);
     for (int64_t q = 0; r && q < (int64_t)B * Cs; ++q) memcpy(dpooled + q * M, dp + q * ldm, sizeof(float) * (size_t)M);
   }
   free(fs); free(ft); free(fst); free(nrm); free(G); free(dp);

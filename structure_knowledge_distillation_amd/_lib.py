@@ -66,7 +66,8 @@ SIGNATURES = {
     "skd_channel_l2_normalise": (_I, [_I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
     "skd_pairwise_workspace_floats": (_L, [_I, _I]),
     "skd_pairwise_gram_loss": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "skd_pairwise_backward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "skd_pairwise_backward_workspace_floats": (_L, [_I, _I, _I]),
+    "skd_pairwise_backward": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "skd_maxunpool_scatter": (_I, [_I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
     "skd_spectral_workspace_floats": (_L, [_I, _I]),
     "skd_spectral_norm_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),

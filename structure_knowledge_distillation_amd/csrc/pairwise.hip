@@ -11,8 +11,8 @@
 //             running (max, argmax) per column, then a short segmented reduce in LDS.
 //   normalise one workgroup per (image, 64 nodes): channel L2 norm + scaled copy into a
 //             zero-padded (B, C, ldm) buffer, ldm = M rounded up to 128 -> the GEMM tiles below
-//             need no edge masks and all their loads are 16-byte aligned.  A node-major copy
-//             FhS^T (B, ldm, ldc) is written for the backward GEMM.
+//             need no edge masks and all their loads are 16-byte aligned.  (An optional node-major copy
+//             (B, ldm, ldc) is still offered by the entry; the backward GEMM no longer needs it.)
 //   gram      G = Fh_T^T Fh_T - Fh_S^T Fh_S accumulated in ONE set of fp32 MFMA accumulators
 //             (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- there is no
 //             TF32/xf32 on gfx950 and bf16 would break the 1e-4 loss tolerance).  128x128 output
@@ -20,9 +20,9 @@
 //             a double-buffered LDS ring of k-major panels; both operands are rows of the same
 //             channel-major matrix, so LDS reads are conflict-free ds_read_b32 with no transposes.
 //             The epilogue squares and reduces the tile (A_S/A_T never exist) and stores G.
-//   backward  dFh_S = -4 g/(M^2 B) * Fh_S G with the same tile routine (operands FhS^T and G),
-//             epilogue divides by the detached norm; unpool scatters through the argmax while
-//             writing the dense gradient once (no zero-fill pass, no atomics).
+//   backward  dFh_S = -4 g/(M^2 B) * Fh_S G with the same tile routine (operands Fh_S, transposed on the way into
+//             LDS, and G; node range split over workgroups with a fixed-order combine), scaled by the detached norm;
+//             unpool scatters through the argmax while writing the dense gradient once (no zero-fill pass, no atomics).
 // Bounds: pool/unpool/normalise are HBM-bound; gram is fp32-MFMA-bound for M >~ 100
 // (2*B*M^2*(C_S+C_T) flop), launch/latency-bound at the reference default M = 9.
 #include "skd_common.hpp"
@@ -208,119 +208,182 @@ __global__ __launch_bounds__(kThreads) void l2_normalise_kernel(const float *__r
 }
 
 // =============================================================================================
-// 128x128 fp32 MFMA tile over k-major panels:  acc[i][j] += sign * sum_k A[k][i] * B[k][j]
+// 128x128 fp32 MFMA tile:  acc[i][j] += sign * sum_k A(k, i) * B(k, j)
+//
+// Round-3 rewrite (profiles/r02h_pmc.json: matrix pipe 0.52 busy in the Gram kernel, 0.31 in the
+// backward).  The disassembly of the round-2 routine showed where the other half went:
+//   * the K segments lived in a dynamically indexed array -> SCRATCH memory; every K-tile re-read its descriptor with
+//     scratch loads and waited (s_waitcnt vmcnt(0)) before each of its four global loads, serialising
+//     4 x (scratch + HBM latency) in front of every 4096 MFMA cycles;
+//   * every k-step was "ds_read; s_waitcnt lgkmcnt(0); 4 MFMA": the wave parked for the LDS latency sixteen times per K-tile;
+//   * the teacher / student sign was a v_cndmask + s_nop in front of every MFMA pair.
+// Now: segments are plain scalars selected with uniform branches (no arrays, global_load with SGPR bases), the sign is
+// applied once per element when a panel is stored to LDS, the LDS operands of k-step s+1 are fetched before the MFMAs
+// of k-step s are issued (software pipelining in registers), and full K-tiles take a guard-free path.
+// The backward GEMM reads its A operand Fhat_S (B, Cs, ldm) in the layout the forward already has -- node index
+// contiguous -- and transposes it on the way into LDS (TRANS_A: 129-float panel rows, <= 2-way bank conflicts on the scalar
+// stores), so the node-major copy that channel_l2_normalise used to write (and its uncoalesced 4-byte stores, 1.9x the
+// algorithmic traffic) is gone; its K = ldm contraction is split over gridDim.z workgroups with a fixed-order combine.
 // =============================================================================================
 constexpr int kTile = 128;
-constexpr int kBK = 32;   // 64 KiB of LDS per workgroup (2 stages x 2 panels): 2 workgroups per CU
-constexpr int kPanel = kBK * kTile;  // floats per panel per stage
-
-struct Segment {
-  const float *A;  // element [k][i] at A[k*lda + i], i in [0,128)
-  const float *B;
-  int64_t lda, ldb;
-  int K;        // valid k rows (rows beyond read as zero)
-  int negate;   // accumulate with a minus sign
+constexpr int kBK = 32;             // K-tile: 16 k-steps of v_mfma_f32_32x32x2_f32
+constexpr int kSAT = kTile + 1;     // A-panel row stride (floats) when A is staged through a transpose
+template <bool TRANS_A>
+struct Panels {
+  static constexpr int SA = TRANS_A ? kSAT : kTile;
+  static constexpr int offB = kBK * SA;                 // B panel follows the A panel
+  static constexpr int stage = kBK * SA + kBK * kTile;  // floats per pipeline stage
+  static constexpr size_t lds_bytes = sizeof(float) * 2 * stage;   // double buffered: 64 KiB (64.25 with TRANS_A): 2 workgroups / CU
 };
 
-constexpr int kLoadsPerThread = kBK / 8;  // panel rows handled by one thread (8 rows per pass of 256 threads)
+// One K segment.  A(k, i): k-major -- element at A[k * lda + i] -- or, TRANS_A, i-major -- element at A[i * lda + k], rows
+// i >= rowsA read as zero.  B(k, j) at B[k * ldb + j].  Rows k >= K read as zero (k-major operands only; TRANS_A needs
+// K % kBK == 0).  All tile-local: i, j in [0, 128).
+struct Seg {
+  const float *A, *B;
+  int lda, ldb, K, rowsA;
+  float sign;
+};
+
 struct TileRegs {
-  float4 a[kLoadsPerThread], b[kLoadsPerThread];
+  float4 a[4], b[4];
 };
 
-__device__ __forceinline__ void panel_load(const Segment &s, int k0, TileRegs &r) {
+// (the segment arrives as scalars BY VALUE: a `const Seg &` picked with `first ? s0 : s1` made the compiler keep both structs
+// in scratch memory and re-load the fields -- with a wait -- in front of every K-tile)
+template <bool TRANS_A>
+__device__ __forceinline__ void panel_load(const float *__restrict__ sA, const float *__restrict__ sB, int lda, int ldb, int K,
+                                           int rowsA, int k0, TileRegs &r) {
+  struct { const float *A, *B; int lda, ldb, K, rowsA; } s = {sA, sB, lda, ldb, K, rowsA};
   const int t = threadIdx.x;
-  const int row = t >> 5;       // 0..7
-  const int c4 = (t & 31) * 4;  // 0..124
+  const int row = t >> 5, c4 = (t & 31) * 4;            // k-major operands: 8 panel rows x 128 columns per pass
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k0 + kBK <= s.K) {                                 // uniform: full K-tile, no guards
 #pragma unroll
-  for (int h = 0; h < kLoadsPerThread; ++h) {
-    const int k = k0 + row + 8 * h;
-    if (k < s.K) {
-      r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)k * s.lda + c4);
-      r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)k * s.ldb + c4);
-    } else {
-      r.a[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      r.b[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < 4; ++h) r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)(k0 + row + 8 * h) * s.ldb + c4);
+    if (!TRANS_A) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)(k0 + row + 8 * h) * s.lda + c4);
+    }
+  } else {                                               // last, partial K-tile of a segment: rows k >= K are zero
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int k = k0 + row + 8 * h;
+      r.b[h] = zero;
+      if (!TRANS_A) r.a[h] = zero;
+      if (k < s.K) {
+        r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)k * s.ldb + c4);
+        if (!TRANS_A) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)k * s.lda + c4);
+      }
+    }
+  }
+  if (TRANS_A) {                                         // i-major: 32 rows x 32 k per pass, a lane reads 4 consecutive k
+    const int i = t >> 3, k4 = (t & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int ii = i + 32 * h;
+      r.a[h] = zero;
+      if (ii < s.rowsA) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)ii * s.lda + k0 + k4);
     }
   }
 }
 
-__device__ __forceinline__ void panel_store(float *lds_stage, const TileRegs &r) {
+template <bool TRANS_A>
+__device__ __forceinline__ void panel_store(float *st, const TileRegs &r, float sign) {
   const int t = threadIdx.x;
-  const int row = t >> 5;
-  const int c4 = (t & 31) * 4;
+  const int row = t >> 5, c4 = (t & 31) * 4;
 #pragma unroll
-  for (int h = 0; h < kLoadsPerThread; ++h) {
-    *reinterpret_cast<float4 *>(lds_stage + (row + 8 * h) * kTile + c4) = r.a[h];
-    *reinterpret_cast<float4 *>(lds_stage + kPanel + (row + 8 * h) * kTile + c4) = r.b[h];
+  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(st + Panels<TRANS_A>::offB + (row + 8 * h) * kTile + c4) = r.b[h];
+  if (!TRANS_A) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float4 v = r.a[h];
+      v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
+      *reinterpret_cast<float4 *>(st + (row + 8 * h) * kTile + c4) = v;
+    }
+  } else {
+    const int i = t >> 3, k4 = (t & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float *q = st + k4 * kSAT + i + 32 * h;
+      q[0] = r.a[h].x * sign;
+      q[kSAT] = r.a[h].y * sign;
+      q[2 * kSAT] = r.a[h].z * sign;
+      q[3 * kSAT] = r.a[h].w * sign;
+    }
   }
 }
 
-__device__ __forceinline__ void tile_compute(const float *lds_stage, bool negate, f32x16 (&acc)[2][2]) {
+// 16 k-steps on one LDS stage.  Lane (l31 = lane & 31, kk = lane >> 5) feeds column / row l31 of the 32-wide operand
+// slices with k = 2 * ks + kk; the operands of step ks + 1 are read before the four MFMAs of step ks are issued.
+template <bool TRANS_A>
+__device__ __forceinline__ void tile_compute(const float *st, f32x16 (&acc)[2][2]) {
+  constexpr int SA = Panels<TRANS_A>::SA;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
   const int kk = lane >> 5, l31 = lane & 31;
-  const float *pa = lds_stage + kk * kTile + wi + l31;
-  const float *pb = lds_stage + kPanel + kk * kTile + wj + l31;
+  const float *pa = st + kk * SA + wi + l31;
+  const float *pb = st + Panels<TRANS_A>::offB + kk * kTile + wj + l31;
+  float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two LDS reads (ds_read2_b32) of step 0
 #pragma unroll
   for (int ks = 0; ks < kBK / 2; ++ks) {
-    float a0 = pa[ks * 2 * kTile], a1 = pa[ks * 2 * kTile + 32];
-    const float b0 = pb[ks * 2 * kTile], b1 = pb[ks * 2 * kTile + 32];
-    if (negate) {
-      a0 = -a0;
-      a1 = -a1;
+    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+    if (ks + 1 < kBK / 2) {
+      na0 = pa[(ks + 1) * 2 * SA];
+      na1 = pa[(ks + 1) * 2 * SA + 32];
+      nb0 = pb[(ks + 1) * 2 * kTile];
+      nb1 = pb[(ks + 1) * 2 * kTile + 32];
     }
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    // pin the issue order: two MFMAs of step ks, the two LDS reads (ds_read2_b32) of step ks + 1, the other two MFMAs.
+    // The compiler waits with a full lgkmcnt(0) before step ks + 1 whatever is in flight, so the reads must be OLD by
+    // then: issued in the middle of the MFMA group they have >= 128 cycles of matrix-pipe time to land (left to itself
+    // the scheduler put them right in front of the wait: one LDS round trip parked per four MFMAs, 16 per K-tile).
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          // MFMA
+    if (ks + 1 < kBK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          // MFMA
   }
 }
 
-// Runs all segments back to back through the double-buffered LDS ring.
-template <int NSEG>
-__device__ __forceinline__ void tile_gemm(const Segment (&seg)[NSEG], float *lds, f32x16 (&acc)[2][2]) {
+// Runs segment s0 then (NSEG == 2) segment s1 through the double-buffered LDS ring into one accumulator set.
+template <bool TRANS_A, int NSEG>
+__device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds, f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int nk[NSEG], total = 0;
-#pragma unroll
-  for (int s = 0; s < NSEG; ++s) {
-    nk[s] = (seg[s].K + kBK - 1) / kBK;
-    total += nk[s];
-  }
+  const int n0 = (s0.K + kBK - 1) / kBK;
+  const int n1 = NSEG == 2 ? (s1.K + kBK - 1) / kBK : 0;
+  const int total = n0 + n1;
   if (total == 0) return;
-
+  constexpr int kStage = Panels<TRANS_A>::stage;
   TileRegs regs;
-  int s_ld = 0, k_ld = 0;  // next K-tile to load
-  while (s_ld < NSEG && nk[s_ld] == 0) ++s_ld;
-  panel_load(seg[s_ld], 0, regs);
-  panel_store(lds, regs);
+  {
+    const bool f = n0 > 0;
+    panel_load<TRANS_A>(f ? s0.A : s1.A, f ? s0.B : s1.B, f ? s0.lda : s1.lda, f ? s0.ldb : s1.ldb, f ? s0.K : s1.K,
+                        f ? s0.rowsA : s1.rowsA, 0, regs);
+    panel_store<TRANS_A>(lds, regs, f ? s0.sign : s1.sign);
+  }
   __syncthreads();
-  int stage = 0, s_cp = s_ld, k_cp = 0;
+  int stage = 0;
   for (int it = 0; it < total; ++it) {
-    // advance the load cursor
-    ++k_ld;
-    if (k_ld >= nk[s_ld]) {
-      k_ld = 0;
-      ++s_ld;
-      while (s_ld < NSEG && nk[s_ld] == 0) ++s_ld;
-    }
-    const bool more = it + 1 < total;
-    if (more) panel_load(seg[s_ld], k_ld * kBK, regs);
-    tile_compute(lds + stage * 2 * kPanel, seg[s_cp].negate != 0, acc);
-    if (more) panel_store(lds + (stage ^ 1) * 2 * kPanel, regs);
+    const int nx = it + 1;
+    const bool more = nx < total;
+    const bool first = nx < n0;                         // uniform: which segment the NEXT K-tile belongs to
+    if (more)                                           // scalar selects of by-value fields: everything stays in SGPRs
+      panel_load<TRANS_A>(first ? s0.A : s1.A, first ? s0.B : s1.B, first ? s0.lda : s1.lda, first ? s0.ldb : s1.ldb,
+                          first ? s0.K : s1.K, first ? s0.rowsA : s1.rowsA, first ? nx * kBK : (nx - n0) * kBK, regs);
+    tile_compute<TRANS_A>(lds + stage * kStage, acc);
+    if (more) panel_store<TRANS_A>(lds + (stage ^ 1) * kStage, regs, first ? s0.sign : s1.sign);
     __syncthreads();
     stage ^= 1;
-    ++k_cp;
-    if (k_cp >= nk[s_cp]) {
-      k_cp = 0;
-      ++s_cp;
-      while (s_cp < NSEG && nk[s_cp] == 0) ++s_cp;
-    }
   }
 }
 
@@ -336,7 +399,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
                                                                 float *__restrict__ G,
                                                                 float *__restrict__ part, int Cs,
                                                                 int Ct, int ldm, int nt) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * 2 * kPanel floats
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<false>::lds_bytes
   __shared__ float red[2 * kWavesPerWG];
   const int b = blockIdx.y;
   int ti = 0, rem = blockIdx.x;
@@ -346,19 +409,21 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
   }
   const int tj = ti + rem;
   const int i0 = ti * kTile, j0 = tj * kTile;
-  Segment seg[2];
-  seg[0].A = ft + (int64_t)b * Ct * ldm + i0;
-  seg[0].B = ft + (int64_t)b * Ct * ldm + j0;
-  seg[0].lda = seg[0].ldb = ldm;
-  seg[0].K = Ct;
-  seg[0].negate = 0;
-  seg[1].A = fs + (int64_t)b * Cs * ldm + i0;
-  seg[1].B = fs + (int64_t)b * Cs * ldm + j0;
-  seg[1].lda = seg[1].ldb = ldm;
-  seg[1].K = Cs;
-  seg[1].negate = 1;
+  Seg st_, ss_;                                          // teacher (+), student (-): one accumulator set
+  st_.A = ft + (int64_t)b * Ct * ldm + i0;
+  st_.B = ft + (int64_t)b * Ct * ldm + j0;
+  st_.lda = st_.ldb = ldm;
+  st_.K = Ct;
+  st_.rowsA = kTile;
+  st_.sign = 1.f;
+  ss_.A = fs + (int64_t)b * Cs * ldm + i0;
+  ss_.B = fs + (int64_t)b * Cs * ldm + j0;
+  ss_.lda = ss_.ldb = ldm;
+  ss_.K = Cs;
+  ss_.rowsA = kTile;
+  ss_.sign = -1.f;
   f32x16 acc[2][2];
-  tile_gemm<2>(seg, lds, acc);
+  tile_gemm<false, 2>(st_, ss_, lds, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
@@ -393,31 +458,51 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
   if (threadIdx.x == 0) part[(int64_t)b * gridDim.x + blockIdx.x] = sq;
 }
 
-// backward: D[c][m] = sum_n FhS^T[n][c] * G[n][m];  dP[c][m] = coef * D[c][m] / norm[m]
-// grid = (ntm * ntc, B)
-__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ fst,
+// backward: D[c][m] = sum_n Fhat_S[c][n] * G[n][m];  dP[c][m] = coef * gscale * D[c][m] / norm[m]
+// grid = (ntm * ntc, B, KS).  KS == 1: the epilogue scales and writes dpooled.  KS > 1: split z contracts the node range
+// [z * kper, (z + 1) * kper) and stores its raw 128 x 128 partial into part[z][b][c][m]; pairwise_bwd_combine_kernel adds the
+// KS partials in index order (deterministic) and applies the scale.
+__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ fs,
                                                                    const float *__restrict__ G,
                                                                    const float *__restrict__ norm,
                                                                    const float *__restrict__ gscale,
-                                                                   float *__restrict__ dpooled, int Cs,
-                                                                   int M, int ldm, int ldc, int ntm,
+                                                                   float *__restrict__ dpooled,
+                                                                   float *__restrict__ part, int Cs,
+                                                                   int M, int ldm, int ntm, int kper,
                                                                    float coef) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * 2 * kPanel floats
-  const int b = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<true>::lds_bytes
+  const int b = blockIdx.y, z = blockIdx.z;
   const int tc = blockIdx.x / ntm, tm = blockIdx.x % ntm;
   const int c0 = tc * kTile, m0 = tm * kTile;
-  Segment seg[1];
-  seg[0].A = fst + (int64_t)b * ldm * ldc + c0;  // [k = n][i = c]
-  seg[0].lda = ldc;
-  seg[0].B = G + (int64_t)b * ldm * ldm + m0;    // [k = n][j = m]
-  seg[0].ldb = ldm;
-  seg[0].K = ldm;
-  seg[0].negate = 0;
+  const int kb = z * kper, ke = min(ldm, kb + kper);
+  Seg s;
+  s.A = fs + ((int64_t)b * Cs + c0) * ldm + kb;      // A(k = n, i = c) = Fhat_S[c][n]: i-major, transposed while staged
+  s.lda = ldm;
+  s.rowsA = Cs - c0;
+  s.B = G + ((int64_t)b * ldm + kb) * ldm + m0;      // B(k = n, j = m) = G[n][m]
+  s.ldb = ldm;
+  s.K = ke - kb;
+  s.sign = 1.f;
   f32x16 acc[2][2];
-  tile_gemm<1>(seg, lds, acc);
+  tile_gemm<true, 1>(s, s, lds, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  if (part != nullptr) {
+    float *dst = part + (((int64_t)z * gridDim.y + b) * Cs) * ldm;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int m = m0 + wj + bj * 32 + (lane & 31);
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = c0 + wi + bi * 32 + frag_row(r, lane);
+          if (c < Cs) dst[(int64_t)c * ldm + m] = acc[bi][bj][r];
+        }
+    }
+    return;
+  }
   const float scale = coef * gscale[0];
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) {
@@ -431,6 +516,32 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
         if (c < Cs) dpooled[((int64_t)b * Cs + c) * ldm + m] = acc[bi][bj][r] * inv;
       }
   }
+}
+
+// dpooled[b][c][m4 .. m4+3] = coef * gscale / norm[b][m] * sum_z part[z][b][c][m]   (m >= M: 0); grid (ldm/4 / 256, Cs, B)
+__global__ __launch_bounds__(kThreads) void pairwise_bwd_combine_kernel(const float *__restrict__ part,
+                                                                       const float *__restrict__ norm,
+                                                                       const float *__restrict__ gscale,
+                                                                       float *__restrict__ dpooled, int KS, int B,
+                                                                       int Cs, int M, int ldm, float coef) {
+  const int m4 = (blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (m4 >= ldm) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int64_t row = ((int64_t)b * Cs + c) * ldm + m4;
+  const int64_t zs = (int64_t)B * Cs * ldm;
+  float4 s = *reinterpret_cast<const float4 *>(part + row);
+  for (int z = 1; z < KS; ++z) {
+    const float4 v = *reinterpret_cast<const float4 *>(part + z * zs + row);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float scale = coef * gscale[0];
+  const float *nr = norm + (int64_t)b * M;
+  float4 o;
+  o.x = m4 + 0 < M ? s.x * (scale / nr[m4 + 0]) : 0.f;
+  o.y = m4 + 1 < M ? s.y * (scale / nr[m4 + 1]) : 0.f;
+  o.z = m4 + 2 < M ? s.z * (scale / nr[m4 + 2]) : 0.f;
+  o.w = m4 + 3 < M ? s.w * (scale / nr[m4 + 3]) : 0.f;
+  *reinterpret_cast<float4 *>(dpooled + row) = o;
 }
 
 
@@ -599,14 +710,13 @@ int64_t skd_pairwise_workspace_floats(int B, int M) {
   return nt * (nt + 1) / 2 * B;
 }
 
-static constexpr size_t kGemmLds = sizeof(float) * 2 * 2 * kPanel;
 static bool gemm_lds_ready() {
   static bool done = false;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds) != hipSuccess) return false;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<false>::lds_bytes) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds) != hipSuccess) return false;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<true>::lds_bytes) != hipSuccess) return false;
     done = true;
   }
   return true;
@@ -622,26 +732,53 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   const int nt = ldm / kTile;
   const int ntri = nt * (nt + 1) / 2;
   if (!gemm_lds_ready()) return 0;
-  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), kGemmLds, st>>>(fhat_s, fhat_t, G, workspace, Cs, Ct,
-                                                                             ldm, nt);
+  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), Panels<false>::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace, Cs,
+                                                                                             Ct, ldm, nt);
   if (!ok()) return 0;
   // utils.py:181: / (M*M) / B
   return launch_final_sum(workspace, (int64_t)ntri * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
 }
 
-int skd_pairwise_backward(int B, int Cs, int M, int ldm, int ldc, const float *fhat_s_t, const float *G,
-                          const float *norm_s, const float *grad_loss, float *dpooled,
+// Node-range splits of the backward contraction: enough workgroups for ~2 per CU slot pair (1024), at least 8 K-tiles each.
+static int bwd_splits(int B, int Cs, int ldm) {
+  const int64_t tiles = (int64_t)(ldm / kTile) * cdiv(Cs, kTile) * B;
+  int64_t ks = cdiv(1024, tiles);
+  const int64_t most = ldm / (8 * kBK);
+  if (ks > most) ks = most;
+  if (ks > 8) ks = 8;
+  return ks < 1 ? 1 : (int)ks;
+}
+
+int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M) {
+  if (B <= 0 || Cs <= 0 || M <= 0) return 1;
+  const int ldm = skd_pairwise_ldm(M);
+  const int ks = bwd_splits(B, Cs, ldm);
+  return ks > 1 ? (int64_t)ks * B * Cs * ldm : 1;
+}
+
+int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, const float *G,
+                          const float *norm_s, const float *grad_loss, float *dpooled, float *workspace,
                           skd_stream_t stream) {
-  if (B <= 0 || Cs <= 0 || M <= 0 || !fhat_s_t || !G || !norm_s || !grad_loss || !dpooled) return 0;
-  if (ldm != skd_pairwise_ldm(M) || ldc % kTile != 0 || ldc < Cs || B > 65535) return 0;
-  if ((reinterpret_cast<uintptr_t>(fhat_s_t) | reinterpret_cast<uintptr_t>(G)) & 15) return 0;
-  const int ntm = ldm / kTile, ntc = ldc / kTile;
+  if (B <= 0 || Cs <= 0 || M <= 0 || !fhat_s || !G || !norm_s || !grad_loss || !dpooled) return 0;
+  if (ldm != skd_pairwise_ldm(M) || B > 65535) return 0;
+  if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(dpooled)) & 15) return 0;
+  const int ntm = ldm / kTile, ntc = (int)cdiv(Cs, kTile);
+  const int ks = bwd_splits(B, Cs, ldm);
+  if (ks > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return 0;
   // dL/dA_S = -2 G /(M^2 B); dFhat = Fhat (dA + dA^T) = -4/(M^2 B) Fhat G   (G symmetric)
   const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
   if (!gemm_lds_ready()) return 0;
-  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B), dim3(kThreads), kGemmLds, as_stream(stream)>>>(
-      fhat_s_t, G, norm_s, grad_loss, dpooled, Cs, M, ldm, ldc, ntm, coef);
-  return ok();
+  hipStream_t st = as_stream(stream);
+  int kper = (int)(cdiv(cdiv(ldm, kBK), ks) * kBK);      // node range per split, a multiple of the K-tile
+  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B, ks), dim3(kThreads), Panels<true>::lds_bytes, st>>>(
+      fhat_s, G, norm_s, grad_loss, dpooled, ks > 1 ? workspace : nullptr, Cs, M, ldm, ntm, kper, coef);
+  if (!ok()) return 0;
+  if (ks > 1) {
+    pairwise_bwd_combine_kernel<<<dim3((unsigned)cdiv(ldm / 4, kThreads), Cs, B), dim3(kThreads), 0, st>>>(
+        workspace, norm_s, grad_loss, dpooled, ks, B, Cs, M, ldm, coef);
+    return ok();
+  }
+  return 1;
 }
 
 

@@ -559,14 +559,12 @@ class _SimDis(Function):
         assert f_s.shape[0] == f_t.shape[0] and f_s.shape[2:] == f_t.shape[2:]
         lib, st = _lib.get(), _lib.stream_of(f_s)
         ldm = lib.skd_pairwise_ldm(m)
-        ldc = -(-cs // 128) * 128
         need = ctx.needs_input_grad[0]
         fh_s = f_s.new_empty((b, cs, ldm))
         fh_t = f_s.new_empty((b, ct, ldm))
-        fh_s_t = f_s.new_empty((b, ldm, ldc)) if need else None
         norm_s = f_s.new_empty((b, m)) if need else None
         _lib.check(lib.skd_channel_l2_normalise(b, cs, m, f_s.data_ptr(), fh_s.data_ptr(), ldm,
-                                                _lib.ptr(fh_s_t), ldc, _lib.ptr(norm_s), st),
+                                                None, 0, _lib.ptr(norm_s), st),
                    "skd_channel_l2_normalise")
         _lib.check(lib.skd_channel_l2_normalise(b, ct, m, f_t.data_ptr(), fh_t.data_ptr(), ldm,
                                                 None, 0, None, st), "skd_channel_l2_normalise")
@@ -576,23 +574,24 @@ class _SimDis(Function):
         _lib.check(lib.skd_pairwise_gram_loss(b, cs, ct, m, ldm, fh_s.data_ptr(), fh_t.data_ptr(),
                                               _lib.ptr(g), loss.data_ptr(), ws.data_ptr(), st),
                    "skd_pairwise_gram_loss")
-        ctx.geom = (tuple(f_s.shape), m, ldm, ldc)
-        ctx.save_for_backward(fh_s_t, g, norm_s)
+        ctx.geom = (tuple(f_s.shape), m, ldm)
+        ctx.save_for_backward(fh_s if need else None, g, norm_s)
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gl):
-        fh_s_t, g, norm_s = ctx.saved_tensors
+        fh_s, g, norm_s = ctx.saved_tensors
         if g is None:
             return None, None
-        shape, m, ldm, ldc = ctx.geom
+        shape, m, ldm = ctx.geom
         b, cs = shape[0], shape[1]
         lib, st = _lib.get(), _lib.stream_of(g)
         gl = gl.to(torch.float32).contiguous()
         dp = g.new_empty((b, cs, ldm))
-        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, ldc, fh_s_t.data_ptr(), g.data_ptr(),
-                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), st),
+        ws = g.new_empty((max(1, lib.skd_pairwise_backward_workspace_floats(b, cs, m)),))
+        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, fh_s.data_ptr(), g.data_ptr(),
+                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), ws.data_ptr(), st),
                    "skd_pairwise_backward")
         return dp[:, :, :m].reshape(shape), None
 
@@ -638,7 +637,6 @@ class _PairWise(Function):
             return loss
         ctx.small = False
         ldm = lib.skd_pairwise_ldm(m)
-        ldc = -(-cs // 128) * 128
         p_s = feat_s.new_empty((b, cs, m))
         p_t = feat_s.new_empty((b, ct, m))
         index = torch.empty((b, cs, m), dtype=torch.int32, device=feat_s.device) if need else None
@@ -648,10 +646,9 @@ class _PairWise(Function):
                                           None, st), "skd_maxpool_argmax")
         fh_s = feat_s.new_empty((b, cs, ldm))
         fh_t = feat_s.new_empty((b, ct, ldm))
-        fh_s_t = feat_s.new_empty((b, ldm, ldc)) if need else None
         norm_s = feat_s.new_empty((b, m)) if need else None
         _lib.check(lib.skd_channel_l2_normalise(b, cs, m, p_s.data_ptr(), fh_s.data_ptr(), ldm,
-                                                _lib.ptr(fh_s_t), ldc, _lib.ptr(norm_s), st),
+                                                None, 0, _lib.ptr(norm_s), st),
                    "skd_channel_l2_normalise")
         _lib.check(lib.skd_channel_l2_normalise(b, ct, m, p_t.data_ptr(), fh_t.data_ptr(), ldm,
                                                 None, 0, None, st), "skd_channel_l2_normalise")
@@ -661,8 +658,8 @@ class _PairWise(Function):
         _lib.check(lib.skd_pairwise_gram_loss(b, cs, ct, m, ldm, fh_s.data_ptr(), fh_t.data_ptr(),
                                               _lib.ptr(g), loss.data_ptr(), ws.data_ptr(), st),
                    "skd_pairwise_gram_loss")
-        ctx.geom = (b, cs, h, w, kh, kw, m, ldm, ldc)
-        ctx.save_for_backward(fh_s_t, g, norm_s, index)
+        ctx.geom = (b, cs, h, w, kh, kw, m, ldm, 0)
+        ctx.save_for_backward(fh_s if need else None, g, norm_s, index)
         return loss
 
     @staticmethod
@@ -679,15 +676,16 @@ class _PairWise(Function):
             _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dpg.data_ptr(), m, index.data_ptr(), dx.data_ptr(), st),
                        "skd_maxunpool_scatter")
             return dx, None, None, None
-        fh_s_t, g, norm_s, index = ctx.saved_tensors
+        fh_s, g, norm_s, index = ctx.saved_tensors
         if g is None:
             return None, None, None, None
-        b, cs, h, w, kh, kw, m, ldm, ldc = ctx.geom
+        b, cs, h, w, kh, kw, m, ldm, _ = ctx.geom
         lib, st = _lib.get(), _lib.stream_of(g)
         gl = gl.to(torch.float32).contiguous()
         dp = g.new_empty((b, cs, ldm))
-        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, ldc, fh_s_t.data_ptr(), g.data_ptr(),
-                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), st),
+        ws = g.new_empty((max(1, lib.skd_pairwise_backward_workspace_floats(b, cs, m)),))
+        _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, fh_s.data_ptr(), g.data_ptr(),
+                                             norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), ws.data_ptr(), st),
                    "skd_pairwise_backward")
         dx = g.new_empty((b, cs, h, w))
         _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dp.data_ptr(), ldm, index.data_ptr(),

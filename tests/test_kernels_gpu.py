@@ -524,7 +524,8 @@ def test_pairwise_stages(hip, ref, B, Cs, Ct, M):
         assert lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, P(fs), P(ft), P(G), P(loss), P(ws), None)
         gl = to(torch.tensor([0.5]))
         dp = to(torch.full((B, Cs, ldm), 9.0))
-        assert lib.skd_pairwise_backward(B, Cs, M, ldm, ldc, P(fst), P(G), P(nrm), P(gl), P(dp), None)
+        bws = to(torch.empty(max(1, lib.skd_pairwise_backward_workspace_floats(B, Cs, M))))
+        assert lib.skd_pairwise_backward(B, Cs, M, ldm, P(fs), P(G), P(nrm), P(gl), P(dp), P(bws), None)
         return [t.cpu() for t in (fs, ft, fst, nrm, G, loss, dp)]
 
     r = run(ref, lambda t: t.clone())

@@ -92,7 +92,7 @@ def test_pairwise_c_vs_torch(ref, H, W, scale):
     assert ref.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, P(fhs), P(fht), P(G), P(loss), P(torch.empty(1)), None)
     assert rel(loss, L.detach().reshape(1)) < 1e-5
     dp, dx = torch.empty(B, Cs, ldm), torch.empty(B, Cs, H, W)
-    assert ref.skd_pairwise_backward(B, Cs, M, ldm, ldc, P(fst), P(G), P(nrm), P(torch.tensor([0.5])), P(dp), None)
+    assert ref.skd_pairwise_backward(B, Cs, M, ldm, P(fhs), P(G), P(nrm), P(torch.tensor([0.5])), P(dp), None, None)
     assert ref.skd_maxunpool_scatter(B * Cs, H, W, kh, kw, P(dp), ldm, P(idx), P(dx), None)
     assert rel(dx, fso.grad) < 1e-4
 

@@ -18,7 +18,6 @@ sys.path.insert(0, ROOT)
 
 def run_mode(det, B):
     import torch
-    from oracle import step_torch as O
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     os.environ["SKD_DETERMINISTIC"] = "1" if det else "0"
     torch.backends.cudnn.deterministic = False
@@ -36,7 +35,10 @@ def run_mode(det, B):
             model.D_model.attn2.gamma.fill_(-0.5)
         snap = lambda mod: {k: v.detach().clone() for k, v in mod.state_dict().items()}
         S0, D0 = snap(model.student), snap(model.D_model)
-        images, labels = O.synthetic_batch(B, 512, 512, seed=0)
+        gen = torch.Generator().manual_seed(0)       # SURVEY.md 8d synthetic inputs (a tool may not import oracle/)
+        images = torch.randn(B, 3, 512, 512, generator=gen) * 57.0
+        labels = torch.randint(0, 19, (B, 512, 512), generator=gen)
+        labels[0, :32] = 255
         alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(7)).to(dev)
         runs = []
         for rep in range(3):

@@ -77,21 +77,24 @@ def build_cases(lib, torch, dev, st):
     B, Cs, Ct = 8, 128, 512
     for M in PAIRWISE_M:
         ldm = lib.skd_pairwise_ldm(M)
-        ldc = -(-Cs // 128) * 128
         ps, pt = torch.randn(B, Cs, M, device=dev), torch.randn(B, Ct, M, device=dev)
         fs, ft = torch.empty(B, Cs, ldm, device=dev), torch.empty(B, Ct, ldm, device=dev)
-        fst, nrm = torch.empty(B, ldm, ldc, device=dev), torch.empty(B, M, device=dev)
+        nrm = torch.empty(B, M, device=dev)
         G, loss, gl = torch.empty(B, ldm, ldm, device=dev), torch.empty(1, device=dev), torch.ones(1, device=dev)
         dp = torch.empty(B, Cs, ldm, device=dev)
         ws = torch.empty(max(1, lib.skd_pairwise_workspace_floats(B, M)), device=dev)
-        keep = (ps, pt, fs, ft, fst, nrm, G, loss, gl, dp, ws)
+        bws = torch.empty(max(1, lib.skd_pairwise_backward_workspace_floats(B, Cs, M)), device=dev)
+        keep = (ps, pt, fs, ft, nrm, G, loss, gl, dp, ws, bws)
         lib.skd_channel_l2_normalise(B, Ct, M, p(pt), p(ft), ldm, None, 0, None, st)
-        add("l2_normalise(student,+transpose)", [B, Cs, M], lambda ps=ps, fs=fs, fst=fst, nrm=nrm, M=M, ldm=ldm, ldc=ldc:
-            lib.skd_channel_l2_normalise(B, Cs, M, p(ps), p(fs), ldm, p(fst), ldc, p(nrm), st), 4 * B * Cs * M * 3, keep=keep)
+        # algorithmic bytes: read the pooled features, write the normalised panel (the node-major copy of rounds 1-2 is gone)
+        add("l2_normalise(student)", [B, Cs, M], lambda ps=ps, fs=fs, nrm=nrm, M=M, ldm=ldm:
+            lib.skd_channel_l2_normalise(B, Cs, M, p(ps), p(fs), ldm, None, 0, p(nrm), st), 4 * B * Cs * M * 2, keep=keep)
         add("pairwise_gram_loss", [B, Cs, Ct, M], lambda fs=fs, ft=ft, G=G, loss=loss, ws=ws, M=M, ldm=ldm:
             lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, p(fs), p(ft), p(G), p(loss), p(ws), st), flops=2.0 * B * M * M * (Cs + Ct))
-        add("pairwise_backward", [B, Cs, M], lambda fst=fst, G=G, nrm=nrm, gl=gl, dp=dp, M=M, ldm=ldm, ldc=ldc:
-            lib.skd_pairwise_backward(B, Cs, M, ldm, ldc, p(fst), p(G), p(nrm), p(gl), p(dp), st), flops=2.0 * B * M * M * Cs)
+        add("pairwise_gram_loss(no G store)", [B, Cs, Ct, M], lambda fs=fs, ft=ft, loss=loss, ws=ws, M=M, ldm=ldm:
+            lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, p(fs), p(ft), None, p(loss), p(ws), st), flops=2.0 * B * M * M * (Cs + Ct))
+        add("pairwise_backward", [B, Cs, M], lambda fs=fs, G=G, nrm=nrm, gl=gl, dp=dp, bws=bws, M=M, ldm=ldm:
+            lib.skd_pairwise_backward(B, Cs, M, ldm, p(fs), p(G), p(nrm), p(gl), p(dp), p(bws), st), flops=2.0 * B * M * M * Cs)
     return cases
 
 
