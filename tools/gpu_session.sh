@@ -138,6 +138,9 @@ EOF
     bench_tstream)
       (SKD_TEACHER_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_tstream.json 2>> $O/bench_tstream.err
       stamp "bench_tstream rc=$?"; cut -c1-260 $O/bench_tstream.json | tee -a $O/session.log ;;
+    det)
+      timeout 400 python tools/determinism_probe.py 8 > $O/determinism.jsonl 2> $O/determinism.err
+      stamp "det rc=$?"; cut -c1-700 $O/determinism.jsonl | tee -a $O/session.log ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
