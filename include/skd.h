@@ -161,6 +161,20 @@ int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const f
                                     const float *var, const float *weight, const float *bias, const float *edz,
                                     const float *eydz, float *dx, float *dweight, float *dbias, float eps,
                                     int accumulate, skd_stream_t stream);
+/* reduce + dx in ONE call (round 3).  When the tensor fits the chip's register file (rows * C up to ~9.4 M elements) both
+ * passes run as a single launch that keeps (y, dz) in VGPRs between them -- 12 instead of 20 bytes per element; larger
+ * tensors run the two entries above back to back.  edz / eydz are written as well (16-byte aligned for the one-launch
+ * path).  skd_abn_forward_train_nhwc takes the same register-resident route for up to ~18.8 M elements (8 instead of 12
+ * bytes per element).  SKD_ABN_FUSED=0 in the environment keeps the two-launch passes.
+ * skd_abn_relu_backward_nhwc: out == NULL selects the mask-from-x form (then dres must be NULL). */
+int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                          const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias,
+                          float eps, int activation, float slope, int accumulate, float *workspace,
+                          skd_stream_t stream);
+int skd_abn_relu_backward_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout,
+                               const float *mean, const float *var, const float *weight, const float *bias,
+                               float *edz, float *eydz, float *dx, float *dres, float *dweight, float *dbias,
+                               float eps, int accumulate, float *workspace, skd_stream_t stream);
 /* cross-replica combine in one launch (functions.py:196-197, 208-209): gathered is (G, 2, C) = every rank's
  * [mean, var]; writes the combined mean / var and, when the running buffers are given, updates them.
  * weights == NULL: the reference rule (equal per-rank sample counts), n = the POOLED count.

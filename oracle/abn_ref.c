@@ -508,6 +508,26 @@ int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const f
   return r;
 }
 
+/* reduce + dx in one call: the product fuses them into one launch, the maths is the two entries above */
+int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                          const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias, float eps,
+                          int act, float slope, int accumulate, float *ws, stream_t st) {
+  if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, act, slope, ws, st)) return 0;
+  return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, accumulate, st);
+}
+
+int skd_abn_relu_backward_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
+                               const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                               float *dres, float *dweight, float *dbias, float eps, int accumulate, float *ws, stream_t st) {
+  if (out == NULL) {
+    if (dres != NULL) return 0;
+    if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, ws, st)) return 0;
+    return skd_abn_relu_backward_dx_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, accumulate, st);
+  }
+  if (!skd_abn_relu_backward_reduce_nhwc(rows, C, x, out, dout, mean, var, edz, eydz, eps, ws, st)) return 0;
+  return skd_abn_relu_backward_dx_nhwc(rows, C, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, accumulate, st);
+}
+
 /* ---- cross-replica combine, libs/functions.py:196-197 + 208-209 ----
  * weights == NULL is the reference rule; weights (w_g = n_g / sum n) the pooled statistics of unequal shards. */
 int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var,

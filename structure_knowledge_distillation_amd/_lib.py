@@ -53,6 +53,8 @@ SIGNATURES = {
     "skd_abn_relu_backward_reduce_nhwc": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "skd_abn_relu_backward_reduce_nhwc_x": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "skd_abn_relu_backward_dx_nhwc_x": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "skd_abn_backward_nhwc": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _P, _P]),
+    "skd_abn_relu_backward_nhwc": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
     "skd_abn_relu_backward_dx_nhwc": (_I, [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "skd_abn_combine_stats": (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _P, _F, _D, _P]),
     "skd_abn_update_running": (_I, [_I, _P, _P, _P, _P, _F, _D, _P]),

@@ -1140,7 +1140,7 @@ static unsigned *red_counters() {
   RedPool &p = g_red_pool[dev];
   if (p.ptr == nullptr) {
     unsigned *q = nullptr;
-    const size_t bytes = sizeof(unsigned) * kRedSlots * kRedMaxCB;
+    const size_t bytes = sizeof(unsigned) * kRedSlots * kRedMaxCB * 2;   // ticket counters, then generation words
     if (hipMalloc(reinterpret_cast<void **>(&q), bytes) != hipSuccess) return nullptr;
     if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipFree(q);
@@ -1151,6 +1151,8 @@ static unsigned *red_counters() {
   const unsigned slot = __atomic_fetch_add(&g_red_next, 1u, __ATOMIC_RELAXED) % kRedSlots;
   return p.ptr + (size_t)slot * kRedMaxCB;
 }
+// the generation words (fused one-launch passes) that belong to a counter slot
+static unsigned *red_gens(unsigned *counters) { return counters + (size_t)kRedSlots * kRedMaxCB; }
 
 // 16-byte write-through store / L1-bypassing load (sc0 sc1): the hand-off traffic of the reductions below.  A plain
 // store would stay dirty in the producer XCD's L2 until an agent-scope release (buffer_wbl2) flushes that WHOLE L2 --
@@ -1401,6 +1403,297 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
   }
 }
 
+// =============================================================================================
+// Channels-last TRAINING passes as ONE launch with the tensor held in registers (round 3).
+//
+// The two-launch form above reads x for the statistics, ends the launch, and reads x again for the normalisation:
+// 12 bytes per element, and for the student's 4-70 MB tensors a second launch whose whole life is 8-20 us.  The chip's
+// register file is larger than those tensors (256 CUs x 512 KiB = 128 MiB): a launch of <= 256 workgroups x 1024
+// threads in which a thread keeps its NR <= 18 float4 of x in VGPRs can hold up to ~75 MB.  So:
+//   phase 1  every thread loads its rows ONCE, accumulates the shifted sums, red_finish() as before;
+//   hand-off the channel block's last arriver finishes mean / var (+ running statistics), stores them write-through
+//            and bumps the block's generation word; the other workgroups of the block spin (bounded) on that word --
+//            a grid barrier per channel block, safe because the launch never exceeds one workgroup per CU
+//            (MI355X_MICROARCH.md: "size the grid ... bound every spin");
+//   phase 2  normalise + affine + activation (+ residual) from the registers, one store.
+// HBM traffic: 8 bytes per element instead of 12 (forward), 12 instead of 20 (backward: z and dz are held, y and the
+// masked dz are kept instead of the raw inputs).  Tensors that do not fit (the 256 x 256 stem layers, C = 512 in the
+// backward) keep the two-launch path.  A spin that times out (2 s of wall clock: the grid was not co-resident) poisons
+// the statistics with NaN instead of hanging the device: loud, not fatal.
+// The generation word is read by every workgroup BEFORE it takes its ticket and bumped by the last arriver AFTER all
+// tickets: no host-side sequence number, so a captured launch can be replayed.
+// =============================================================================================
+constexpr uint64_t kFuseSpinTicks = 200000000ull;   // wall_clock64(): 100 MHz
+
+__device__ __forceinline__ unsigned gen_load(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0 spins until the generation word moves on from gen0; false = timed out
+__device__ __forceinline__ bool gen_wait(const unsigned *p, unsigned gen0) {
+  const uint64_t t0 = wall_clock64();
+  while (gen_load(p) == gen0) {
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > kFuseSpinTicks) return false;
+  }
+  return true;
+}
+__device__ __forceinline__ void store_wt4(float *p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 load_wt16(const float *p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+struct FuseGeom {
+  RedGeom r;
+  int nr;        // rows per thread actually used (<= NR of the instantiation)
+};
+
+// NRmax rows per thread: geometry with the most workgroups (<= 256 / CB per channel block) and the fewest rows each
+static bool make_fuse_geom(int64_t rows, int C, int nr_max, FuseGeom &f) {
+  if (!make_red_geom(rows, C, 1, f.r)) return false;
+  RedGeom &g = f.r;
+  const int64_t cap = kRedMaxWG / g.CB;
+  const int64_t want = cdiv(rows, g.rpp);
+  g.RG = (int)(want < cap ? want : cap);
+  const int64_t nr = cdiv(rows, (int64_t)g.RG * g.rpp);
+  if (nr > nr_max) return false;
+  f.nr = (int)nr;
+  g.RG = (int)cdiv(rows, (int64_t)g.rpp * f.nr);     // drop workgroups that would own no row
+  return true;
+}
+
+template <int ACT, bool HAS_RES, int NR>
+__global__ __launch_bounds__(kRedThreads) void abn_fwd_fused_nhwc_kernel(
+    const float *x, const float *res, float *out, float *__restrict__ part, unsigned *counters, unsigned *gens,
+    float *mean, float *var, float *running_mean, float *running_var, const float *__restrict__ weight,
+    const float *__restrict__ bias, int64_t rows, RedGeom g, int nr, float momentum, float eps, float slope) {
+  __shared__ double lds[kRedThreads * 4];
+  __shared__ double fin[kRedThreads * 2];
+  __shared__ unsigned ticket_s;
+  __shared__ unsigned gen_s;
+  const int t = threadIdx.x;
+  const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
+  const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
+  const int col = (cb * g.CW4 + cq) * 4;
+  if (t == 0) gen_s = gen_load(gens + cb);              // before this workgroup's ticket, hence before the bump
+  const int r0 = rg * g.rpp * nr + rsub;      // 32-bit row / element indices: a fused launch holds < 2^27 elements
+  const int nrows = (int)rows;
+  float4 v[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = r0 + u * g.rpp;
+    if (u < nr && r < nrows) v[u] = *reinterpret_cast<const float4 *>(x + ((r << (g.log2C4 + 2)) + col));
+  }
+  float4 K;
+  {
+    const float4 ka = *reinterpret_cast<const float4 *>(x + col);
+    const float4 kb = *reinterpret_cast<const float4 *>(x + ((rows / 2) << (g.log2C4 + 2)) + col);
+    const float4 kc = *reinterpret_cast<const float4 *>(x + ((rows - 1) << (g.log2C4 + 2)) + col);
+    K = make_float4(median3(ka.x, kb.x, kc.x), median3(ka.y, kb.y, kc.y), median3(ka.z, kb.z, kc.z), median3(ka.w, kb.w, kc.w));
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = r0 + u * g.rpp;
+    if (u < nr && r < nrows) {
+      const float d0 = v[u].x - K.x, d1 = v[u].y - K.y, d2 = v[u].z - K.z, d3 = v[u].w - K.w;
+      s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+      s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
+    }
+  }
+  const int CW = g.CW4 * 4;
+  bool good = true;
+  if (red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) {
+    if (t < CW) {
+      const int c = cb * CW + t;
+      const double cnt = (double)rows;
+      const double d = fin[(t >> 2) * 8 + (t & 3)] / cnt;
+      double vv = fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt - d * d;
+      if (vv < 0.0) vv = 0.0;
+      const int64_t ldr = (int64_t)g.C4 * 4;
+      const double Kc = (double)median3(x[c], x[(rows / 2) * ldr + c], x[(rows - 1) * ldr + c]);
+      const float m_f = (float)(Kc + d), v_f = (float)vv;
+      store_wt4(mean + c, m_f);
+      store_wt4(var + c, v_f);
+      if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
+      if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v_f, (float)rows);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(gens + cb, gen_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s) ? 1u : 0u;
+    __syncthreads();
+    good = ticket_s != 0u;
+  }
+  const f32x4 m4 = load_wt16(mean + col), v4 = load_wt16(var + col);
+  float m[4], is[4], gm[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = good ? m4[k] : __builtin_nanf("");
+    is[k] = inv_std_of(v4[k], eps);
+    gm[k] = gamma_of(weight, col + k, eps);
+    b[k] = beta_of(bias, col + k);
+  }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = r0 + u * g.rpp;
+    if (u < nr && r < nrows) {
+      const int o = (r << (g.log2C4 + 2)) + col;
+      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_RES) r4 = *reinterpret_cast<const float4 *>(res + o);
+      float4 z;
+      z.x = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].x, m[0], is[0], gm[0], b[0]) + r4.x : bn_pre(v[u].x, m[0], is[0], gm[0], b[0]), slope);
+      z.y = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].y, m[1], is[1], gm[1], b[1]) + r4.y : bn_pre(v[u].y, m[1], is[1], gm[1], b[1]), slope);
+      z.z = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].z, m[2], is[2], gm[2], b[2]) + r4.z : bn_pre(v[u].z, m[2], is[2], gm[2], b[2]), slope);
+      z.w = act_fwd<ACT>(HAS_RES ? bn_pre(v[u].w, m[3], is[3], gm[3], b[3]) + r4.w : bn_pre(v[u].w, m[3], is[3], gm[3], b[3]), slope);
+      *reinterpret_cast<float4 *>(out + o) = z;
+    }
+  }
+}
+
+// Backward, both passes in one launch.  MODE as in abn_grad_nhwc2_kernel / abn_grad_dx_nhwc_kernel; a thread keeps (y, dz) of
+// its NR rows -- the masked / activation-undone gradient and the normalised input -- between the phases.
+template <int ACT, int MODE, bool WRITE_RES, int NR>
+__global__ __launch_bounds__(kRedThreads) void abn_bwd_fused_nhwc_kernel(
+    const float *a_, const float *b_, const float *c_, const float *__restrict__ mean, const float *__restrict__ var,
+    const float *__restrict__ weight, const float *__restrict__ bias, float *__restrict__ part, unsigned *counters,
+    unsigned *gens, float *edz, float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps, float slope,
+    int64_t rows, RedGeom g, int nr, int accumulate) {
+  __shared__ double lds[kRedThreads * 4];
+  __shared__ double fin[kRedThreads * 2];
+  __shared__ unsigned ticket_s;
+  __shared__ unsigned gen_s;
+  const int t = threadIdx.x;
+  const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
+  const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
+  const int col = (cb * g.CW4 + cq) * 4;
+  if (t == 0) gen_s = gen_load(gens + cb);
+  float p0[4], p1[4], gm[4], bt[4], mul[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gam = gamma_of(weight, col + k, eps), is = inv_std_of(var[col + k], eps);
+    if (MODE == 0) {
+      p0[k] = beta_of(bias, col + k);
+      p1[k] = gam;
+    } else {
+      p0[k] = mean[col + k];
+      p1[k] = is;
+    }
+    gm[k] = gam;
+    bt[k] = MODE == 2 ? beta_of(bias, col + k) : 0.f;
+    mul[k] = gam * is;
+  }
+  const float inv_slope = 1.f / slope;
+  const int r0 = rg * g.rpp * nr + rsub;      // 32-bit row / element indices: a fused launch holds < 2^27 elements
+  const int nrows = (int)rows;
+  float4 Y[NR], DZ[NR];
+  constexpr int CH = 2;                    // rows loaded per trip: bounds the registers holding raw inputs
+#pragma unroll
+  for (int u0 = 0; u0 < NR; u0 += CH) {
+    float4 va[CH], vb[CH], vc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int u = u0 + j;
+      const int r = r0 + u * g.rpp;
+      if (u < NR && u < nr && r < nrows) {
+        const int o = (r << (g.log2C4 + 2)) + col;
+        va[j] = *reinterpret_cast<const float4 *>(a_ + o);
+        vb[j] = *reinterpret_cast<const float4 *>(b_ + o);
+        if (MODE == 1) vc[j] = *reinterpret_cast<const float4 *>(c_ + o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int u = u0 + j;
+      const int r = r0 + u * g.rpp;
+      if (u < NR && u < nr && r < nrows) {
+        const float A[4] = {va[j].x, va[j].y, va[j].z, va[j].w};
+        const float B[4] = {vb[j].x, vb[j].y, vb[j].z, vb[j].w};
+        const float Cc[4] = {MODE == 1 ? vc[j].x : 0.f, MODE == 1 ? vc[j].y : 0.f, MODE == 1 ? vc[j].z : 0.f,
+                             MODE == 1 ? vc[j].w : 0.f};
+        float y[4], dz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (MODE == 0) {
+            float zv = A[k];
+            dz[k] = B[k];
+            act_undo<ACT>(zv, dz[k], slope, inv_slope);
+            y[k] = (zv - p0[k]) / p1[k];
+          } else if (MODE == 1) {
+            dz[k] = B[k] > 0.f ? Cc[k] : 0.f;
+            y[k] = (A[k] - p0[k]) * p1[k];
+          } else {
+            dz[k] = bn_pre(A[k], p0[k], p1[k], gm[k], bt[k]) > 0.f ? B[k] : 0.f;
+            y[k] = (A[k] - p0[k]) * p1[k];
+          }
+        }
+        Y[u] = make_float4(y[0], y[1], y[2], y[3]);
+        DZ[u] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      }
+    }
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = r0 + u * g.rpp;
+    if (u < nr && r < nrows) {
+      s1[0] += DZ[u].x; s1[1] += DZ[u].y; s1[2] += DZ[u].z; s1[3] += DZ[u].w;
+      s2[0] += Y[u].x * DZ[u].x; s2[1] += Y[u].y * DZ[u].y; s2[2] += Y[u].z * DZ[u].z; s2[3] += Y[u].w * DZ[u].w;
+    }
+  }
+  const int CW = g.CW4 * 4;
+  bool good = true;
+  if (red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) {
+    if (t < CW) {
+      const int c = cb * CW + t;
+      const double cnt = (double)rows;
+      const float e_f = (float)(fin[(t >> 2) * 8 + (t & 3)] / cnt);          // bn.cu:176
+      const float ey_f = (float)(fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt);     // bn.cu:177
+      store_wt4(edz + c, e_f);
+      store_wt4(eydz + c, ey_f);
+      const float norm = (float)rows;
+      if (dweight != nullptr) {   // bn.cu:217-229 accumulates; accumulate == 0 writes
+        const float wv = weight[c];
+        const float gwt = wv > 0.f ? ey_f * norm : (wv < 0.f ? -ey_f * norm : 0.f);
+        dweight[c] = accumulate ? dweight[c] + gwt : gwt;
+      }
+      if (dbias != nullptr) dbias[c] = accumulate ? dbias[c] + e_f * norm : e_f * norm;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(gens + cb, gen_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s) ? 1u : 0u;
+    __syncthreads();
+    good = ticket_s != 0u;
+  }
+  const f32x4 e4 = load_wt16(edz + col), ey4 = load_wt16(eydz + col);
+  float e[4], ey[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e[k] = good ? e4[k] : __builtin_nanf("");
+    ey[k] = ey4[k];
+  }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = r0 + u * g.rpp;
+    if (u < nr && r < nrows) {
+      const int o = (r << (g.log2C4 + 2)) + col;
+      float4 D;
+      D.x = (DZ[u].x - e[0] - Y[u].x * ey[0]) * mul[0];
+      D.y = (DZ[u].y - e[1] - Y[u].y * ey[1]) * mul[1];
+      D.z = (DZ[u].z - e[2] - Y[u].z * ey[2]) * mul[2];
+      D.w = (DZ[u].w - e[3] - Y[u].w * ey[3]) * mul[3];
+      *reinterpret_cast<float4 *>(dx + o) = D;
+      if (WRITE_RES) *reinterpret_cast<float4 *>(dres + o) = DZ[u];
+    }
+  }
+}
+
 constexpr int kStatsU = 8, kGrad0U = 8, kGrad1U = 4;
 
 // Rows in flight per thread and trip (U): the tuned maximum for large tensors; halved while the launch would leave
@@ -1456,6 +1749,73 @@ static int launch_apply_nhwc_train(int act, const float *x, const float *res, fl
     default:
       return 0;
   }
+  return ok();
+}
+
+// SKD_ABN_FUSED=0 keeps the two-launch passes (A/B switch); default: the register-resident one-launch passes when they fit
+static bool fused_enabled() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("SKD_ABN_FUSED");
+    mode = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  return mode == 1;
+}
+constexpr int kFuseFwdMaxNR = 18, kFuseBwdMaxNR = 10;
+
+// returns -1 when the call does not take the fused path (not enabled, activation / size not covered), else ok()
+template <bool HAS_RES>
+static int launch_fwd_fused(int act, int64_t rows, int C, const float *x, const float *res, float *out, float *mean,
+                            float *var, float *running_mean, float *running_var, const float *weight, const float *bias,
+                            float momentum, float eps, float slope, float *workspace, hipStream_t st) {
+  if (!fused_enabled() || act == SKD_ACT_ELU || (HAS_RES && act != SKD_ACT_RELU)) return -1;
+  FuseGeom f;
+  if (!make_fuse_geom(rows, C, kFuseFwdMaxNR, f)) return -1;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  const dim3 grid((unsigned)(f.r.RG * f.r.CB)), block(kRedThreads);
+#define SKD_FWD_FUSED(ACT_, NR_)                                                                                         \
+  abn_fwd_fused_nhwc_kernel<ACT_, HAS_RES, NR_><<<grid, block, 0, st>>>(x, res, out, workspace, cnt, red_gens(cnt), mean, var, \
+                                                                        running_mean, running_var, weight, bias, rows, f.r, \
+                                                                        f.nr, momentum, eps, slope)
+#define SKD_FWD_FUSED_NR(ACT_)                 \
+  if (f.nr <= 6) SKD_FWD_FUSED(ACT_, 6);       \
+  else if (f.nr <= 10) SKD_FWD_FUSED(ACT_, 10); \
+  else SKD_FWD_FUSED(ACT_, 18)
+  if (act == SKD_ACT_RELU) {
+    SKD_FWD_FUSED_NR(SKD_ACT_RELU);
+  } else if (!HAS_RES && act == SKD_ACT_LEAKY_RELU) {
+    SKD_FWD_FUSED_NR(SKD_ACT_LEAKY_RELU);
+  } else if (!HAS_RES && act == SKD_ACT_NONE) {
+    SKD_FWD_FUSED_NR(SKD_ACT_NONE);
+  } else {
+    return -1;
+  }
+#undef SKD_FWD_FUSED_NR
+#undef SKD_FWD_FUSED
+  return ok();
+}
+
+// MODE 0: (z, dz) of the in-place ABN; MODE 1: (x, out, dout); MODE 2: (x, dout).  -1 = not taken.
+template <int ACT, int MODE, bool WRITE_RES>
+static int launch_bwd_fused(int64_t rows, int C, const float *a, const float *b, const float *c, const float *mean,
+                            const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                            float *dres, float *dweight, float *dbias, float eps, float slope, int accumulate,
+                            float *workspace, hipStream_t st) {
+  if (!fused_enabled()) return -1;
+  FuseGeom f;
+  if (!make_fuse_geom(rows, C, kFuseBwdMaxNR, f)) return -1;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  const dim3 grid((unsigned)(f.r.RG * f.r.CB)), block(kRedThreads);
+  if (f.nr <= 6)
+    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 6><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
+                                                                               red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
+                                                                               eps, slope, rows, f.r, f.nr, accumulate);
+  else
+    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 10><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
+                                                                                red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
+                                                                                eps, slope, rows, f.r, f.nr, accumulate);
   return ok();
 }
 
@@ -1747,6 +2107,13 @@ int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float 
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !mean || !var || !workspace) return 0;
   if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual))) return 0;
   hipStream_t st = as_stream(stream);
+  if (aligned16(mean) && aligned16(var)) {
+    const int r = residual ? launch_fwd_fused<true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                    weight, bias, momentum, eps, slope, workspace, st)
+                           : launch_fwd_fused<false>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                     weight, bias, momentum, eps, slope, workspace, st);
+    if (r >= 0) return r;
+  }
   if (!launch_stats_nhwc2(rows, C, x, mean, var, running_mean, running_var, momentum, workspace, st)) return 0;
   return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
                   : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
@@ -1864,6 +2231,62 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
   else
     abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g, accumulate);
   return ok();
+}
+
+// One-call channels-last backward (reduce + dx): ONE register-resident launch when the tensor fits (see "one launch with the
+// tensor held in registers" above), the two launches of the entries above otherwise.  edz / eydz are outputs as well
+// (functions.py:139-150 keeps them for the cross-replica path, which calls the two entries separately around its exchange).
+int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                          const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias, float eps,
+                          int activation, float slope, int accumulate, float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !z || !dz || !var || !edz || !eydz || !dx || !workspace) return 0;
+  if (!aligned16(z) || !aligned16(dz) || !aligned16(dx) || activation == SKD_ACT_RELU || (dweight && !weight)) return 0;
+  hipStream_t st = as_stream(stream);
+  if (aligned16(edz) && aligned16(eydz) && activation != SKD_ACT_ELU) {
+    const int r = activation == SKD_ACT_LEAKY_RELU
+                      ? launch_bwd_fused<SKD_ACT_LEAKY_RELU, 0, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx,
+                                                                        nullptr, dweight, dbias, eps, slope, accumulate, workspace, st)
+                      : launch_bwd_fused<SKD_ACT_NONE, 0, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx,
+                                                                  nullptr, dweight, dbias, eps, slope, accumulate, workspace, st);
+    if (r >= 0) return r;
+  }
+  if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, activation, slope, workspace, stream)) return 0;
+  return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, activation, slope,
+                                  accumulate, stream);
+}
+
+// The same for the fused BN + ReLU (+ residual) op: out == NULL -> the mask is recomputed from x (forward without residual).
+int skd_abn_relu_backward_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
+                               const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                               float *dres, float *dweight, float *dbias, float eps, int accumulate, float *workspace,
+                               skd_stream_t stream) {
+  NhwcGeom g;
+  if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !dout || !mean || !var || !edz || !eydz || !dx || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(dout) || !aligned16(dx) || (out && !aligned16(out)) || (dres && !aligned16(dres)) || (dweight && !weight)) return 0;
+  if (out == nullptr && dres != nullptr) return 0;
+  hipStream_t st = as_stream(stream);
+  if (aligned16(edz) && aligned16(eydz)) {
+    int r;
+    if (out == nullptr)
+      r = launch_bwd_fused<SKD_ACT_NONE, 2, false>(rows, C, x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                   dbias, eps, 0.f, accumulate, workspace, st);
+    else if (dres != nullptr)
+      r = launch_bwd_fused<SKD_ACT_NONE, 1, true>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight, dbias,
+                                                  eps, 0.f, accumulate, workspace, st);
+    else
+      r = launch_bwd_fused<SKD_ACT_NONE, 1, false>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                   dbias, eps, 0.f, accumulate, workspace, st);
+    if (r >= 0) return r;
+  }
+  if (out == nullptr) {
+    if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, workspace, stream)) return 0;
+    return skd_abn_relu_backward_dx_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, accumulate,
+                                           stream);
+  }
+  if (!skd_abn_relu_backward_reduce_nhwc(rows, C, x, out, dout, mean, var, edz, eydz, eps, workspace, stream)) return 0;
+  return skd_abn_relu_backward_dx_nhwc(rows, C, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, accumulate,
+                                       stream);
 }
 
 // ---- legacy drop-in entries ---------------------------------------------------------------------

@@ -313,13 +313,21 @@ class _InPlaceABN(autograd.Function):
         # functions.py:146-147: inference-mode backward uses edz = eydz = 0 (training overwrites both)
         stat = z.new_empty((2, c)) if ctx.training else z.new_zeros((2, c))
         edz, eydz = stat[0], stat[1]
+        if dx is None and geo.nhwc:
+            dx = torch.empty_like(z)        # the channels-last dx entry always writes dx
+        if ctx.training and ctx.group is None and geo.nhwc:
+            # reduce + dx in one call: one register-resident launch when the tensor fits (csrc/abn.hip), else two
+            ws = geo.workspace(lib, z)
+            _lib.check(lib.skd_abn_backward_nhwc(geo.rows, c, z.data_ptr(), dz.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+                                                 _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), dx.data_ptr(),
+                                                 _lib.ptr(dweight), _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, 0,
+                                                 ws.data_ptr(), st), "skd_abn_backward_nhwc")
+            return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None, None
         if ctx.training:
             ws = geo.workspace(lib, z)
             geo.backward_reduce(lib, z, dz, weight, bias, edz, eydz, ctx.eps, ctx.act, ctx.slope, ws, st)
             if ctx.group is not None:
                 _sync_grad_stats(stat, ctx.group)
-        if dx is None and geo.nhwc:
-            dx = torch.empty_like(z)        # the channels-last dx entry always writes dx
         geo.backward_dx(lib, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, ctx.eps, ctx.act, ctx.slope, st)
         return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None, None
 
@@ -388,6 +396,13 @@ class _ABNRelu(autograd.Function):
         stat = x.new_empty((2, c))
         edz, eydz = stat[0], stat[1]
         ws = geo.workspace(lib, x)
+        if ctx.group is None and geo.nhwc:
+            _lib.check(lib.skd_abn_relu_backward_nhwc(geo.rows, c, x.data_ptr(), _lib.ptr(out), dout.data_ptr(), mean.data_ptr(),
+                                                      var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(),
+                                                      eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight),
+                                                      _lib.ptr(dbias), ctx.eps, 0, ws.data_ptr(), st),
+                       "skd_abn_relu_backward_nhwc")
+            return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
         geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st, weight=weight, bias=bias)
         if ctx.group is not None:
             _sync_grad_stats(stat, ctx.group)

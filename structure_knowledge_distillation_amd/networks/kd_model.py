@@ -142,13 +142,15 @@ class NetModel():
         torch.backends.cudnn.enabled = True          # MIOpen
         # SKD_DETERMINISTIC=1: run-to-run bit-reproducible steps.  Every hand-written kernel already is (fixed-order
         # reductions, no float atomics); what is not by default are MIOpen's fastest fp32 weight-gradient / backward-data
-        # solvers (split-K with atomic adds) and rocBLAS kernels with atomics.  The mode sets MIOpen's DETERMINISTIC
-        # convolution attribute (torch.backends.cudnn.deterministic) and PyTorch's deterministic-algorithms switch (which
-        # also puts rocBLAS into atomics-not-allowed mode); warn_only because a few stock backward ops have no
-        # deterministic variant and are not on this path.  Cost: DESIGN.md section 9 (profiles/r03*_determinism.json).
+        # solvers (split-K with atomic adds).  MIOpen's own DETERMINISTIC attribute (torch.backends.cudnn.deterministic)
+        # was measured first (gpurun_out r03a, tools/determinism_probe.py): with this find-db it falls back to solvers
+        # that take 9.2 s per step AND still differ between runs, so the mode routes every convolution through PyTorch's
+        # own im2col + rocBLAS path instead (cudnn disabled) with rocBLAS in atomics-not-allowed mode
+        # (torch.use_deterministic_algorithms; warn_only because a few stock backward ops have no deterministic variant
+        # and are not on this path).  Cost: DESIGN.md section 9 (profiles/r03*_determinism.json).
         self.deterministic = os.environ.get("SKD_DETERMINISTIC", "0") == "1"
         if self.deterministic:
-            torch.backends.cudnn.deterministic = True
+            torch.backends.cudnn.enabled = False
             torch.use_deterministic_algorithms(True, warn_only=True)
         student = Res_pspnet(BasicBlock, [2, 2, 2, 2], num_classes=args.classes_num)
         load_S_model(args, student, False)

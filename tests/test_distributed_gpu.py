@@ -147,7 +147,7 @@ def _sharded_oracle(outs):
     shards = [slice(r * _B, (r + 1) * _B) for r in range(2)]
     cfg = O.StepConfig(weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
     for name, dt in (("o64", torch.float64), ("o32", torch.float32)):
-        cast = lambda P: {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+        cast = lambda P: {k: (v.to(dt, copy=True) if v.is_floating_point() else v.clone()) for k, v in P.items()}   # copy: the step updates in place
         PS, PT, PD = cast(outs[0]["init"]), cast(outs[0]["teacher"]), cast(outs[0]["d_init"])
         _ORACLE[name] = O.distillation_step_sharded(PS, PT, PD, x.to(dt), y, cfg, shards, [alpha[sl].to(dt) for sl in shards])
         _ORACLE[name + "_after"] = (PS, PD)
@@ -208,7 +208,7 @@ def test_netmodel_ho_step_two_ranks_vs_sharded_oracle(d_stream, monkeypatch):
     for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
         acc = {}
         for r, sl in enumerate(orc["shards"]):
-            P = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in orc["d_init"].items()}
+            P = {k: (v.to(dt, copy=True) if v.is_floating_point() else v.clone()) for k, v in orc["d_init"].items()}
             pS, pT = outs[r]["logits"]
             loss, grads = O.discriminator_step(P, pS.to(dt), pT.to(dt), cfg, orc["alpha"][sl].to(dt))
             if name == "f64":

@@ -297,6 +297,61 @@ def test_abn_nhwc_training(hip, ref, rows, C, act):
     assert hip.skd_abn_nhwc_workspace_floats(100, 48) == 0     # not a power of two: caller must use NCHW
 
 
+@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 128), (8 * 129 * 129, 64), (8 * 65 * 65, 256), (8 * 65 * 65, 512), (2 * 33 * 33, 512),
+                                    (8 * 36, 128), (50, 4), (2, 128), (300000, 8), (4 * 256 * 256, 64)])
+def test_abn_nhwc_one_call_backward(hip, ref, rows, C):
+    """skd_abn_backward_nhwc / skd_abn_relu_backward_nhwc (reduce + dx in one call; ONE register-resident launch for the
+    sizes that fit, the last two shapes and C = 512 fall back to two launches) vs the C oracle and vs the two separate
+    entries: every output incl. edz / eydz, dres, written (not accumulated) dweight / dbias."""
+    g = torch.Generator().manual_seed(rows * 3 + C)
+    x = torch.randn(rows, C, generator=g) * 3 + torch.randn(1, C, generator=g) * 5
+    r, dz = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w[0], w[1] = 0.0, -abs(float(w[1]))
+    ws_r = torch.empty(max(1, ref.skd_abn_nhwc_workspace_floats(rows, C)))
+    ws_g = torch.empty(max(1, hip.skd_abn_nhwc_workspace_floats(rows, C)), device=DEV)
+    nan = lambda *shape: torch.full(shape, float("nan"), device=DEV)
+    # ---- in-place ABN (leaky): z from the oracle's forward ----
+    zr, mr, vr = x.clone(), torch.empty(C), torch.empty(C)
+    assert ref.skd_abn_forward_train_nhwc(rows, C, P(zr), None, P(zr), P(w), P(b), None, None, P(mr), P(vr), 0.1, 1e-5, 1, 0.01, P(ws_r), None)
+    st_r, dxr, dwr, dbr = torch.empty(2, C), torch.empty_like(x), torch.empty(C), torch.empty(C)
+    assert ref.skd_abn_backward_nhwc(rows, C, P(zr), P(dz), P(vr), P(w), P(b), P(st_r[0]), P(st_r[1]), P(dxr), P(dwr), P(dbr), 1e-5, 1, 0.01, 0, P(ws_r), None)
+    st_g, dxg, dwg, dbg = nan(2, C), nan(rows, C), nan(C), nan(C)
+    zg, dzg, vg, wg_, bg_ = gpu(zr), gpu(dz), gpu(vr), gpu(w), gpu(b)
+    assert hip.skd_abn_backward_nhwc(rows, C, P(zg), P(dzg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(dwg), P(dbg), 1e-5, 1, 0.01, 0, P(ws_g), None)
+    mul = float(((w.abs() + 1e-5) / torch.sqrt(vr + 1e-5)).max())
+    close(st_g[0], st_r[0], 5e-5, "edz"); close(st_g[1], st_r[1], 5e-5, "eydz", floor=float(st_r[1].abs().max()) * 1e-1)
+    close(dxg, dxr, 1e-4, "dx", floor=float(dz.abs().max()) * mul)
+    close(dwg, dwr, 5e-5, "dweight", floor=float(dwr.abs().max()) * 1e-2 + 1e-6); close(dbg, dbr, 5e-5, "dbias", floor=float(dbr.abs().max()) * 1e-2 + 1e-6)
+    assert torch.equal(zg.cpu(), zr) and torch.equal(dzg.cpu(), dz)               # inputs untouched
+    # the two separate entries on the same inputs: same maths, another summation order
+    e2, ey2, dx2, dw2, db2 = nan(C), nan(C), nan(rows, C), nan(C), nan(C)
+    assert hip.skd_abn_backward_reduce_nhwc(rows, C, P(zg), P(dzg), P(wg_), P(bg_), P(e2), P(ey2), 1e-5, 1, 0.01, P(ws_g), None)
+    assert hip.skd_abn_backward_dx_nhwc(rows, C, P(zg), P(dzg), P(vg), P(wg_), P(bg_), P(e2), P(ey2), P(dx2), P(dw2), P(db2), 1e-5, 1, 0.01, 0, None)
+    close(st_g[0], e2, 2e-5, "edz vs two launches", floor=1e-3); close(dxg, dx2, 2e-5, "dx vs two launches", floor=float(dz.abs().max()) * mul)
+    # accumulate = 1 adds to dweight / dbias
+    dwa, dba = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    assert hip.skd_abn_backward_nhwc(rows, C, P(zg), P(dzg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(dwa), P(dba), 1e-5, 1, 0.01, 1, P(ws_g), None)
+    assert torch.equal(dwa, dwg + 1.0) and torch.equal(dba, dbg + 1.0)
+    # ---- fused BN -> (+ residual) -> ReLU ----
+    for res in (None, r):
+        outr = torch.empty_like(x)
+        assert ref.skd_abn_forward_train_nhwc(rows, C, P(x), P(res), P(outr), P(w), P(b), None, None, P(mr), P(vr), 0.1, 1e-5, 3, 0.0, P(ws_r), None)
+        xg, outg, mg, vg = gpu(x), gpu(outr), gpu(mr), gpu(vr)
+        for out_r, out_g in ((outr, outg),) + (((None, None),) if res is None else ()):
+            drr = torch.empty_like(x) if res is not None else None
+            drg = nan(rows, C) if res is not None else None
+            assert ref.skd_abn_relu_backward_nhwc(rows, C, P(x), P(out_r), P(dz), P(mr), P(vr), P(w), P(b), P(st_r[0]), P(st_r[1]), P(dxr), P(drr), P(dwr), P(dbr), 1e-5, 0, P(ws_r), None)
+            st_g, dxg, dwg, dbg = nan(2, C), nan(rows, C), nan(C), nan(C)
+            assert hip.skd_abn_relu_backward_nhwc(rows, C, P(xg), P(out_g), P(dzg), P(mg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(drg), P(dwg), P(dbg), 1e-5, 0, P(ws_g), None)
+            close(st_g[0], st_r[0], 5e-5, "relu edz"); close(st_g[1], st_r[1], 5e-5, "relu eydz")
+            close(dxg, dxr, 1e-4, "relu dx", floor=float(dz.abs().max()) * mul)
+            close(dwg, dwr, 5e-5, "relu dweight", floor=float(dwr.abs().max()) * 1e-2 + 1e-6); close(dbg, dbr, 5e-5, "relu dbias", floor=float(dbr.abs().max()) * 1e-2 + 1e-6)
+            if res is not None:
+                assert torch.equal(drg.cpu(), drr)
+    assert hip.skd_abn_relu_backward_nhwc(rows, C, P(xg), None, P(dzg), P(mg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(dxg), P(dwg), P(dbg), 1e-5, 0, P(ws_g), None) == 0
+
+
 def test_abn_single_sample_running_var_is_finite(hip):
     """One sample per channel (PSP 1x1 stage at batch 1, one replica): the reference's n / (n - 1) poisons
     running_var with NaN; here the biased variance (0) is kept -- DESIGN.md section 7."""

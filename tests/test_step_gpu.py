@@ -336,6 +336,12 @@ def _check_grads(got, recs, what, bound=GRAD_BOUND, floor=GRAD_FLOOR):
     _report(what, rows, bound, floor)
 
 
+# The critic step with its convolutions on PyTorch's im2col + rocBLAS path: measured 4e-5 ... 1.0e-4 of |g| on the weight
+# gradients (gpurun_out r03a; tools/d_step_error_probe.py splits it by source), 50x under GRAD_FLOOR.  The WGAN-GP term
+# differentiates (|grad| - 1)^2, a cancellation that amplifies fp32 rounding of the GPU's blocked summation order.
+IM2COL_D_FLOOR = 3e-4
+
+
 def test_full_step_b8_vs_golden():
     """BASELINE configs[2] exactly as bench.py runs it -- batch 8, 512x512, Pi + Pa + Ho (wgan-gp) -- one step against
     tests/golden/step_b8_oracle.pt (CPU oracle in fp64 and fp32; generator tests/golden/make_golden_step_b8.py)."""
@@ -412,7 +418,7 @@ def test_full_step_b8_vs_golden():
     g2 = {k: p.grad for k, p in D2.named_parameters() if p.grad is not None}
     _report("B=8 discriminator step, convolutions on the im2col + rocBLAS path",
             [(k, float((g2[k].cpu().double() - g).norm()), float((ref["f32"][1][k].double() - g).norm()), float(g.norm()))
-             for k, g in ref["f64"][1].items() if g is not None and float(g.norm()) > 1e-12], GRAD_BOUND, 1e-5)
+             for k, g in ref["f64"][1].items() if g is not None and float(g.norm()) > 1e-12], GRAD_BOUND, IM2COL_D_FLOOR)
     _check_grads(gD, gold["grads_D"], "B=8 discriminator gradients end to end (informative bound)", bound=10.0, floor=2e-2)
     after = model.student.state_dict()
     for k, rec in gold["running"].items():
@@ -427,7 +433,7 @@ DET_GRAD_FLOOR = 5e-4
 
 
 def test_full_step_b8_deterministic_mode_bit_equal_and_tight_bound(monkeypatch):
-    """SKD_DETERMINISTIC=1 (MIOpen's deterministic convolution attribute + rocBLAS without atomics): the SAME batch-8 step
+    """SKD_DETERMINISTIC=1 (convolutions on PyTorch's im2col + rocBLAS path, rocBLAS without atomics): the SAME batch-8 step
     executed twice from the same state gives bit-identical losses and gradients (student and discriminator), and -- with
     the split-K atomics noise gone -- every student gradient tensor meets the ONE bound with a floor of 5e-4 instead of
     5e-3.  The cost of the mode is measured by tools/determinism_probe.py (profiles/)."""
@@ -442,7 +448,7 @@ def test_full_step_b8_deterministic_mode_bit_equal_and_tight_bound(monkeypatch):
         PS, PT, PD = gen.init(torch.float32)
         args = default_args(batch_size=B, device=DEV, weight_decay=gold["cfg"]["weight_decay"], lambda_pa=gold["cfg"]["lambda_pa"])
         model = NetModel(args)
-        assert model.deterministic and torch.backends.cudnn.deterministic
+        assert model.deterministic and not torch.backends.cudnn.enabled
         no_dropout(model.student)
         images, labels = O.synthetic_batch(B, H, W, seed=gold["seeds"]["batch"])
         alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(gold["seeds"]["alpha"]))
@@ -466,7 +472,7 @@ def test_full_step_b8_deterministic_mode_bit_equal_and_tight_bound(monkeypatch):
             assert abs(got - want) <= 1e-4 * abs(want), (k, got, want)
         _check_grads(runs[0][0], gold["grads_S"], "B=8 student gradients, deterministic mode", bound=GRAD_BOUND, floor=DET_GRAD_FLOOR)
     finally:
-        torch.backends.cudnn.deterministic = False
+        torch.backends.cudnn.enabled = True
         torch.use_deterministic_algorithms(False)
 
 

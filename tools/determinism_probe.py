@@ -20,7 +20,7 @@ def run_mode(det, B):
     import torch
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     os.environ["SKD_DETERMINISTIC"] = "1" if det else "0"
-    torch.backends.cudnn.deterministic = False
+    torch.backends.cudnn.enabled = True
     torch.use_deterministic_algorithms(False)
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
@@ -73,7 +73,7 @@ def run_mode(det, B):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 6 * 1e3
     msgs = sorted({str(w.message)[:160] for w in wlist if "deterministic" in str(w.message).lower()})
-    torch.backends.cudnn.deterministic = False
+    torch.backends.cudnn.enabled = True
     torch.use_deterministic_algorithms(False)
     return {"mode": "deterministic" if det else "default", "batch": B, "ms_per_step": round(ms, 2),
             "images_per_s": round(B / ms * 1e3, 2), "tensors": len(runs[0][0]), "tensors_differing_between_runs": len(differing),

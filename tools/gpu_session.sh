@@ -138,6 +138,19 @@ EOF
     bench_tstream)
       (SKD_TEACHER_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_tstream.json 2>> $O/bench_tstream.err
       stamp "bench_tstream rc=$?"; cut -c1-260 $O/bench_tstream.json | tee -a $O/session.log ;;
+    dstep)
+      timeout 300 python tools/d_step_error_probe.py 8 > $O/d_step_error.jsonl 2> $O/d_step_error.err
+      stamp "dstep rc=$?"; cut -c1-420 $O/d_step_error.jsonl | tee -a $O/session.log ;;
+    fused_ab)
+      for v in "SKD_ABN_FUSED=1" "SKD_ABN_FUSED=0"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
+        stamp "fused_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
+    tests_r3)
+      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py tests/test_distributed_gpu.py -m gpu -q --tb=short -s \
+        -k "nhwc or pairwise or b8 or config1 or two_ranks or full_step or d_stream" > $O/pytest_r3.log 2>&1
+      stamp "tests_r3 rc=$?"; grep -E "passed|failed|error" $O/pytest_r3.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED" $O/pytest_r3.log | cut -c1-300 | head -40 | tee -a $O/session.log ;;
     det)
       timeout 400 python tools/determinism_probe.py 8 > $O/determinism.jsonl 2> $O/determinism.err
       stamp "det rc=$?"; cut -c1-700 $O/determinism.jsonl | tee -a $O/session.log ;;

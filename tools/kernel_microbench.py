@@ -64,6 +64,14 @@ def build_cases(lib, torch, dev, st):
             lib.skd_abn_relu_backward_dx_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(e), p(ey), p(dx), None, p(dw), p(db), 1e-5, 0, st), 16 * n)
         add("relu_backward_dx_nhwc(+dres)", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, e=e, ey=ey, dx=dx, dres=dres, dw=dw, db=db, rows=rows, C=C:
             lib.skd_abn_relu_backward_dx_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(e), p(ey), p(dx), p(dres), p(dw), p(db), 1e-5, 0, st), 20 * n)
+        # reduce + dx in one call (one register-resident launch when the tensor fits): bytes = the two-pass algorithmic figure,
+        # so the GB/s are "equivalent" rates comparable with the separate entries above
+        add("backward_nhwc(leaky, one call)", sh, lambda x=x, dz=dz, v=rv, w=w, b=b, e=e, ey=ey, dx=dx, dw=dw, db=db, ws=ws, rows=rows, C=C:
+            lib.skd_abn_backward_nhwc(rows, C, p(x), p(dz), p(v), p(w), p(b), p(e), p(ey), p(dx), p(dw), p(db), 1e-5, 1, 0.01, 0, p(ws), st), 20 * n)
+        add("relu_backward_nhwc(mask from x, one call)", sh, lambda x=x, dz=dz, m=rm, v=rv, w=w, b=b, e=e, ey=ey, dx=dx, dw=dw, db=db, ws=ws, rows=rows, C=C:
+            lib.skd_abn_relu_backward_nhwc(rows, C, p(x), None, p(dz), p(m), p(v), p(w), p(b), p(e), p(ey), p(dx), None, p(dw), p(db), 1e-5, 0, p(ws), st), 20 * n)
+        add("relu_backward_nhwc(+dres, one call)", sh, lambda x=x, out=out, dz=dz, m=rm, v=rv, w=w, b=b, e=e, ey=ey, dx=dx, dres=dres, dw=dw, db=db, ws=ws, rows=rows, C=C:
+            lib.skd_abn_relu_backward_nhwc(rows, C, p(x), p(out), p(dz), p(m), p(v), p(w), p(b), p(e), p(ey), p(dx), p(dres), p(dw), p(db), 1e-5, 0, p(ws), st), 32 * n)
     for rows, C in TEACHER:
         n = rows * C
         x, r = torch.randn(rows, C, device=dev), torch.randn(rows, C, device=dev)
