@@ -375,13 +375,22 @@ int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, fl
  *       out[m][n] = act( ((sum_k x[m][k] * w[n][k] - mean[n]) * invstd[n]) * (|weight[n]| + eps) + bias[n] [+ residual[m][n]] )
  *     x (M, K) = (B*H*W, Cin); w (N, K) = the (Cout, Cin, 1, 1) convolution weight; residual / out (M, N); mean / var =
  *     the running statistics; weight / bias may be NULL (gamma 1, beta 0); activation: SKD_ACT_NONE / RELU / LEAKY_RELU.
- *     skd_conv1x1_abn_supported(): K % 64 == 0 and N % 128 == 0 (every stride-1 1x1 convolution of the ResNet101
+ *     skd_conv1x1_abn_supported(): K % 32 == 0 and N % 128 == 0 (every stride-1 1x1 convolution of the ResNet101
  *     teacher except the two with 64 output channels); other problems stay on convolution + skd_abn_apply_nhwc.
+ *     skd_conv1x1_abn_pro_nhwc (round 3): the same GEMM with the PRECEDING eval-mode BatchNorm + ReLU applied to x on its
+ *     way into LDS -- x[m][k] <- relu(((x[m][k] - pmean[k]) * invstd(pvar[k], peps)) * (|pweight[k]| + peps) + pbias[k]) --
+ *     so that for a bottleneck tail conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu (pspnet_combine.py:71-82)
+ *     x is the raw 3x3-convolution output and neither ABN pass exists.  pmean / pvar: K floats, 16-byte aligned, required;
+ *     pweight / pbias may be NULL.
  * ---------------------------------------------------------------------------------- */
 int skd_conv1x1_abn_supported(int64_t M, int K, int N);
 int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                          const float *mean, const float *var, const float *weight, const float *bias, float eps,
                          int activation, float slope, skd_stream_t stream);
+int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                             const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                             const float *pmean, const float *pvar, const float *pweight, const float *pbias, float peps,
+                             int activation, float slope, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210

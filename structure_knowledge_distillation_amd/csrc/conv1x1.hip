@@ -31,46 +31,84 @@ constexpr size_t kConvLds = sizeof(float) * 2 * kStageFloats;
 
 __device__ __forceinline__ float inv_std_of(float var, float eps) { return (var != 0.f || eps != 0.f) ? 1.f / sqrtf(var + eps) : 0.f; }
 
-// Staging registers are plain float4 variables handled by macros: two named sets (a*, b* suffix 0 / 1) that ping-pong.
-// (Held in a struct passed by reference they ended up in scratch memory once two sets were live across the loop.)
-// thread t -> row t/8 (+32h), float4 t%8 of the K-tile.  Rows beyond the matrix are clamped (never stored).
-#define SKD_GLOAD(S, k0)                                                                          \
-  do {                                                                                            \
-    const float *xa = X + (k0) + gkq, *wb = Wt + (k0) + gkq;                                       \
-    xa0##S = *reinterpret_cast<const float4 *>(xa + grow0);                                        \
-    xa1##S = *reinterpret_cast<const float4 *>(xa + grow1);                                        \
-    xa2##S = *reinterpret_cast<const float4 *>(xa + grow2);                                        \
-    xa3##S = *reinterpret_cast<const float4 *>(xa + grow3);                                        \
-    wb0##S = *reinterpret_cast<const float4 *>(wb + wrow0);                                        \
-    wb1##S = *reinterpret_cast<const float4 *>(wb + wrow0 + 32 * (int64_t)K);                      \
-    wb2##S = *reinterpret_cast<const float4 *>(wb + wrow0 + 64 * (int64_t)K);                      \
-    wb3##S = *reinterpret_cast<const float4 *>(wb + wrow0 + 96 * (int64_t)K);                      \
-  } while (0)
-#define SKD_SSTORE(S, stage)                                                                      \
-  do {                                                                                            \
-    float *sa = (stage) + srow, *sb = (stage) + kTM * kLDK + srow;                                 \
-    *reinterpret_cast<float4 *>(sa) = xa0##S;                                                      \
-    *reinterpret_cast<float4 *>(sa + 32 * kLDK) = xa1##S;                                          \
-    *reinterpret_cast<float4 *>(sa + 64 * kLDK) = xa2##S;                                          \
-    *reinterpret_cast<float4 *>(sa + 96 * kLDK) = xa3##S;                                          \
-    *reinterpret_cast<float4 *>(sb) = wb0##S;                                                      \
-    *reinterpret_cast<float4 *>(sb + 32 * kLDK) = wb1##S;                                          \
-    *reinterpret_cast<float4 *>(sb + 64 * kLDK) = wb2##S;                                          \
-    *reinterpret_cast<float4 *>(sb + 96 * kLDK) = wb3##S;                                          \
-  } while (0)
+// Per K-tile a thread moves four float4 of the A panel (rows t/8 + 32h, k quad t%8) and four of the B panel from global memory
+// to LDS.  The loads are issued at the top of a trip, the LDS stores after the trip's MFMAs (a whole K-tile of matrix-pipe
+// time for them to land), the staging registers are not loop-carried (nothing for the compiler to copy).
+struct Staging {
+  float4 a[4], b[4];
+};
+struct ProParams {         // PRO: the k quad's mean / var / weight / bias of the BatchNorm applied to A on the way in
+  float4 pm, pv, pw, pb;   // (kept apart from Staging: a struct with members that one instantiation never writes stayed in scratch)
+};
 
+template <bool PRO>
+__device__ __forceinline__ void stage_load(Staging &s, ProParams &pp, const float *__restrict__ X, const float *__restrict__ Wt, int k0,
+                                           int gkq, const int64_t (&arow)[4], int64_t wrow0, int K,
+                                           const float *__restrict__ pmean, const float *__restrict__ pvar,
+                                           const float *__restrict__ pweight, const float *__restrict__ pbias) {
+  const float *xa = X + k0 + gkq, *wb = Wt + k0 + gkq;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) s.a[h] = *reinterpret_cast<const float4 *>(xa + arow[h]);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) s.b[h] = *reinterpret_cast<const float4 *>(wb + wrow0 + (int64_t)(32 * h) * K);
+  if (PRO) {
+    pp.pm = *reinterpret_cast<const float4 *>(pmean + k0 + gkq);
+    pp.pv = *reinterpret_cast<const float4 *>(pvar + k0 + gkq);
+    pp.pw = pweight != nullptr ? *reinterpret_cast<const float4 *>(pweight + k0 + gkq) : make_float4(1.f, 1.f, 1.f, 1.f);
+    pp.pb = pbias != nullptr ? *reinterpret_cast<const float4 *>(pbias + k0 + gkq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// relu(bn(x)) with the expression of abn_apply (bn.cu:146-159 + ReLU): ((x - mean) * invstd) * gamma + beta
+__device__ __forceinline__ float pro_one(float x, float m, float is, float g, float b) {
+  const float z = __builtin_fmaf((x - m) * is, g, b);
+  return z < 0.f ? 0.f : z;
+}
+
+template <bool PRO>
+__device__ __forceinline__ void stage_store(const Staging s, const ProParams pp, float *stage, int srow, float peps, bool has_pw) {
+  float *sa = stage + srow, *sb = stage + kTM * kLDK + srow;
+  if (PRO) {
+    const float i0 = inv_std_of(pp.pv.x, peps), i1 = inv_std_of(pp.pv.y, peps), i2 = inv_std_of(pp.pv.z, peps), i3 = inv_std_of(pp.pv.w, peps);
+    const float g0 = has_pw ? fabsf(pp.pw.x) + peps : 1.f, g1 = has_pw ? fabsf(pp.pw.y) + peps : 1.f;
+    const float g2 = has_pw ? fabsf(pp.pw.z) + peps : 1.f, g3 = has_pw ? fabsf(pp.pw.w) + peps : 1.f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float4 v = s.a[h];
+      v.x = pro_one(v.x, pp.pm.x, i0, g0, pp.pb.x);
+      v.y = pro_one(v.y, pp.pm.y, i1, g1, pp.pb.y);
+      v.z = pro_one(v.z, pp.pm.z, i2, g2, pp.pb.z);
+      v.w = pro_one(v.w, pp.pm.w, i3, g3, pp.pb.w);
+      *reinterpret_cast<float4 *>(sa + 32 * h * kLDK) = v;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(sa + 32 * h * kLDK) = s.a[h];
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(sb + 32 * h * kLDK) = s.b[h];
+}
+
+// One K-tile out of LDS: per group of 8 k four conflict-free ds_read_b128 (a0, a1, b0, b1: FOUR consecutive k of the lane's
+// row) feed sixteen MFMAs; the reads of group g + 1 are issued before the MFMAs of group g (software pipelining in registers).
 __device__ __forceinline__ void tile_mma(const float *stage, f32x16 (&acc)[2][2]) {
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
   const int half = lane >> 5, r = lane & 31;
   const float *pa = stage + (wi + r) * kLDK + half * 4;
   const float *pb = stage + (kTM + wj + r) * kLDK + half * 4;
+  float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 32 * kLDK);
+  float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the four reads of group 0 (the pipeline below is matched in order)
 #pragma unroll
   for (int g = 0; g < kBK / 8; ++g) {
-    const float4 a0 = *reinterpret_cast<const float4 *>(pa + g * 8);
-    const float4 a1 = *reinterpret_cast<const float4 *>(pa + 32 * kLDK + g * 8);
-    const float4 b0 = *reinterpret_cast<const float4 *>(pb + g * 8);
-    const float4 b1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK + g * 8);
+    float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+    if (g + 1 < kBK / 8) {
+      na0 = *reinterpret_cast<const float4 *>(pa + (g + 1) * 8);
+      na1 = *reinterpret_cast<const float4 *>(pa + 32 * kLDK + (g + 1) * 8);
+      nb0 = *reinterpret_cast<const float4 *>(pb + (g + 1) * 8);
+      nb1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK + (g + 1) * 8);
+    }
     const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
     const float B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -80,15 +118,49 @@ __device__ __forceinline__ void tile_mma(const float *stage, f32x16 (&acc)[2][2]
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B0[t], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B1[t], acc[1][1], 0, 0, 0);
     }
+    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    // pin the issue order (left alone the scheduler sinks the reads to just before their first use and every group starts
+    // with an exposed LDS round trip): 4 MFMAs, the next group's four reads, the other 12 MFMAs (768 matrix-pipe cycles cover them)
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (g + 1 < kBK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
   }
 }
 
-template <int ACT, bool HAS_RES>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1x1_abn_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
-                                                                  const float *__restrict__ R, float *__restrict__ Y,
-                                                                  const float *__restrict__ mean, const float *__restrict__ var,
-                                                                  const float *__restrict__ weight, const float *__restrict__ bias,
-                                                                  float eps, float slope, int64_t M, int K, int N, int tiles_n) {
+// Epilogue of one 32 x 32 accumulator block: rows row0 + frag_row(q), column col.  FULL: every row of the tile exists (all
+// but the last row tile) -- no per-element branches, and the sixteen residual loads are issued together before the first
+// use (round 2 interleaved load -> wait -> store per element behind a branch: 64 serialised HBM round trips per lane).
+template <int ACT, bool HAS_RES, bool FULL>
+__device__ __forceinline__ void store_block(const f32x16 &acc, const float *__restrict__ R, float *__restrict__ Y, int64_t row0,
+                                            int col, int64_t M, int N, float mu, float is, float ga, float be, float slope) {
+  const int lane = threadIdx.x & (kWave - 1);
+  float rv[16];
+  int64_t off[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    off[q] = row * N + col;
+    rv[q] = 0.f;
+    if (HAS_RES && (FULL || row < M)) rv[q] = R[off[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    float z = ((acc[q] - mu) * is) * ga + be;                 // bn.cu:158-159
+    if (HAS_RES) z += rv[q];
+    if (ACT == SKD_ACT_RELU) z = z < 0.f ? 0.f : z;
+    if (ACT == SKD_ACT_LEAKY_RELU) z = z < 0.f ? z * slope : z;
+    if (FULL || row < M) Y[off[q]] = z;
+  }
+}
+
+template <int ACT, bool HAS_RES, bool PRO>
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_abn_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
+    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
+    const float *__restrict__ bias, const float *__restrict__ pmean, const float *__restrict__ pvar,
+    const float *__restrict__ pweight, const float *__restrict__ pbias, float peps, float eps, float slope, int64_t M, int K,
+    int N, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // consecutive workgroups walk the N tiles of one row panel: the 128 x K activation panel is read from HBM once and
   // re-used out of L2 by its tiles_n neighbours; the (N, K) weights stay L2-resident throughout
@@ -104,36 +176,34 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
   const int nk = K / kBK;
-  // Software pipeline, two K-tiles deep, unrolled by two so that the two staging register sets ping-pong WITHOUT copies:
-  // while tile kt is multiplied out of one LDS stage, tile kt + 1 moves from its staging set into the other stage
-  // (its loads were issued a whole MFMA phase earlier) and the loads of tile kt + 2 are issued into the set that has
-  // just been drained.  (A single loop-carried staging set makes the compiler load into temporaries and copy them at
-  // the bottom of the trip -- an HBM-latency wait per K-tile; loads placed at the top of a trip are sunk to their use.)
-  // K is a multiple of 64; indices past the end are clamped to the last tile (loaded, never used).
   const int gt = threadIdx.x, grow = gt >> 3, gkq = (gt & 7) * 4;
   const int srow = grow * kLDK + gkq;
-  auto clampm = [&](int64_t m) { return (m > M - 1 ? M - 1 : m) * K; };
-  const int64_t grow0 = clampm(m0 + grow), grow1 = clampm(m0 + grow + 32), grow2 = clampm(m0 + grow + 64), grow3 = clampm(m0 + grow + 96);
+  int64_t arow[4];   // rows beyond the matrix are clamped (loaded, multiplied, never stored)
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int64_t m = m0 + grow + 32 * h;
+    arow[h] = (m > M - 1 ? M - 1 : m) * K;
+  }
   const int64_t wrow0 = (int64_t)(n0 + grow) * K;
-  float4 xa00, xa10, xa20, xa30, wb00, wb10, wb20, wb30;     // staging set 0
-  float4 xa01, xa11, xa21, xa31, wb01, wb11, wb21, wb31;     // staging set 1
-  SKD_GLOAD(0, 0);
-  SKD_SSTORE(0, lds);
-  SKD_GLOAD(1, kBK);
+  const bool has_pw = pweight != nullptr;
+  Staging st;
+  ProParams pp = {};
+  stage_load<PRO>(st, pp, X, Wt, 0, gkq, arow, wrow0, K, pmean, pvar, pweight, pbias);
+  stage_store<PRO>(st, pp, lds, srow, peps, has_pw);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    tile_mma(lds, acc);
-    SKD_SSTORE(1, lds + kStageFloats);                                          // tile kt + 1
-    SKD_GLOAD(0, (kt + 2 < nk ? kt + 2 : nk - 1) * kBK);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) stage_load<PRO>(st, pp, X, Wt, (kt + 1) * kBK, gkq, arow, wrow0, K, pmean, pvar, pweight, pbias);
+    tile_mma(lds + stage * kStageFloats, acc);
+    if (more) stage_store<PRO>(st, pp, lds + (stage ^ 1) * kStageFloats, srow, peps, has_pw);
     __syncthreads();
-    tile_mma(lds + kStageFloats, acc);
-    SKD_SSTORE(0, lds);                                                         // tile kt + 2
-    SKD_GLOAD(1, (kt + 3 < nk ? kt + 3 : nk - 1) * kBK);
-    __syncthreads();
+    stage ^= 1;
   }
   // ---- epilogue: the eval-mode InPlace-ABN formula on the accumulator (+ residual) + activation ----
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const bool full = m0 + kTM <= M;
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) {
     const int col = n0 + wj + bj * 32 + (lane & 31);
@@ -142,35 +212,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float be = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int64_t row = m0 + wi + bi * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < M) {
-          float z = ((acc[bi][bj][q] - mu) * is) * ga + be;                 // bn.cu:158-159
-          if (HAS_RES) z += R[row * N + col];
-          if (ACT == SKD_ACT_RELU) z = z < 0.f ? 0.f : z;
-          if (ACT == SKD_ACT_LEAKY_RELU) z = z < 0.f ? z * slope : z;
-          Y[row * N + col] = z;
-        }
-      }
+      const int64_t row0 = m0 + wi + bi * 32;
+      if (full)
+        store_block<ACT, HAS_RES, true>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
+      else
+        store_block<ACT, HAS_RES, false>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
     }
   }
 }
 
-template <int ACT, bool HAS_RES>
+template <int ACT, bool HAS_RES, bool PRO>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
-                  const float *weight, const float *bias, float eps, float slope, int64_t M, int K, int N, hipStream_t st) {
+                  const float *weight, const float *bias, const float *pmean, const float *pvar, const float *pweight,
+                  const float *pbias, float peps, float eps, float slope, int64_t M, int K, int N, hipStream_t st) {
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES, PRO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvLds) != hipSuccess) return 0;
     ready = true;
   }
   const int tiles_n = N / kTN;
   const int64_t tiles_m = cdiv(M, kTM);
   if (tiles_m * tiles_n > 2147483647) return 0;
-  conv1x1_abn_kernel<ACT, HAS_RES><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(kThreads), kConvLds, st>>>(
-      X, Wt, R, Y, mean, var, weight, bias, eps, slope, M, K, N, tiles_n);
+  conv1x1_abn_kernel<ACT, HAS_RES, PRO><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(kThreads), kConvLds, st>>>(
+      X, Wt, R, Y, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, tiles_n);
   return ok();
 }
 
@@ -181,19 +246,26 @@ using namespace skd;
 
 extern "C" {
 
-// 1 when the fused kernel takes the problem (K a multiple of 64, N a multiple of 128), 0 when the caller must run
+// 1 when the fused kernel takes the problem (K a multiple of 32, N a multiple of 128), 0 when the caller must run
 // the convolution and the ABN pass separately.
-int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % (2 * kBK) == 0 && N % kTN == 0; }
+int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % kBK == 0 && N % kTN == 0; }
 
-int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
-                         const float *mean, const float *var, const float *weight, const float *bias, float eps,
-                         int activation, float slope, skd_stream_t stream) {
+static int conv1x1_dispatch(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                            const float *mean, const float *var, const float *weight, const float *bias, const float *pmean,
+                            const float *pvar, const float *pweight, const float *pbias, float peps, float eps, int activation,
+                            float slope, skd_stream_t stream) {
   if (!skd_conv1x1_abn_supported(M, K, N) || !x || !w || !out || !mean || !var) return 0;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return 0;
   hipStream_t st = as_stream(stream);
-#define SKD_C11(A)                                                                                                       \
-  return residual ? launch<A, true>(x, w, residual, out, mean, var, weight, bias, eps, slope, M, K, N, st)               \
-                  : launch<A, false>(x, w, residual, out, mean, var, weight, bias, eps, slope, M, K, N, st)
+  const bool pro = pmean != nullptr;
+  if (pro && (!pvar || ((reinterpret_cast<uintptr_t>(pmean) | reinterpret_cast<uintptr_t>(pvar) | reinterpret_cast<uintptr_t>(pweight) |
+                         reinterpret_cast<uintptr_t>(pbias)) & 15))) return 0;
+#define SKD_C11(A)                                                                                                                       \
+  if (pro)                                                                                                                               \
+    return residual ? launch<A, true, true>(x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, st)  \
+                    : launch<A, false, true>(x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, st); \
+  return residual ? launch<A, true, false>(x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps, slope, M, K, N, st) \
+                  : launch<A, false, false>(x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps, slope, M, K, N, st)
   switch (activation) {
     case SKD_ACT_NONE: SKD_C11(SKD_ACT_NONE);
     case SKD_ACT_RELU: SKD_C11(SKD_ACT_RELU);
@@ -201,6 +273,27 @@ int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w
     default: return 0;
   }
 #undef SKD_C11
+}
+
+int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                         const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                         int activation, float slope, skd_stream_t stream) {
+  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps,
+                          activation, slope, stream);
+}
+
+// The same GEMM with the PRECEDING eval-mode BatchNorm + ReLU applied to x on the way into LDS:
+//   a[m][k] = relu(((x[m][k] - pmean[k]) * invstd(pvar[k])) * (|pweight[k]| + peps) + pbias[k])
+// (networks/pspnet_combine.py:71-75: conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu): x is the raw output of the
+// 3x3 convolution, neither ABN pass of the block tail exists any more.  pmean / pvar (K floats, 16-byte aligned) are required,
+// pweight / pbias may be NULL.
+int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
+                             const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                             const float *pmean, const float *pvar, const float *pweight, const float *pbias, float peps,
+                             int activation, float slope, skd_stream_t stream) {
+  if (!pmean || !pvar) return 0;
+  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, activation,
+                          slope, stream);
 }
 
 }  // extern "C"

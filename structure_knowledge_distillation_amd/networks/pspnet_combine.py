@@ -37,6 +37,14 @@ def _gemm_tail(x):
     return (os.environ.get("SKD_TEACHER_GEMM", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
 
 
+def _fused_tail(x):
+    """SKD_TEACHER_TAIL=1: the frozen bottleneck's tail conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> relu] as ONE
+    fp32-MFMA GEMM (csrc/conv1x1.hip, round 3): bn2 + ReLU applied to the raw 3x3-convolution output on its way into LDS,
+    bn3 + residual + ReLU in the epilogue -- both InPlace-ABN passes of the block tail (33 + 33 per teacher forward) disappear.
+    Measured A/B: profiles/r03*_tail*.json."""
+    return (os.environ.get("SKD_TEACHER_TAIL", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
+
+
 def _blas_tail(module, x):
     """Frozen network, fp32, SKD_TEACHER_BLAS != 0: the 1x1 reduce convolutions and stride-1 down-sample branches run as
     library GEMMs with the folded BN (+ ReLU) in the epilogue (functional.conv1x1_bn_blas)."""
@@ -101,7 +109,11 @@ class Bottleneck(nn.Module):
                 out = SF.conv1x1_bn_blas(x, self.conv1, self.bn1, relu=True)
             else:
                 out = self.bn1.forward_relu(self.conv1(x))
-            out = self.bn2.forward_relu(self.conv2(out))
+            c2 = self.conv2(out)
+            tail = (not self.training and _fused_tail(x) and SF.conv1x1_abn_supported(c2, self.conv3)
+                    and getattr(self.bn2, "activation", None) == "none" and getattr(self.bn3, "activation", None) == "none")
+            if not tail:
+                out = self.bn2.forward_relu(c2)
             if self.downsample is None:
                 residual = x
             elif (blas and len(self.downsample) == 2 and SF.blas_1x1_bn_supported(x, self.downsample[0])
@@ -109,6 +121,10 @@ class Bottleneck(nn.Module):
                 residual = SF.conv1x1_bn_blas(x, self.downsample[0], self.downsample[1], relu=False)
             else:
                 residual = self.downsample(x)
+            if tail:
+                return SF.conv1x1_abn_eval(c2, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
+                                           self.bn3.bias, self.bn3.eps, "relu", residual=residual,
+                                           pro=(self.bn2.running_mean, self.bn2.running_var, self.bn2.weight, self.bn2.bias, self.bn2.eps))
             if gemm and SF.conv1x1_abn_supported(out, self.conv3):
                 return SF.conv1x1_abn_eval(out, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
                                            self.bn3.bias, self.bn3.eps, "relu", residual=residual)

@@ -332,7 +332,7 @@ def test_abn_nhwc_one_call_backward(hip, ref, rows, C):
     # accumulate = 1 adds to dweight / dbias
     dwa, dba = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
     assert hip.skd_abn_backward_nhwc(rows, C, P(zg), P(dzg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(dwa), P(dba), 1e-5, 1, 0.01, 1, P(ws_g), None)
-    assert torch.equal(dwa, dwg + 1.0) and torch.equal(dba, dbg + 1.0)
+    close(dwa, dwg + 1.0, 1e-6, "accumulated dweight"); close(dba, dbg + 1.0, 1e-6, "accumulated dbias")     # (e * n + old may be one fma)
     # ---- fused BN -> (+ residual) -> ReLU ----
     for res in (None, r):
         outr = torch.empty_like(x)
@@ -876,8 +876,49 @@ def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
     assert ref.skd_conv1x1_abn_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, act, 0.01, None)
     assert hip.skd_conv1x1_abn_nhwc(M, K, N, P(gpu(x)), P(gpu(w)), P(gpu(r)), P(o_g), P(gpu(mean)), P(gpu(var)), P(gpu(ga)), P(gpu(be)), 1e-5, act, 0.01, None)
     close(o_g, o_r, 2e-5, "conv1x1+abn")
-    assert hip.skd_conv1x1_abn_supported(M, K, N) == 1 and hip.skd_conv1x1_abn_supported(M, K + 32, N) == 0 and hip.skd_conv1x1_abn_supported(M, K, N + 64) == 0
-    assert hip.skd_conv1x1_abn_nhwc(M, K + 32, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
+    assert hip.skd_conv1x1_abn_supported(M, K, N) == 1 and hip.skd_conv1x1_abn_supported(M, K + 16, N) == 0 and hip.skd_conv1x1_abn_supported(M, K, N + 64) == 0
+    assert hip.skd_conv1x1_abn_nhwc(M, K + 16, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 96, 256), (129, 512, 2048)])
+@pytest.mark.parametrize("with_res,affine", [(True, True), (False, True), (True, False)])
+def test_conv1x1_abn_gemm_with_bn_relu_prologue(hip, ref, M, K, N, with_res, affine):
+    """skd_conv1x1_abn_pro_nhwc: relu(bn_k(x)) applied to the GEMM's A operand on the way into LDS (the bottleneck tail
+    conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu, pspnet_combine.py:71-82) vs the C oracle, which
+    materialises the activated operand; x itself must stay untouched."""
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    x, w = torch.randn(M, K, generator=g) * 2, torch.randn(N, K, generator=g) / K ** 0.5
+    r = torch.randn(M, N, generator=g) if with_res else None
+    mean, var = torch.randn(N, generator=g) * 0.3, torch.rand(N, generator=g) + 0.5
+    ga, be = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    pm, pv = torch.randn(K, generator=g) * 0.5, torch.rand(K, generator=g) + 0.5
+    pw, pb = (torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.5) if affine else (None, None)
+    o_r, o_g = torch.empty(M, N), torch.full((M, N), 7.0, device=DEV)
+    assert ref.skd_conv1x1_abn_pro_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, P(pm), P(pv), P(pw), P(pb), 1e-5, 3, 0.01, None)
+    xg = gpu(x)
+    assert hip.skd_conv1x1_abn_pro_nhwc(M, K, N, P(xg), P(gpu(w)), P(gpu(r)), P(o_g), P(gpu(mean)), P(gpu(var)), P(gpu(ga)), P(gpu(be)), 1e-5,
+                                        P(gpu(pm)), P(gpu(pv)), P(gpu(pw)), P(gpu(pb)), 1e-5, 3, 0.01, None)
+    close(o_g, o_r, 3e-5, "bn+relu -> conv1x1 -> abn")
+    assert torch.equal(xg.cpu(), x)
+    assert hip.skd_conv1x1_abn_pro_nhwc(M, K, N, P(xg), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, None, None, None, None, 1e-5, 3, 0.01, None) == 0
+
+
+def test_teacher_bottleneck_fused_tail_equals_unfused(monkeypatch):
+    """SKD_TEACHER_TAIL=1 (conv2 -> ONE GEMM with bn2 + ReLU in its prologue and bn3 + residual + ReLU in its epilogue) gives the
+    frozen bottleneck's output of the default path (conv + in-place ABN passes) at the layer-3 shape."""
+    from structure_knowledge_distillation_amd.networks import pspnet_combine as PC
+    torch.manual_seed(3)
+    blk = PC.Bottleneck(1024, 256, stride=1, dilation=2).to(DEV).eval().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for bn in (blk.bn1, blk.bn2, blk.bn3):
+            bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.normal_(0, 1); bn.bias.normal_(0, 0.5)
+        x = torch.randn(2, 1024, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
+        monkeypatch.setenv("SKD_TEACHER_TAIL", "0")
+        want = blk(x.clone(memory_format=torch.channels_last))
+        monkeypatch.setenv("SKD_TEACHER_TAIL", "1")
+        got = blk(x.clone(memory_format=torch.channels_last))
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    close(got, want, 3e-5, "fused bottleneck tail")
 
 
 def test_conv1x1_abn_gemm_full_size_vs_conv2d():

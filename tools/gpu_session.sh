@@ -138,6 +138,28 @@ EOF
     bench_tstream)
       (SKD_TEACHER_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_tstream.json 2>> $O/bench_tstream.err
       stamp "bench_tstream rc=$?"; cut -c1-260 $O/bench_tstream.json | tee -a $O/session.log ;;
+    lab)
+      timeout 240 tools/gemm_lab time 10 > $O/gemm_lab.jsonl 2> $O/gemm_lab.err
+      stamp "lab rc=$?"; cut -c1-330 $O/gemm_lab.jsonl | tee -a $O/session.log ;;
+    lab_pmc)
+      i=0
+      for set in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+                 "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" \
+                 "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i+1))
+        (cd /tmp && timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/labpmc$i -o k -- $R/tools/gemm_lab pmc 2 > $O/labpmc$i.log 2>&1)
+        stamp "lab_pmc pass $i ($set) rc=$?"
+        find $O/labpmc$i -name "*kernel_trace.csv" -delete
+      done ;;
+    tail_ab)
+      for v in "SKD_TEACHER_TAIL=1" "SKD_TEACHER_TAIL=0"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
+        stamp "tail_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
+    tests_c11)
+      timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -s -k "conv1x1 or bottleneck or one_call" > $O/pytest_c11.log 2>&1
+      stamp "tests_c11 rc=$?"; grep -E "passed|failed|error" $O/pytest_c11.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED" $O/pytest_c11.log | cut -c1-300 | head -30 | tee -a $O/session.log ;;
     dstep)
       timeout 300 python tools/d_step_error_probe.py 8 > $O/d_step_error.jsonl 2> $O/d_step_error.err
       stamp "dstep rc=$?"; cut -c1-420 $O/d_step_error.jsonl | tee -a $O/session.log ;;
