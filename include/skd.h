@@ -393,6 +393,34 @@ int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const floa
                              int activation, float slope, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * 12. One-hop exchange of the cross-replica InPlace-ABN statistics (round 3): replaces libs/functions.py:185-205
+ *     (master / worker queues + comm.gather + comm.broadcast_coalesced of [mean, var]) and :263-280 ([edz, eydz]) --
+ *     and the torch.distributed all_gather / all_reduce this package used first -- by ONE small kernel per exchange
+ *     that stores this rank's vector straight into every peer's IPC-mapped mailbox (one xGMI hop), raises per-slot
+ *     sequence flags, waits for the peers' flags in its own mailbox and applies the combine rule in the same launch.
+ *       ctx = skd_sync_create(world, rank, handle_out)   allocates the rank's mailbox on the CURRENT device and writes
+ *             its IPC handle (skd_sync_handle_bytes() bytes) to handle_out; NULL on failure;
+ *       skd_sync_connect(ctx, all_handles)               all_handles = world x handle bytes in rank order (gathered by the
+ *             caller with whatever host-side transport it has, e.g. dist.all_gather_object); opens the peers' mailboxes;
+ *       the three exchanges are COLLECTIVES: every rank calls them in the same order, on any stream;
+ *       skd_sync_all_gather    gathered (world, n) <- every rank's n floats, n <= skd_sync_max_floats();
+ *       skd_abn_sync_stats     stat (2, C) = this replica's [mean | var] -> combined mean / var + running update: the
+ *                              arguments and the arithmetic of skd_abn_combine_stats (bit-identical on the same data);
+ *       skd_abn_sync_grad_stats stat (2, C) = [edz | eydz], in place <- sum_g w_g stat_g in rank order (w_g = weights[g],
+ *                              or 1 / world when weights == NULL).
+ *     A peer that does not arrive within 5 s poisons the outputs with NaN (no device hang).  world <= 16.
+ * ---------------------------------------------------------------------------------- */
+int skd_sync_handle_bytes(void);
+int skd_sync_max_floats(void);
+void *skd_sync_create(int world, int rank, void *handle_out);
+int skd_sync_connect(void *ctx, const void *all_handles);
+int skd_sync_destroy(void *ctx);
+int skd_sync_all_gather(void *ctx, int n, const float *src, float *gathered, skd_stream_t stream);
+int skd_abn_sync_stats(void *ctx, int C, const float *stat, const float *weights, float *mean, float *var,
+                       float *running_mean, float *running_var, float momentum, double n, skd_stream_t stream);
+int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights, skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210
  *     (CSDataSet.__getitem__ after the PNG decode), one launch per batch:
  *       label = lut[label] (id -> trainId, datasets.py:143-148,162-171); image / label resized by f (cv2.resize,

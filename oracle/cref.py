@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ("abn_ref.c", "losses_ref.c", "input_ref.c")]
+    srcs = [os.path.join(HERE, f) for f in ("abn_ref.c", "losses_ref.c", "input_ref.c", "sync_ref.c")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH

@@ -1,0 +1,163 @@
+/* sync_ref.c -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): host restatement of csrc/sync.hip, the one-hop exchange of
+ * the cross-replica InPlace-ABN statistics (libs/functions.py:185-209 forward, :263-280 backward), behind the same C ABI
+ * (include/skd.h section 12).  The product maps every rank's mailbox into every process with HIP IPC and lets ONE kernel
+ * store / flag / spin / combine; here the mailboxes are POSIX shared-memory segments and the same four steps run on the host
+ * (C11 atomics for the flag words), so the world-2 gloo tests on a box without a GPU execute the protocol itself: slot layout,
+ * parity alternation, sequence numbers, the combine rule and the rank-ordered weighted sum. */
+#define _GNU_SOURCE
+#include <fcntl.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+typedef void *stream_t;
+#define MAX_WORLD 16
+#define MAX_FLOATS 4096
+#define HEADER_FLOATS 16
+#define SLOT_FLOATS (HEADER_FLOATS + MAX_FLOATS)
+#define HANDLE_BYTES 64
+
+typedef struct {
+  float *mail[MAX_WORLD];
+  size_t bytes;
+  int world, rank;
+  unsigned seq;
+  char name[HANDLE_BYTES];
+} sync_ctx;
+
+int skd_sync_handle_bytes(void) { return HANDLE_BYTES; }
+int skd_sync_max_floats(void) { return MAX_FLOATS; }
+
+static float *slot_of(float *mailbox, int world, int parity, int writer) {
+  return mailbox + ((size_t)parity * world + writer) * SLOT_FLOATS;
+}
+
+void *skd_sync_create(int world, int rank, void *handle_out) {
+  static unsigned counter = 0;
+  if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world || !handle_out) return NULL;
+  sync_ctx *c = (sync_ctx *)calloc(1, sizeof *c);
+  if (!c) return NULL;
+  c->world = world;
+  c->rank = rank;
+  c->bytes = sizeof(float) * 2 * (size_t)world * SLOT_FLOATS;
+  snprintf(c->name, sizeof c->name, "/skdsync_%ld_%u", (long)getpid(), counter++);
+  const int fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) {
+    if (fd >= 0) { close(fd); shm_unlink(c->name); }
+    free(c);
+    return NULL;
+  }
+  void *p = mmap(NULL, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { shm_unlink(c->name); free(c); return NULL; }
+  memset(p, 0, c->bytes);
+  c->mail[rank] = (float *)p;
+  memset(handle_out, 0, HANDLE_BYTES);
+  memcpy(handle_out, c->name, strlen(c->name) + 1);
+  return c;
+}
+
+int skd_sync_connect(void *ctx, const void *all_handles) {
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!c || !all_handles) return 0;
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    char name[HANDLE_BYTES];
+    memcpy(name, (const char *)all_handles + (size_t)r * HANDLE_BYTES, HANDLE_BYTES);
+    name[HANDLE_BYTES - 1] = 0;
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return 0;
+    void *p = mmap(NULL, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return 0;
+    c->mail[r] = (float *)p;
+  }
+  return 1;
+}
+
+int skd_sync_destroy(void *ctx) {
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!c) return 0;
+  for (int r = 0; r < c->world; ++r)
+    if (c->mail[r]) munmap(c->mail[r], c->bytes);
+  shm_unlink(c->name);
+  free(c);
+  return 1;
+}
+
+static int connected(const sync_ctx *c) {
+  if (!c) return 0;
+  for (int r = 0; r < c->world; ++r)
+    if (!c->mail[r]) return 0;
+  return 1;
+}
+
+/* steps (1)-(3) of csrc/sync.hip: payload into every mailbox, flags, wait for all flags of the own mailbox (5 s) */
+static int exchange(sync_ctx *c, unsigned seq, int n, const float *src) {
+  const int parity = (int)(seq & 1u);
+  for (int r = 0; r < c->world; ++r) memcpy(slot_of(c->mail[r], c->world, parity, c->rank) + HEADER_FLOATS, src, sizeof(float) * (size_t)n);
+  for (int r = 0; r < c->world; ++r)
+    __atomic_store_n((unsigned *)slot_of(c->mail[r], c->world, parity, c->rank), seq, __ATOMIC_RELEASE);
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int r = 0; r < c->world; ++r) {
+    const unsigned *flag = (const unsigned *)slot_of(c->mail[c->rank], c->world, parity, r);
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) return 0;
+      usleep(20);
+    }
+  }
+  return 1;
+}
+
+int skd_sync_all_gather(void *ctx, int n, const float *src, float *gathered, stream_t st) {
+  (void)st;
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!connected(c) || n <= 0 || n > MAX_FLOATS || !src || !gathered) return 0;
+  const unsigned seq = ++c->seq;
+  const int good = exchange(c, seq, n, src);
+  for (int r = 0; r < c->world; ++r)
+    for (int i = 0; i < n; ++i) gathered[(size_t)r * n + i] = good ? slot_of(c->mail[c->rank], c->world, (int)(seq & 1u), r)[HEADER_FLOATS + i] : NAN;
+  return 1;
+}
+
+int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var, float *rm,
+                          float *rv, float momentum, double n, stream_t st);
+
+int skd_abn_sync_stats(void *ctx, int C, const float *stat, const float *weights, float *mean, float *var, float *running_mean,
+                       float *running_var, float momentum, double n, stream_t st) {
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!connected(c) || C <= 0 || 2 * C > MAX_FLOATS || !stat || !mean || !var) return 0;
+  float *g = (float *)malloc(sizeof(float) * (size_t)c->world * 2 * C);
+  if (!g) return 0;
+  int r = skd_sync_all_gather(ctx, 2 * C, stat, g, st);
+  r = r && skd_abn_combine_stats(c->world, C, g, weights, c->rank, mean, var, running_mean, running_var, momentum, n, st);
+  free(g);
+  return r;
+}
+
+int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights, stream_t st) {
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!connected(c) || C <= 0 || 2 * C > MAX_FLOATS || !stat) return 0;
+  float *g = (float *)malloc(sizeof(float) * (size_t)c->world * 2 * C);
+  if (!g) return 0;
+  const int r = skd_sync_all_gather(ctx, 2 * C, stat, g, st);
+  for (int i = 0; r && i < 2 * C; ++i) {
+    float s = 0.f;
+    for (int q = 0; q < c->world; ++q) {
+      const float v = g[(size_t)q * 2 * C + i];
+      const float term = weights ? weights[q] * v : v;     /* product rounded to float, then added */
+      s = s + term;
+    }
+    if (!weights) s /= (float)c->world;
+    stat[i] = s;
+  }
+  free(g);
+  return r;
+}

@@ -98,6 +98,14 @@ SIGNATURES = {
     "skd_maxpool3x3s2_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_seg_confusion": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "skd_sum_f32": (_I, [_L, _P, _P, _F, _P, _P]),
+    "skd_sync_handle_bytes": (_I, []),
+    "skd_sync_max_floats": (_I, []),
+    "skd_sync_create": (_P, [_I, _I, _P]),
+    "skd_sync_connect": (_I, [_P, _P]),
+    "skd_sync_destroy": (_I, [_P]),
+    "skd_sync_all_gather": (_I, [_P, _I, _P, _P, _P]),
+    "skd_abn_sync_stats": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _D, _P]),
+    "skd_abn_sync_grad_stats": (_I, [_P, _I, _P, _P, _P]),
 }
 
 _lib = None

@@ -255,20 +255,11 @@ __global__ void abn_combine_stats_kernel(int G, int C, const float *__restrict__
                                          float momentum, float nf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float m = 0.f;
-  for (int g = 0; g < G; ++g) m += (weights ? weights[g] : 1.f) * gathered[((int64_t)g * 2) * C + c];
-  if (!weights) m /= (float)G;
-  float v = 0.f;
-  for (int g = 0; g < G; ++g) {
-    const float d = m - gathered[((int64_t)g * 2) * C + c];
-    v += (weights ? weights[g] : 1.f) * (gathered[((int64_t)g * 2 + 1) * C + c] + d * d);
-  }
-  if (!weights) v /= (float)G;
-  if (weights) nf = nf / weights[rank];
+  float m, v;
+  combine_channel(G, C, c, [&](int g, int j) { return gathered[(int64_t)g * 2 * C + j]; }, weights, rank, nf, momentum, m, v,
+                  running_mean, running_var);
   mean[c] = m;
   var[c] = v;
-  if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m;
-  if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v, nf);
 }
 
 __global__ void abn_update_running_kernel(int C, float *running_mean, float *running_var,

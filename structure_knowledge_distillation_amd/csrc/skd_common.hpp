@@ -54,6 +54,30 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *scratch) {
   }
 }
 
+// Cross-replica combine of the batch statistics for ONE channel (libs/functions.py:196-197 + the running update of
+// :208-209): mean = sum_g w_g mean_g, var = sum_g w_g (var_g + (mean - mean_g)^2), w_g = 1 / G without `weights`.
+// `ld(g, j)` returns element j (0 <= j < 2 C) of rank g's [mean | var] vector.  One definition for the gathered-buffer kernel
+// (abn.hip) and the one-hop exchange kernel (sync.hip), so that both produce the same bits.
+template <class L>
+__device__ __forceinline__ void combine_channel(int G, int C, int c, L ld, const float *__restrict__ weights, int rank, float nf,
+                                                float momentum, float &m_out, float &v_out, float *running_mean,
+                                                float *running_var) {
+  float m = 0.f;
+  for (int g = 0; g < G; ++g) m += (weights ? weights[g] : 1.f) * ld(g, c);
+  if (!weights) m /= (float)G;
+  float v = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float d = m - ld(g, c);
+    v += (weights ? weights[g] : 1.f) * (ld(g, C + c) + d * d);
+  }
+  if (!weights) v /= (float)G;
+  if (weights) nf = nf / weights[rank];
+  m_out = m;
+  v_out = v;
+  if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m;
+  if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * (nf > 1.f ? v * nf / (nf - 1.f) : v);
+}
+
 // Stream a contiguous, arbitrarily aligned run of `len` floats with the whole workgroup:
 // scalar head up to the first 16-byte boundary, float4 body, scalar tail.
 // The functor supplies split load / use halves so that the four 16-B loads of a lane are

@@ -212,8 +212,19 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
     """Cross-replica statistics (libs/functions.py:185-209): all_gather [mean, var], the reference combine rule
     (pooled with the per-rank sample weights when utils.parallel.set_replica_batch announced them), running-stat
     update with the pooled n.  Returns contiguous (mean, var)."""
-    from ..utils.parallel import comm_timer
+    from ..utils.parallel import comm_timer, SyncMailbox
     g = _group_size(group)
+    mb = SyncMailbox.get(group, stat.device)
+    if mb is not None and c <= mb.max_channels:
+        # one launch: store into every replica's mailbox (one xGMI hop), flags, wait, combine + running update (csrc/sync.hip)
+        w = _replica_weights(group)
+        out = stat.new_empty((2, c))
+        tok = comm_timer.begin("syncabn", stat)
+        _lib.check(lib.skd_abn_sync_stats(mb.ctx, c, stat.data_ptr(), _lib.ptr(w), out[0].data_ptr(), out[1].data_ptr(),
+                                          _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
+                                          float(count) if w is not None else float(count * g), st), "skd_abn_sync_stats")
+        comm_timer.end(tok)
+        return out[0], out[1]
     gathered = stat.new_empty((g, 2, c))
     tok = comm_timer.begin("syncabn", stat)
     dist.all_gather_into_tensor(gathered.view(-1), stat.view(-1), group=group)
@@ -230,8 +241,15 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
 def _sync_grad_stats(stat, group):
     """libs/functions.py:271-272: [edz, eydz] are averaged over the replicas -- weighted by the per-rank sample
     counts when they are known (the pooled expectation), plain mean otherwise."""
-    from ..utils.parallel import comm_timer
+    from ..utils.parallel import comm_timer, SyncMailbox
     w = _replica_weights(group)
+    mb = SyncMailbox.get(group, stat.device)
+    if mb is not None and stat.shape[1] <= mb.max_channels:
+        tok = comm_timer.begin("syncabn", stat)
+        _lib.check(mb.lib.skd_abn_sync_grad_stats(mb.ctx, stat.shape[1], stat.data_ptr(), _lib.ptr(w), _lib.stream_of(stat)),
+                   "skd_abn_sync_grad_stats")
+        comm_timer.end(tok)
+        return
     if w is not None:
         stat.mul_(w[dist.get_rank(group)])
     tok = comm_timer.begin("syncabn", stat)

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
            "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
-           "clear_replica_batch", "replica_weights"]
+           "clear_replica_batch", "replica_weights", "SyncMailbox"]
 
 
 def init_distributed(backend=None):
@@ -99,6 +99,77 @@ def clear_replica_batch():
 def replica_weights():
     """(G,) device tensor of n_g / sum(n) set by ``set_replica_batch`` for this step, or None (equal shards)."""
     return _REPLICA["weights"]
+
+
+class SyncMailbox:
+    """Per process group: the IPC mailboxes of csrc/sync.hip (include/skd.h section 12) that carry the cross-replica
+    InPlace-ABN statistics in one small kernel per exchange instead of a torch.distributed collective.
+
+    ``SyncMailbox.get(group, device)`` is COLLECTIVE the first time it is called for a group: every rank creates its
+    mailbox, the IPC handles (and host names) travel with ``dist.all_gather_object``, every rank opens the others' and the
+    ranks run one self-test exchange whose result they check on the host; the verdicts are combined with an all-reduce
+    (MIN) so that EITHER every rank uses the mailboxes OR every rank keeps the torch.distributed path -- a rank on another
+    host, a failed hipIpcOpenMemHandle or a wrong self-test answer anywhere switches the whole group back.
+    SKD_SYNC_IPC=0 keeps torch.distributed (the selectable fallback)."""
+    _by_group = {}
+
+    def __init__(self, ctx, lib, world, rank):
+        self.ctx, self.lib, self.world, self.rank = ctx, lib, world, rank
+        self.max_channels = lib.skd_sync_max_floats() // 2
+
+    @classmethod
+    def get(cls, group, device):
+        key = id(group) if group is not None else 0
+        if key not in cls._by_group:
+            cls._by_group[key] = cls._create(group, device)
+        return cls._by_group[key]
+
+    @classmethod
+    def reset(cls):
+        for mb in cls._by_group.values():
+            if mb:
+                mb.lib.skd_sync_destroy(mb.ctx)
+        cls._by_group.clear()
+
+    @classmethod
+    def _create(cls, group, device):
+        import ctypes
+        import socket
+        from .. import _lib
+        import contextlib
+        w = world_size(group)
+        on_gpu = torch.device(device).type == "cuda"
+        # (CPU tensors only with the tests' C-ABI double installed: its mailboxes are POSIX shared memory, oracle/sync_ref.c)
+        if w <= 1 or w > 16 or os.environ.get("SKD_SYNC_IPC", "1") != "1" or not (on_gpu or _lib.test_backend_active()):
+            return None
+        lib = _lib.get()
+        rk = dist.get_rank(group)
+        nb = lib.skd_sync_handle_bytes()
+        buf = ctypes.create_string_buffer(nb)
+        on_device = (lambda: torch.cuda.device(device)) if on_gpu else contextlib.nullcontext
+        with on_device():
+            ctx = lib.skd_sync_create(w, rk, ctypes.cast(buf, ctypes.c_void_p))
+        mine = (bytes(buf.raw) if ctx else None, socket.gethostname())
+        everyone = [None] * w
+        dist.all_gather_object(everyone, mine, group=group)
+        good = bool(ctx) and all(h is not None and host == mine[1] for h, host in everyone)
+        if good:
+            blob = ctypes.create_string_buffer(b"".join(h for h, _ in everyone), nb * w)
+            with on_device():
+                good = bool(lib.skd_sync_connect(ctx, ctypes.cast(blob, ctypes.c_void_p)))
+        if good:                                     # self-test: all-gather of [rank, rank + 0.5] through the mailboxes
+            src = torch.tensor([float(rk), rk + 0.5], device=device)
+            out = torch.full((w, 2), -1.0, device=device)
+            good = bool(lib.skd_sync_all_gather(ctx, 2, src.data_ptr(), out.data_ptr(), _lib.stream_of(src)))
+            want = torch.tensor([[float(r), r + 0.5] for r in range(w)])
+            good = good and torch.equal(out.cpu(), want)
+        verdict = torch.tensor([1.0 if good else 0.0], device=device if dist.get_backend(group) == "nccl" else "cpu")   # gloo: host
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+        if float(verdict) < 1.0:
+            if ctx:
+                lib.skd_sync_destroy(ctx)
+            return None
+        return cls(ctx, lib, w, rk)
 
 
 def broadcast_module(module, src=0, group=None):

@@ -93,6 +93,69 @@ def test_sync_abn_two_ranks_hip_kernels():
 
 
 # ---------------------------------------------------------------------------------------------------
+def _mailbox_vs_collectives(rank, world):
+    """csrc/sync.hip with REAL HIP IPC (two processes, one device: each rank's mailbox is the other process's allocation):
+    bit-identical to the all_gather + skd_abn_combine_stats / mul_ + all_reduce path it replaces, and timed against it."""
+    import importlib
+    import time
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dev = torch.device("cuda", 0)
+    lib, group = _lib.get(), dist.group.WORLD
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {"rounds": [], "us": {}}
+    for rnd in range(5):
+        C = (8, 64, 512, 2048, 12)[rnd]
+        weighted = rnd % 2 == 1
+        if weighted:
+            P.set_replica_batch(3 if rank == 0 else 1, dev)
+        else:
+            P.clear_replica_batch()
+        res = {}
+        for mode in ("1", "0"):
+            os.environ["SKD_SYNC_IPC"] = mode
+            P.SyncMailbox.reset()
+            mb = P.SyncMailbox.get(group, dev)
+            assert (mb is not None) == (mode == "1"), "IPC mailboxes could not be set up between two processes on one device"
+            stat = (torch.randn(2, C, generator=torch.Generator().manual_seed(100 * rnd + rank)).abs() + 0.1).to(dev)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            count = 7 * (3 if rank == 0 else 1) if weighted else 7
+            mean, var = IA._sync_stats(stat.clone(), C, count, group, rm, rv, 0.1, lib, st)
+            gstat = torch.randn(2, C, generator=torch.Generator().manual_seed(7000 + 100 * rnd + rank)).to(dev)
+            for _ in range(3):
+                IA._sync_grad_stats(gstat, group)
+            torch.cuda.synchronize()
+            res[mode] = tuple(t.cpu() for t in (mean, var, rm, rv, gstat))
+            if C == 512:                                # latency of one backward exchange at the student's widest layer
+                for timed in (False, True):
+                    torch.cuda.synchronize(); dist.barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(200):
+                        IA._sync_grad_stats(gstat, group)
+                    torch.cuda.synchronize()
+                    if timed:
+                        out["us"][mode] = (time.perf_counter() - t0) / 200 * 1e6
+        for a, b in zip(res["1"], res["0"]):
+            assert torch.equal(a, b), "mailbox exchange differs from the collectives (round %d)" % rnd
+        out["rounds"].append(res["1"])
+    os.environ["SKD_SYNC_IPC"] = "1"
+    P.SyncMailbox.reset()
+    return out
+
+
+def test_mailbox_exchange_over_hip_ipc_is_bit_identical_to_the_collectives():
+    outs = _run("_mailbox_vs_collectives")
+    for a, b in zip(outs[0]["rounds"], outs[1]["rounds"]):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb), "replicas must hold identical pooled statistics"
+    us = outs[0]["us"]
+    print("SyncABN exchange of 2 x 512 floats, two ranks on one MI355X, host-to-host per call: mailbox kernel %.1f us, "
+          "gloo all_reduce %.1f us" % (us["1"], us["0"]))
+    assert us["1"] < us["0"]
+
+
+# ---------------------------------------------------------------------------------------------------
 # BASELINE configs[3] (DP + SyncABN + Ho) on two ranks sharing the MI355X: the whole optimize_parameters()
 # with the discriminator step, against the sharded oracle (oracle.step_torch.distillation_step_sharded =
 # utils/parallel.py:155 + libs/functions.py:185-209 + sagan_models.py:148 semantics).

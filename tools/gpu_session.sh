@@ -160,6 +160,10 @@ EOF
       timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -s -k "conv1x1 or bottleneck or one_call" > $O/pytest_c11.log 2>&1
       stamp "tests_c11 rc=$?"; grep -E "passed|failed|error" $O/pytest_c11.log | tail -3 | tee -a $O/session.log
       grep -E "^E  |^FAILED" $O/pytest_c11.log | cut -c1-300 | head -30 | tee -a $O/session.log ;;
+    tests_dist)
+      timeout 900 python -m pytest tests/test_distributed_gpu.py tests/test_kernels_gpu.py -m gpu -q --tb=short -s -k "distributed or one_call or mailbox or two_ranks or torchrun" > $O/pytest_dist.log 2>&1
+      stamp "tests_dist rc=$?"; grep -E "passed|failed|error" $O/pytest_dist.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED|SyncABN exchange" $O/pytest_dist.log | cut -c1-300 | head -30 | tee -a $O/session.log ;;
     dstep)
       timeout 300 python tools/d_step_error_probe.py 8 > $O/d_step_error.jsonl 2> $O/d_step_error.err
       stamp "dstep rc=$?"; cut -c1-420 $O/d_step_error.jsonl | tee -a $O/session.log ;;
