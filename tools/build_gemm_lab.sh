@@ -3,7 +3,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 python -m structure_knowledge_distillation_amd.build > /dev/null
-/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -I $R/include $R/tools/gemm_lab.cpp -o $R/tools/gemm_lab \
+/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 -I $R/include $R/tools/gemm_lab.cpp $R/tools/gemm_lab_kernels.hip -o $R/tools/gemm_lab \
   -L $R/structure_knowledge_distillation_amd -lskd_hip -L /opt/rocm/lib -lhipblaslt \
   -Wl,-rpath,'$ORIGIN/../structure_knowledge_distillation_amd' -Wl,-rpath,/opt/rocm/lib
 echo built $R/tools/gemm_lab

@@ -266,6 +266,56 @@ static void conv_cases() {
   }
 }
 
+extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *Y, int64_t M, int K, int N);
+extern "C" const char *lab_tn_name(int variant);
+
+// experiment variants of the TN GEMM core (tools/gemm_lab_kernels.hip): plain C = X W^T, main-loop decomposition and tile shapes
+static void variant_cases() {
+  const ConvShape shapes[] = {{33800, 1024, 256, false, 22}, {33800, 256, 1024, false, 23}, {33800, 1024, 2048, false, 1}};
+  for (const ConvShape &s : shapes) {
+    std::vector<float> hx, hw;
+    float *x = dev_random((size_t)s.M * s.K, 1.f, &hx), *w = dev_random((size_t)s.N * s.K, 0.05f, &hw);
+    float *out = dev_empty((size_t)s.M * s.N);
+    const double flops = 2.0 * s.M * s.K * s.N;
+    for (int v = 0; lab_tn_name(v) != nullptr; ++v) {
+      char tag[128];
+      snprintf(tag, sizeof tag, "variant %d [%s] M=%lld K=%d N=%d", v, lab_tn_name(v), (long long)s.M, s.K, s.N);
+      if (g_filter[0] && std::string(tag).find(g_filter) == std::string::npos) continue;
+      CK(hipMemset(out, 0xff, (size_t)s.M * s.N * sizeof(float)));
+      const int rc = lab_tn_gemm(v, x, w, out, s.M, s.K, s.N);
+      if (rc != 1) {
+        printf("{\"case\": \"%s\", \"skipped\": %d}\n", tag, rc);
+        continue;
+      }
+      CK(hipDeviceSynchronize());
+      std::string ex;
+      const bool exact = strstr(lab_tn_name(v), "no-") == nullptr && strstr(lab_tn_name(v), "only") == nullptr;
+      if (exact) {
+        std::vector<float> ho((size_t)s.M * s.N);
+        CK(hipMemcpy(ho.data(), out, ho.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double worst = 0;
+        uint32_t sd = 4242;
+        for (int t = 0; t < 512; ++t) {
+          sd = sd * 1664525u + 1013904223u;
+          const int64_t m = t < 32 ? s.M - 1 - t : (int64_t)(sd >> 4) % s.M;
+          sd = sd * 1664525u + 1013904223u;
+          const int n = (int)((sd >> 4) % (uint32_t)s.N);
+          double acc = 0;
+          for (int k = 0; k < s.K; ++k) acc += (double)hx[(size_t)m * s.K + k] * (double)hw[(size_t)n * s.K + k];
+          const double err = fabs(acc - (double)ho[(size_t)m * s.N + n]) / (fabs(acc) + 1.0);
+          if (err > worst) worst = err;
+        }
+        char buf[64];
+        snprintf(buf, sizeof buf, ", \"max_err_vs_fp64\": %.2e", worst);
+        ex = buf;
+      }
+      run_case(tag, flops, 0, [&] { lab_tn_gemm(v, x, w, out, s.M, s.K, s.N); }, ex);
+    }
+    CK(hipDeviceSynchronize());
+    for (float *p : {x, w, out}) CK(hipFree(p));
+  }
+}
+
 int main(int argc, char **argv) {
   if (argc > 1) g_pmc = strcmp(argv[1], "pmc") == 0;
   if (argc > 2) g_reps = atoi(argv[2]);
@@ -277,7 +327,10 @@ int main(int argc, char **argv) {
   Timer t;
   g_timer = &t;
   CKB(hipblasLtCreate(&g_lt));
-  pairwise_cases();
-  conv_cases();
+  if (!(argc > 4 && strcmp(argv[4], "variants-only") == 0)) {
+    pairwise_cases();
+    conv_cases();
+  }
+  variant_cases();
   return 0;
 }

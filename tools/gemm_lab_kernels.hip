@@ -1,0 +1,193 @@
+// gemm_lab_kernels.hip -- EXPERIMENT variants of the fp32-MFMA TN GEMM core (both operands K-contiguous: C[M][N] = X[M][K] . W[N][K]^T),
+// timed by tools/gemm_lab.  Not shipped: what wins here moves into csrc/conv1x1.hip / csrc/pairwise.hip.
+//
+// Knobs (template parameters): BK (K-tile), WM x WN MFMA blocks per wave (wave tile 32*WM x 32*WN), 2 x 2 waves per workgroup,
+// minimum workgroups per CU (register budget), MODE:
+//   0 full kernel                         1 no global loads in the loop (the first tile's registers are re-stored every trip)
+//   2 no LDS writes / barrier either      3 MFMA only (operands from registers)
+// The epilogue is a plain coalesced dword store of C (no BN, no residual): the variants isolate the main loop.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lab {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kWave = 64;
+
+template <int RA, int RB>
+struct Stg {
+  float4 a[RA], b[RB];
+};
+
+template <int RA, int RB, int RPP>
+__device__ __forceinline__ void lab_gload(Stg<RA, RB> &o, const float *__restrict__ X, const float *__restrict__ Wt, int64_t m0, int grow, int gkq,
+                                          int64_t wrow0, int64_t M, int K, int k0) {
+#pragma unroll
+  for (int h = 0; h < RA; ++h) {
+    const int64_t m = m0 + grow + RPP * h;
+    o.a[h] = *reinterpret_cast<const float4 *>(X + (m > M - 1 ? M - 1 : m) * K + k0 + gkq);
+  }
+#pragma unroll
+  for (int h = 0; h < RB; ++h) o.b[h] = *reinterpret_cast<const float4 *>(Wt + wrow0 + (int64_t)(RPP * h) * K + k0 + gkq);
+}
+template <int RA, int RB, int RPP, int LDK, int TM>
+__device__ __forceinline__ void lab_sstore(const Stg<RA, RB> v, float *stage, int srow) {
+#pragma unroll
+  for (int h = 0; h < RA; ++h) *reinterpret_cast<float4 *>(stage + srow + RPP * h * LDK) = v.a[h];
+#pragma unroll
+  for (int h = 0; h < RB; ++h) *reinterpret_cast<float4 *>(stage + TM * LDK + srow + RPP * h * LDK) = v.b[h];
+}
+
+template <int BK, int WM, int WN, int MINWG, int MODE>
+__global__ __launch_bounds__(256, MINWG) void tn_gemm_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                             float *__restrict__ Y, int64_t M, int K, int N, int tiles_n) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;      // 2 x 2 waves
+  constexpr int LDK = BK + 4;
+  constexpr int STAGE = (TM + TN) * LDK;
+  constexpr int RA = TM * BK / 4 / 256, RB = TN * BK / 4 / 256;   // float4 per thread and K-tile
+  constexpr int QK = BK / 4;                                      // float4 per panel row
+  constexpr int ROWS_PER_PASS = 256 / QK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tn = blockIdx.x % tiles_n;
+  const int64_t tm = blockIdx.x / tiles_n;
+  const int64_t m0 = tm * TM;
+  const int n0 = tn * TN;
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const int nk = K / BK;
+  const int t = threadIdx.x, grow = t / QK, gkq = (t % QK) * 4;
+  const int srow = grow * LDK + gkq;
+  const int64_t wrow0 = (int64_t)(n0 + grow) * K;
+  Stg<RA, RB> st;
+  const int lane = t & (kWave - 1), wid = t / kWave;
+  const int wi = (wid >> 1) * 32 * WM, wj = (wid & 1) * 32 * WN;
+  const int half = lane >> 5, r = lane & 31;
+  auto mma = [&](const float *stage) {
+    const float *pa = stage + (wi + r) * LDK + half * 4;
+    const float *pb = stage + (TM + wj + r) * LDK + half * 4;
+    float4 a[WM], b[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4 *>(pa + 32 * i * LDK);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const float4 *>(pb + 32 * j * LDK);
+    __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 na[WM], nb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) na[i] = a[i];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) nb[j] = b[j];
+      if (g + 1 < BK / 8) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) na[i] = *reinterpret_cast<const float4 *>(pa + 32 * i * LDK + (g + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) nb[j] = *reinterpret_cast<const float4 *>(pb + 32 * j * LDK + (g + 1) * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const float av = q == 0 ? a[i].x : q == 1 ? a[i].y : q == 2 ? a[i].z : a[i].w;
+            const float bv = q == 0 ? b[j].x : q == 1 ? b[j].y : q == 2 ? b[j].z : b[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = na[i];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = nb[j];
+      __builtin_amdgcn_sched_group_barrier(0x008, WM * WN, 0);
+      if (g + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * WM * WN, 0);
+    }
+  };
+  lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, 0);
+  lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds, srow);
+  __syncthreads();
+  int stage = 0;
+  if (MODE == 3) {
+    float av = X[t], bv = Wt[t];
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int q = 0; q < BK / 2; ++q)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (MODE == 0 && more) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+      mma(lds + stage * STAGE);
+      if (MODE <= 1) {
+        if (more) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
+        __syncthreads();
+        stage ^= 1;
+      }
+    }
+  }
+  // plain epilogue
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = n0 + wj + j * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + wi + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M) Y[row * N + col] = acc[i][j][q];
+      }
+  }
+}
+
+template <int BK, int WM, int WN, int MINWG, int MODE>
+int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;
+  constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
+  if (K % BK || N % TN) return 0;
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(tn_gemm_kernel<BK, WM, WN, MINWG, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return 0;
+    ready = true;
+  }
+  const int tiles_n = N / TN;
+  const int64_t tiles_m = (M + TM - 1) / TM;
+  tn_gemm_kernel<BK, WM, WN, MINWG, MODE><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n);
+  return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace lab
+
+// C-callable table for gemm_lab.cpp
+extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
+  using namespace lab;
+  switch (variant) {
+    case 0: return launch_tn<32, 2, 2, 2, 0>(X, Wt, Y, M, K, N);    // the shipped structure: 128 x 128 x 32, 2 workgroups / CU
+    case 1: return launch_tn<32, 2, 2, 2, 1>(X, Wt, Y, M, K, N);    //   ... without global loads in the loop
+    case 2: return launch_tn<32, 2, 2, 2, 2>(X, Wt, Y, M, K, N);    //   ... without LDS writes / barriers either
+    case 3: return launch_tn<32, 2, 2, 2, 3>(X, Wt, Y, M, K, N);    //   ... MFMA only
+    case 4: return launch_tn<16, 2, 2, 4, 0>(X, Wt, Y, M, K, N);    // BK 16: 36 KB LDS, up to 4 workgroups / CU
+    case 5: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N);    // BK 16, 3 workgroups / CU (168 VGPRs)
+    case 6: return launch_tn<32, 4, 2, 1, 0>(X, Wt, Y, M, K, N);    // 256 x 128 tile, wave tile 128 x 64, 1 workgroup / CU
+    case 7: return launch_tn<32, 2, 4, 1, 0>(X, Wt, Y, M, K, N);    // 128 x 256 tile, wave tile 64 x 128
+    case 8: return launch_tn<16, 4, 4, 1, 0>(X, Wt, Y, M, K, N);    // 256 x 256 x 16, wave tile 128 x 128 (256 accumulator registers)
+    case 9: return launch_tn<32, 2, 2, 1, 0>(X, Wt, Y, M, K, N);    // shipped tile, 1 workgroup / CU allowed to use 512 registers
+    default: return -1;
+  }
+}
+extern "C" const char *lab_tn_name(int variant) {
+  static const char *names[] = {"128x128x32 2wg/cu",          "128x128x32 no-gload",       "128x128x32 no-gload no-lds-write",
+                                "128x128x32 mfma-only",       "128x128x16 4wg/cu",         "128x128x16 3wg/cu",
+                                "256x128x32 1wg/cu",          "128x256x32 1wg/cu",         "256x256x16 1wg/cu",
+                                "128x128x32 1wg/cu"};
+  return variant >= 0 && variant < 10 ? names[variant] : nullptr;
+}
