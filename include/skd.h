@@ -375,22 +375,24 @@ int skd_sum_f32(int64_t n, const float *x, float *out /* [1] */, float scale, fl
  *       out[m][n] = act( ((sum_k x[m][k] * w[n][k] - mean[n]) * invstd[n]) * (|weight[n]| + eps) + bias[n] [+ residual[m][n]] )
  *     x (M, K) = (B*H*W, Cin); w (N, K) = the (Cout, Cin, 1, 1) convolution weight; residual / out (M, N); mean / var =
  *     the running statistics; weight / bias may be NULL (gamma 1, beta 0); activation: SKD_ACT_NONE / RELU / LEAKY_RELU.
- *     skd_conv1x1_abn_supported(): K % 32 == 0 and N % 128 == 0 (every stride-1 1x1 convolution of the ResNet101
+ *     skd_conv1x1_abn_supported(): K % 16 == 0 and N % 128 == 0 (every stride-1 1x1 convolution of the ResNet101
  *     teacher except the two with 64 output channels); other problems stay on convolution + skd_abn_apply_nhwc.
  *     skd_conv1x1_abn_pro_nhwc (round 3): the same GEMM with the PRECEDING eval-mode BatchNorm + ReLU applied to x on its
- *     way into LDS -- x[m][k] <- relu(((x[m][k] - pmean[k]) * invstd(pvar[k], peps)) * (|pweight[k]| + peps) + pbias[k]) --
- *     so that for a bottleneck tail conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu (pspnet_combine.py:71-82)
- *     x is the raw 3x3-convolution output and neither ABN pass exists.  pmean / pvar: K floats, 16-byte aligned, required;
- *     pweight / pbias may be NULL.
+ *     way into LDS -- x[m][k] <- relu(((x[m][k] - mean_k) * invstd_k) * gamma_k + beta_k) -- so that for a bottleneck tail
+ *     conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu (pspnet_combine.py:71-82) x is the raw 3x3-convolution
+ *     output and neither ABN pass exists.  ppack (4, K) = [mean | invstd | gamma | beta] of that BatchNorm, written by
+ *     skd_abn_pack_eval_params (invstd = 1 / sqrt(var + eps), gamma = |weight| + eps or 1, beta = bias or 0; bn.cu:146-159):
+ *     a frozen network packs once.  16-byte aligned; K <= 512 (the table rides in LDS next to the operand tiles).
  * ---------------------------------------------------------------------------------- */
 int skd_conv1x1_abn_supported(int64_t M, int K, int N);
 int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                          const float *mean, const float *var, const float *weight, const float *bias, float eps,
                          int activation, float slope, skd_stream_t stream);
+int skd_abn_pack_eval_params(int K, const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                             float *pack, skd_stream_t stream);
 int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                              const float *mean, const float *var, const float *weight, const float *bias, float eps,
-                             const float *pmean, const float *pvar, const float *pweight, const float *pbias, float peps,
-                             int activation, float slope, skd_stream_t stream);
+                             const float *ppack, int activation, float slope, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 12. One-hop exchange of the cross-replica InPlace-ABN statistics (round 3): replaces libs/functions.py:185-205

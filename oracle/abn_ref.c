@@ -550,7 +550,7 @@ int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weig
 
 /* ---- 1x1 convolution + eval-mode ABN (+ residual) + activation, channels-last (include/skd.h section 11):
  *      the convolution as a plain dot product in double, then the forward formula of bn.cu:146-159 ---- */
-int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % 32 == 0 && N % 128 == 0; }
+int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % 16 == 0 && N % 128 == 0; }
 
 int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                          const float *mean, const float *var, const float *weight, const float *bias, float eps, int act,
@@ -575,19 +575,30 @@ int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w
   return 1;
 }
 
-/* the same with the preceding eval-mode BN + ReLU applied to x first (bn.cu:146-159 + ReLU), materialised here */
+/* [mean | invstd | gamma | beta] of an eval-mode InPlace-ABN, bn.cu:146-159 */
+int skd_abn_pack_eval_params(int K, const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                             float *pack, stream_t st) {
+  (void)st;
+  if (K <= 0 || !mean || !var || !pack) return 0;
+  for (int k = 0; k < K; ++k) {
+    pack[k] = mean[k];
+    pack[K + k] = (var[k] != 0.f || eps != 0.f) ? 1.f / sqrtf(var[k] + eps) : 0.f;
+    pack[2 * (int64_t)K + k] = weight ? fabsf(weight[k]) + eps : 1.f;
+    pack[3 * (int64_t)K + k] = bias ? bias[k] : 0.f;
+  }
+  return 1;
+}
+
+/* the same GEMM with the preceding eval-mode BN + ReLU applied to x first (bn.cu:146-159 + ReLU), materialised here */
 int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                              const float *mean, const float *var, const float *weight, const float *bias, float eps,
-                             const float *pmean, const float *pvar, const float *pweight, const float *pbias, float peps, int act,
-                             float slope, stream_t st) {
-  if (!skd_conv1x1_abn_supported(M, K, N) || !x || !pmean || !pvar) return 0;
+                             const float *ppack, int act, float slope, stream_t st) {
+  if (!skd_conv1x1_abn_supported(M, K, N) || !x || !ppack) return 0;
   float *a = (float *)malloc(sizeof(float) * (size_t)M * K);
   if (!a) return 0;
   for (int64_t m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k) {
-      const float is = (pvar[k] != 0.f || peps != 0.f) ? 1.f / sqrtf(pvar[k] + peps) : 0.f;
-      const float ga = pweight ? fabsf(pweight[k]) + peps : 1.f, be = pbias ? pbias[k] : 0.f;
-      const float z = ((x[m * K + k] - pmean[k]) * is) * ga + be;
+      const float z = ((x[m * K + k] - ppack[k]) * ppack[K + k]) * ppack[2 * (int64_t)K + k] + ppack[3 * (int64_t)K + k];
       a[m * K + k] = z < 0.f ? 0.f : z;
     }
   const int r = skd_conv1x1_abn_nhwc(M, K, N, a, w, residual, out, mean, var, weight, bias, eps, act, slope, st);

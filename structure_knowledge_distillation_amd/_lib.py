@@ -83,7 +83,8 @@ SIGNATURES = {
     "skd_ppm_concat_backward": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_conv1x1_abn_supported": (_I, [_L, _I, _I]),
     "skd_conv1x1_abn_nhwc": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _P]),
-    "skd_conv1x1_abn_pro_nhwc": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _I, _F, _P]),
+    "skd_abn_pack_eval_params": (_I, [_I, _P, _P, _P, _P, _F, _P, _P]),
+    "skd_conv1x1_abn_pro_nhwc": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _F, _P]),
     "skd_pairwise_small": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "skd_cs_transform": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _P]),
     "skd_ppm_nhwc_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I, _P]),

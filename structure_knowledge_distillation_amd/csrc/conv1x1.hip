@@ -10,13 +10,18 @@
 // into the weights and checkpoints / state-dict semantics are untouched.
 //
 // Kernel: 128 x 128 output tile per 256-thread workgroup (4 waves, each 64 x 64 = 2 x 2 v_mfma_f32_32x32x2_f32 blocks:
-// exact fp32, 64 accumulator registers), K streamed in tiles of 32 through a double-buffered LDS ring.  Both operands are
+// exact fp32, 64 accumulator registers), K streamed in tiles of 16 through a double-buffered LDS ring.  Both operands are
 // K-contiguous in memory (activations channels-last, weights (N, K, 1, 1)), and they stay K-contiguous in LDS: rows of
-// 32 + 4 floats, so a lane fetches FOUR consecutive k of its row with one conflict-free ds_read_b128 (row stride 36
-// floats spreads 16 lanes x 16 bytes over all 64 banks) and feeds four MFMAs from it -- the MFMA's two k-slots
-// (lanes 0-31 / 32-63) are simply assigned k = 0..3 and k = 4..7 of each group of eight, identically for A and B.
-// Per 8 k: 4 ds_read_b128 -> 16 MFMAs (1024 matrix-pipe cycles); per K-tile and thread 8 global float4 loads and 8
-// ds_write_b128.  73.7 KB of LDS per workgroup -> 2 workgroups (2 waves per SIMD) per CU.
+// 16 + 4 floats, so a lane fetches FOUR consecutive k of its row with one conflict-free ds_read_b128 (row stride 20
+// floats puts the 16 lanes of each of the instruction's four lane groups on 16 distinct 4-bank slots) and feeds four MFMAs
+// from it -- the MFMA's two k-slots (lanes 0-31 / 32-63) are simply assigned k = 0..3 and k = 4..7 of each group of eight,
+// identically for A and B.  Per 8 k: 4 ds_read_b128 -> 16 MFMAs (1024 matrix-pipe cycles), the reads of the next group issued
+// after the first four MFMAs of the current one (sched_group_barrier); per K-tile and thread 4 global float4 loads and 4
+// ds_write_b128.  41 KB of LDS per workgroup, <= 168 VGPRs -> 3 workgroups (3 waves per SIMD) per CU.
+// Measured decomposition of the main loop (tools/gemm_lab variants, profiles/r03f/g_*): LDS reads cost nothing, LDS writes +
+// barrier 4 %, the global loads 13 % (two tiles of look-ahead do not help: not latency); an MFMA-only loop with this tile
+// shape and epilogue reaches 0.60-0.86 of the nominal 157.3 TFLOP/s depending on how well M x N / (128 x 128) divides the
+// 256 CUs and on the sustained clock.
 // Bound: fp32 MFMA (157.3 TFLOP/s); algorithmic flops 2*M*N*K; epilogue traffic 4*M*N (+ 4*M*N residual) bytes.
 #include "skd_common.hpp"
 
@@ -25,9 +30,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTM = 128, kTN = 128, kBK = 32, kLDK = kBK + 4;
-constexpr int kStageFloats = (kTM + kTN) * kLDK;           // 9216 floats = 36,864 bytes
+// K-tile 16 (round 3, tools/gemm_lab variants 0 / 5, profiles/r03f_gemm_lab_variants.jsonl): the same speed as 32 on the long-K
+// problems and +7 % at K = 256 -- half the LDS per workgroup, so THREE workgroups (12 waves) share a CU and the prologue /
+// epilogue of one tile hides behind two neighbours' MFMAs instead of one.
+constexpr int kTM = 128, kTN = 128, kBK = 16, kLDK = kBK + 4, kMinWG = 3;
+constexpr int kQK = kBK / 4;                               // float4 per panel row
+constexpr int kRPP = kThreads / kQK;                       // panel rows covered by one pass of the workgroup (64)
+constexpr int kRA = kTM / kRPP, kRB = kTN / kRPP;          // float4 per thread, operand and K-tile (2 + 2)
+constexpr int kStageFloats = (kTM + kTN) * kLDK;           // 5120 floats = 20,480 bytes
 constexpr size_t kConvLds = sizeof(float) * 2 * kStageFloats;
+constexpr int kProMaxK = 512;                             // prologue form: the (4, K) parameter table rides in LDS (<= 8 KB)
 
 __device__ __forceinline__ float inv_std_of(float var, float eps) { return (var != 0.f || eps != 0.f) ? 1.f / sqrtf(var + eps) : 0.f; }
 
@@ -35,28 +47,20 @@ __device__ __forceinline__ float inv_std_of(float var, float eps) { return (var 
 // to LDS.  The loads are issued at the top of a trip, the LDS stores after the trip's MFMAs (a whole K-tile of matrix-pipe
 // time for them to land), the staging registers are not loop-carried (nothing for the compiler to copy).
 struct Staging {
-  float4 a[4], b[4];
+  float4 a[kRA], b[kRB];
 };
-struct ProParams {         // PRO: the k quad's mean / var / weight / bias of the BatchNorm applied to A on the way in
-  float4 pm, pv, pw, pb;   // (kept apart from Staging: a struct with members that one instantiation never writes stayed in scratch)
+struct ProParams {         // PRO: the k quad's mean / invstd / gamma / beta of the BatchNorm applied to A on the way in
+  float4 pm, pi, pg, pb;   // (kept apart from Staging: a struct with members that one instantiation never writes stayed in scratch)
 };
 
 template <bool PRO>
-__device__ __forceinline__ void stage_load(Staging &s, ProParams &pp, const float *__restrict__ X, const float *__restrict__ Wt, int k0,
-                                           int gkq, const int64_t (&arow)[4], int64_t wrow0, int K,
-                                           const float *__restrict__ pmean, const float *__restrict__ pvar,
-                                           const float *__restrict__ pweight, const float *__restrict__ pbias) {
+__device__ __forceinline__ void stage_load(Staging &s, const float *__restrict__ X, const float *__restrict__ Wt, int k0,
+                                           int gkq, const int64_t (&arow)[kRA], int64_t wrow0, int K) {
   const float *xa = X + k0 + gkq, *wb = Wt + k0 + gkq;
 #pragma unroll
-  for (int h = 0; h < 4; ++h) s.a[h] = *reinterpret_cast<const float4 *>(xa + arow[h]);
+  for (int h = 0; h < kRA; ++h) s.a[h] = *reinterpret_cast<const float4 *>(xa + arow[h]);
 #pragma unroll
-  for (int h = 0; h < 4; ++h) s.b[h] = *reinterpret_cast<const float4 *>(wb + wrow0 + (int64_t)(32 * h) * K);
-  if (PRO) {
-    pp.pm = *reinterpret_cast<const float4 *>(pmean + k0 + gkq);
-    pp.pv = *reinterpret_cast<const float4 *>(pvar + k0 + gkq);
-    pp.pw = pweight != nullptr ? *reinterpret_cast<const float4 *>(pweight + k0 + gkq) : make_float4(1.f, 1.f, 1.f, 1.f);
-    pp.pb = pbias != nullptr ? *reinterpret_cast<const float4 *>(pbias + k0 + gkq) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int h = 0; h < kRB; ++h) s.b[h] = *reinterpret_cast<const float4 *>(wb + wrow0 + (int64_t)(kRPP * h) * K);
 }
 
 // relu(bn(x)) with the expression of abn_apply (bn.cu:146-159 + ReLU): ((x - mean) * invstd) * gamma + beta
@@ -66,27 +70,29 @@ __device__ __forceinline__ float pro_one(float x, float m, float is, float g, fl
 }
 
 template <bool PRO>
-__device__ __forceinline__ void stage_store(const Staging s, const ProParams pp, float *stage, int srow, float peps, bool has_pw) {
+__device__ __forceinline__ void stage_store(const Staging s, float *stage, int srow, const float *ptab, int K, int kq) {
   float *sa = stage + srow, *sb = stage + kTM * kLDK + srow;
-  if (PRO) {
-    const float i0 = inv_std_of(pp.pv.x, peps), i1 = inv_std_of(pp.pv.y, peps), i2 = inv_std_of(pp.pv.z, peps), i3 = inv_std_of(pp.pv.w, peps);
-    const float g0 = has_pw ? fabsf(pp.pw.x) + peps : 1.f, g1 = has_pw ? fabsf(pp.pw.y) + peps : 1.f;
-    const float g2 = has_pw ? fabsf(pp.pw.z) + peps : 1.f, g3 = has_pw ? fabsf(pp.pw.w) + peps : 1.f;
+  if (PRO) {   // ptab (LDS copy of ppack): mean | invstd | gamma | beta, each K floats; kq = first of this thread's four k
+    ProParams pp;
+    pp.pm = *reinterpret_cast<const float4 *>(ptab + kq);
+    pp.pi = *reinterpret_cast<const float4 *>(ptab + K + kq);
+    pp.pg = *reinterpret_cast<const float4 *>(ptab + 2 * K + kq);
+    pp.pb = *reinterpret_cast<const float4 *>(ptab + 3 * K + kq);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    for (int h = 0; h < kRA; ++h) {
       float4 v = s.a[h];
-      v.x = pro_one(v.x, pp.pm.x, i0, g0, pp.pb.x);
-      v.y = pro_one(v.y, pp.pm.y, i1, g1, pp.pb.y);
-      v.z = pro_one(v.z, pp.pm.z, i2, g2, pp.pb.z);
-      v.w = pro_one(v.w, pp.pm.w, i3, g3, pp.pb.w);
-      *reinterpret_cast<float4 *>(sa + 32 * h * kLDK) = v;
+      v.x = pro_one(v.x, pp.pm.x, pp.pi.x, pp.pg.x, pp.pb.x);
+      v.y = pro_one(v.y, pp.pm.y, pp.pi.y, pp.pg.y, pp.pb.y);
+      v.z = pro_one(v.z, pp.pm.z, pp.pi.z, pp.pg.z, pp.pb.z);
+      v.w = pro_one(v.w, pp.pm.w, pp.pi.w, pp.pg.w, pp.pb.w);
+      *reinterpret_cast<float4 *>(sa + kRPP * h * kLDK) = v;
     }
   } else {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(sa + 32 * h * kLDK) = s.a[h];
+    for (int h = 0; h < kRA; ++h) *reinterpret_cast<float4 *>(sa + kRPP * h * kLDK) = s.a[h];
   }
 #pragma unroll
-  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(sb + 32 * h * kLDK) = s.b[h];
+  for (int h = 0; h < kRB; ++h) *reinterpret_cast<float4 *>(sb + kRPP * h * kLDK) = s.b[h];
 }
 
 // One K-tile out of LDS: per group of 8 k four conflict-free ds_read_b128 (a0, a1, b0, b1: FOUR consecutive k of the lane's
@@ -155,12 +161,11 @@ __device__ __forceinline__ void store_block(const f32x16 &acc, const float *__re
 }
 
 template <int ACT, bool HAS_RES, bool PRO>
-__global__ __launch_bounds__(kThreads, 2) void conv1x1_abn_kernel(
+__global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
     const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
-    const float *__restrict__ bias, const float *__restrict__ pmean, const float *__restrict__ pvar,
-    const float *__restrict__ pweight, const float *__restrict__ pbias, float peps, float eps, float slope, int64_t M, int K,
-    int N, int tiles_n) {
+    const float *__restrict__ bias, const float *__restrict__ ppack, float eps, float slope, int64_t M, int K, int N,
+    int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // consecutive workgroups walk the N tiles of one row panel: the 128 x K activation panel is read from HBM once and
   // re-used out of L2 by its tiles_n neighbours; the (N, K) weights stay L2-resident throughout
@@ -176,27 +181,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_abn_kernel(
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
   const int nk = K / kBK;
-  const int gt = threadIdx.x, grow = gt >> 3, gkq = (gt & 7) * 4;
+  const int gt = threadIdx.x, grow = gt / kQK, gkq = (gt % kQK) * 4;
   const int srow = grow * kLDK + gkq;
-  int64_t arow[4];   // rows beyond the matrix are clamped (loaded, multiplied, never stored)
+  int64_t arow[kRA];   // rows beyond the matrix are clamped (loaded, multiplied, never stored)
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    const int64_t m = m0 + grow + 32 * h;
+  for (int h = 0; h < kRA; ++h) {
+    const int64_t m = m0 + grow + kRPP * h;
     arow[h] = (m > M - 1 ? M - 1 : m) * K;
   }
   const int64_t wrow0 = (int64_t)(n0 + grow) * K;
-  const bool has_pw = pweight != nullptr;
+  float *ptab = lds + 2 * kStageFloats;             // PRO: the (4, K) parameter table, K <= kProMaxK
+  if (PRO) {
+    for (int i = gt * 4; i < 4 * K; i += kThreads * 4) *reinterpret_cast<float4 *>(ptab + i) = *reinterpret_cast<const float4 *>(ppack + i);
+    __syncthreads();
+  }
   Staging st;
-  ProParams pp = {};
-  stage_load<PRO>(st, pp, X, Wt, 0, gkq, arow, wrow0, K, pmean, pvar, pweight, pbias);
-  stage_store<PRO>(st, pp, lds, srow, peps, has_pw);
+  stage_load<PRO>(st, X, Wt, 0, gkq, arow, wrow0, K);
+  stage_store<PRO>(st, lds, srow, ptab, K, gkq);
   __syncthreads();
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) stage_load<PRO>(st, pp, X, Wt, (kt + 1) * kBK, gkq, arow, wrow0, K, pmean, pvar, pweight, pbias);
+    if (more) stage_load<PRO>(st, X, Wt, (kt + 1) * kBK, gkq, arow, wrow0, K);
     tile_mma(lds + stage * kStageFloats, acc);
-    if (more) stage_store<PRO>(st, pp, lds + (stage ^ 1) * kStageFloats, srow, peps, has_pw);
+    if (more) stage_store<PRO>(st, lds + (stage ^ 1) * kStageFloats, srow, ptab, K, (kt + 1) * kBK + gkq);
     __syncthreads();
     stage ^= 1;
   }
@@ -221,21 +229,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_abn_kernel(
   }
 }
 
+__global__ void pack_eval_params_kernel(int K, const float *__restrict__ mean, const float *__restrict__ var,
+                                        const float *__restrict__ weight, const float *__restrict__ bias, float eps,
+                                        float *__restrict__ pack) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  pack[k] = mean[k];
+  pack[K + k] = inv_std_of(var[k], eps);
+  pack[2 * (int64_t)K + k] = weight != nullptr ? fabsf(weight[k]) + eps : 1.f;   // bn.cu:153
+  pack[3 * (int64_t)K + k] = bias != nullptr ? bias[k] : 0.f;
+}
+
 template <int ACT, bool HAS_RES, bool PRO>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
-                  const float *weight, const float *bias, const float *pmean, const float *pvar, const float *pweight,
-                  const float *pbias, float peps, float eps, float slope, int64_t M, int K, int N, hipStream_t st) {
+                  const float *weight, const float *bias, const float *ppack, float eps, float slope, int64_t M, int K, int N,
+                  hipStream_t st) {
   static bool ready = false;
   if (!ready) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES, PRO>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvLds) != hipSuccess) return 0;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kConvLds + sizeof(float) * 4 * kProMaxK)) != hipSuccess) return 0;
     ready = true;
   }
+  const size_t lds_bytes = kConvLds + (PRO ? sizeof(float) * 4 * (size_t)K : 0);
   const int tiles_n = N / kTN;
   const int64_t tiles_m = cdiv(M, kTM);
   if (tiles_m * tiles_n > 2147483647) return 0;
-  conv1x1_abn_kernel<ACT, HAS_RES, PRO><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(kThreads), kConvLds, st>>>(
-      X, Wt, R, Y, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, tiles_n);
+  conv1x1_abn_kernel<ACT, HAS_RES, PRO><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(kThreads), lds_bytes, st>>>(
+      X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n);
   return ok();
 }
 
@@ -246,26 +266,22 @@ using namespace skd;
 
 extern "C" {
 
-// 1 when the fused kernel takes the problem (K a multiple of 32, N a multiple of 128), 0 when the caller must run
+// 1 when the fused kernel takes the problem (K a multiple of 16, N a multiple of 128), 0 when the caller must run
 // the convolution and the ABN pass separately.
 int skd_conv1x1_abn_supported(int64_t M, int K, int N) { return M > 0 && K > 0 && N > 0 && K % kBK == 0 && N % kTN == 0; }
 
 static int conv1x1_dispatch(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
-                            const float *mean, const float *var, const float *weight, const float *bias, const float *pmean,
-                            const float *pvar, const float *pweight, const float *pbias, float peps, float eps, int activation,
-                            float slope, skd_stream_t stream) {
+                            const float *mean, const float *var, const float *weight, const float *bias, const float *ppack,
+                            float eps, int activation, float slope, skd_stream_t stream) {
   if (!skd_conv1x1_abn_supported(M, K, N) || !x || !w || !out || !mean || !var) return 0;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return 0;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(ppack)) & 15) return 0;
   hipStream_t st = as_stream(stream);
-  const bool pro = pmean != nullptr;
-  if (pro && (!pvar || ((reinterpret_cast<uintptr_t>(pmean) | reinterpret_cast<uintptr_t>(pvar) | reinterpret_cast<uintptr_t>(pweight) |
-                         reinterpret_cast<uintptr_t>(pbias)) & 15))) return 0;
-#define SKD_C11(A)                                                                                                                       \
-  if (pro)                                                                                                                               \
-    return residual ? launch<A, true, true>(x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, st)  \
-                    : launch<A, false, true>(x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, slope, M, K, N, st); \
-  return residual ? launch<A, true, false>(x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps, slope, M, K, N, st) \
-                  : launch<A, false, false>(x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps, slope, M, K, N, st)
+#define SKD_C11(A)                                                                                                        \
+  if (ppack != nullptr)                                                                                                   \
+    return residual ? launch<A, true, true>(x, w, residual, out, mean, var, weight, bias, ppack, eps, slope, M, K, N, st)   \
+                    : launch<A, false, true>(x, w, residual, out, mean, var, weight, bias, ppack, eps, slope, M, K, N, st); \
+  return residual ? launch<A, true, false>(x, w, residual, out, mean, var, weight, bias, nullptr, eps, slope, M, K, N, st) \
+                  : launch<A, false, false>(x, w, residual, out, mean, var, weight, bias, nullptr, eps, slope, M, K, N, st)
   switch (activation) {
     case SKD_ACT_NONE: SKD_C11(SKD_ACT_NONE);
     case SKD_ACT_RELU: SKD_C11(SKD_ACT_RELU);
@@ -278,22 +294,27 @@ static int conv1x1_dispatch(int64_t M, int K, int N, const float *x, const float
 int skd_conv1x1_abn_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                          const float *mean, const float *var, const float *weight, const float *bias, float eps,
                          int activation, float slope, skd_stream_t stream) {
-  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, nullptr, nullptr, nullptr, nullptr, 0.f, eps,
-                          activation, slope, stream);
+  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, nullptr, eps, activation, slope, stream);
+}
+
+// pack (4, K) = [mean | invstd(var, eps) | |weight| + eps (1 when NULL) | bias (0 when NULL)]: the per-channel constants of an
+// eval-mode InPlace-ABN (bn.cu:146-159) in the form the prologue below consumes.  A frozen network computes it once.
+int skd_abn_pack_eval_params(int K, const float *mean, const float *var, const float *weight, const float *bias, float eps,
+                             float *pack, skd_stream_t stream) {
+  if (K <= 0 || !mean || !var || !pack) return 0;
+  pack_eval_params_kernel<<<dim3((unsigned)cdiv(K, 256)), dim3(256), 0, as_stream(stream)>>>(K, mean, var, weight, bias, eps, pack);
+  return ok();
 }
 
 // The same GEMM with the PRECEDING eval-mode BatchNorm + ReLU applied to x on the way into LDS:
-//   a[m][k] = relu(((x[m][k] - pmean[k]) * invstd(pvar[k])) * (|pweight[k]| + peps) + pbias[k])
+//   a[m][k] = relu(((x[m][k] - mean_k) * invstd_k) * gamma_k + beta_k),   (mean | invstd | gamma | beta) = ppack (4, K)
 // (networks/pspnet_combine.py:71-75: conv2 -> bn2 -> relu -> conv3 -> bn3 -> + residual -> relu): x is the raw output of the
-// 3x3 convolution, neither ABN pass of the block tail exists any more.  pmean / pvar (K floats, 16-byte aligned) are required,
-// pweight / pbias may be NULL.
+// 3x3 convolution, neither ABN pass of the block tail exists any more.  ppack: skd_abn_pack_eval_params, 16-byte aligned.
 int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const float *w, const float *residual, float *out,
                              const float *mean, const float *var, const float *weight, const float *bias, float eps,
-                             const float *pmean, const float *pvar, const float *pweight, const float *pbias, float peps,
-                             int activation, float slope, skd_stream_t stream) {
-  if (!pmean || !pvar) return 0;
-  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, pmean, pvar, pweight, pbias, peps, eps, activation,
-                          slope, stream);
+                             const float *ppack, int activation, float slope, skd_stream_t stream) {
+  if (!ppack || K > kProMaxK) return 0;
+  return conv1x1_dispatch(M, K, N, x, w, residual, out, mean, var, weight, bias, ppack, eps, activation, slope, stream);
 }
 
 }  // extern "C"

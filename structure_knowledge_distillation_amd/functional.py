@@ -430,7 +430,7 @@ def conv1x1_bn_blas(x, conv, bn, relu):
 
 def conv1x1_abn_supported(x, conv):
     """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
-    input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 32 and Cout of 128."""
+    input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 16 and Cout of 128."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         return False
     if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
@@ -440,12 +440,30 @@ def conv1x1_abn_supported(x, conv):
     return bool(_lib.get().skd_conv1x1_abn_supported(m, conv.in_channels, conv.out_channels))
 
 
+def abn_pack_eval_params(bn):
+    """(4, C) = [running_mean | 1 / sqrt(running_var + eps) | |weight| + eps | bias] of an eval-mode InPlace-ABN module (the
+    constants of bn.cu:146-159), cached on the module and rebuilt when any of its tensors is written (their autograd version
+    counters) or moved: the frozen teacher packs each BatchNorm once."""
+    key = tuple((t.data_ptr(), t._version) if t is not None else None
+                for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias)) + (float(bn.eps),)
+    cached = getattr(bn, "_skd_eval_pack", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    c = bn.running_mean.numel()
+    pack = bn.running_mean.new_empty((4, c))
+    _lib.check(_lib.get().skd_abn_pack_eval_params(c, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _lib.ptr(bn.weight),
+                                                   _lib.ptr(bn.bias), float(bn.eps), pack.data_ptr(), _lib.stream_of(pack)),
+               "skd_abn_pack_eval_params")
+    bn._skd_eval_pack = (key, pack)
+    return pack
+
+
 def conv1x1_abn_eval(x, conv_weight, running_mean, running_var, weight, bias, eps=1e-5, activation="relu", slope=0.01,
                      residual=None, pro=None):
     """act(bn_running(conv1x1(x)) [+ residual]) as ONE fp32-MFMA GEMM with the normalisation in its epilogue (inference
     only; networks/pspnet_combine.py:65-84 for the frozen teacher).  x (B, Cin, H, W) and residual / result
     (B, Cout, H, W) in channels-last memory; conv_weight (Cout, Cin, 1, 1).
-    ``pro`` = (running_mean, running_var, weight, bias, eps) of an eval-mode BatchNorm + ReLU that PRECEDES the convolution
+    ``pro`` = ``abn_pack_eval_params(bn)`` of an eval-mode BatchNorm + ReLU that PRECEDES the convolution
     (bn2 -> relu -> conv3, pspnet_combine.py:71-75): applied to x on its way into the GEMM, x itself is left untouched."""
     if torch.is_grad_enabled() and (x.requires_grad or conv_weight.requires_grad):
         raise RuntimeError("conv1x1_abn_eval is inference-only")
@@ -462,13 +480,13 @@ def conv1x1_abn_eval(x, conv_weight, running_mean, running_var, weight, bias, ep
     if not wt.is_contiguous():
         wt = wt.contiguous()
     if pro is not None:
-        pm, pv, pw, pb, peps = pro
-        _lib.require_device(pm, pv, pw, pb)
+        _lib.require_device(pro)
+        if pro.dtype != torch.float32 or tuple(pro.shape) != (4, k) or not pro.is_contiguous():
+            raise ValueError("pro must be the (4, Cin) fp32 pack of abn_pack_eval_params")
         _lib.check(_lib.get().skd_conv1x1_abn_pro_nhwc(b * h * w, k, n, x.data_ptr(), wt.data_ptr(), _lib.ptr(residual), out.data_ptr(),
                                                        running_mean.data_ptr(), running_var.data_ptr(), _lib.ptr(weight),
-                                                       _lib.ptr(bias), float(eps), pm.data_ptr(), pv.data_ptr(), _lib.ptr(pw),
-                                                       _lib.ptr(pb), float(peps), act, float(slope), _lib.stream_of(x)),
-                   "skd_conv1x1_abn_pro_nhwc")
+                                                       _lib.ptr(bias), float(eps), pro.data_ptr(), act, float(slope),
+                                                       _lib.stream_of(x)), "skd_conv1x1_abn_pro_nhwc")
         return out
     _lib.check(_lib.get().skd_conv1x1_abn_nhwc(b * h * w, k, n, x.data_ptr(), wt.data_ptr(), _lib.ptr(residual), out.data_ptr(),
                                                running_mean.data_ptr(), running_var.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),

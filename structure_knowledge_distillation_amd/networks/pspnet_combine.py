@@ -110,7 +110,7 @@ class Bottleneck(nn.Module):
             else:
                 out = self.bn1.forward_relu(self.conv1(x))
             c2 = self.conv2(out)
-            tail = (not self.training and _fused_tail(x) and SF.conv1x1_abn_supported(c2, self.conv3)
+            tail = (not self.training and _fused_tail(x) and SF.conv1x1_abn_supported(c2, self.conv3) and self.conv3.in_channels <= 512
                     and getattr(self.bn2, "activation", None) == "none" and getattr(self.bn3, "activation", None) == "none")
             if not tail:
                 out = self.bn2.forward_relu(c2)
@@ -124,7 +124,7 @@ class Bottleneck(nn.Module):
             if tail:
                 return SF.conv1x1_abn_eval(c2, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
                                            self.bn3.bias, self.bn3.eps, "relu", residual=residual,
-                                           pro=(self.bn2.running_mean, self.bn2.running_var, self.bn2.weight, self.bn2.bias, self.bn2.eps))
+                                           pro=SF.abn_pack_eval_params(self.bn2))
             if gemm and SF.conv1x1_abn_supported(out, self.conv3):
                 return SF.conv1x1_abn_eval(out, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
                                            self.bn3.bias, self.bn3.eps, "relu", residual=residual)

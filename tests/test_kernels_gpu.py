@@ -876,8 +876,8 @@ def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
     assert ref.skd_conv1x1_abn_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, act, 0.01, None)
     assert hip.skd_conv1x1_abn_nhwc(M, K, N, P(gpu(x)), P(gpu(w)), P(gpu(r)), P(o_g), P(gpu(mean)), P(gpu(var)), P(gpu(ga)), P(gpu(be)), 1e-5, act, 0.01, None)
     close(o_g, o_r, 2e-5, "conv1x1+abn")
-    assert hip.skd_conv1x1_abn_supported(M, K, N) == 1 and hip.skd_conv1x1_abn_supported(M, K + 16, N) == 0 and hip.skd_conv1x1_abn_supported(M, K, N + 64) == 0
-    assert hip.skd_conv1x1_abn_nhwc(M, K + 16, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
+    assert hip.skd_conv1x1_abn_supported(M, K, N) == 1 and hip.skd_conv1x1_abn_supported(M, K + 8, N) == 0 and hip.skd_conv1x1_abn_supported(M, K, N + 64) == 0
+    assert hip.skd_conv1x1_abn_nhwc(M, K + 8, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 96, 256), (129, 512, 2048)])
@@ -894,13 +894,17 @@ def test_conv1x1_abn_gemm_with_bn_relu_prologue(hip, ref, M, K, N, with_res, aff
     pm, pv = torch.randn(K, generator=g) * 0.5, torch.rand(K, generator=g) + 0.5
     pw, pb = (torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.5) if affine else (None, None)
     o_r, o_g = torch.empty(M, N), torch.full((M, N), 7.0, device=DEV)
-    assert ref.skd_conv1x1_abn_pro_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, P(pm), P(pv), P(pw), P(pb), 1e-5, 3, 0.01, None)
+    pk_r, pk_g = torch.empty(4, K), torch.empty(4, K, device=DEV)
+    assert ref.skd_abn_pack_eval_params(K, P(pm), P(pv), P(pw), P(pb), 1e-5, P(pk_r), None)
+    assert hip.skd_abn_pack_eval_params(K, P(gpu(pm)), P(gpu(pv)), P(gpu(pw)), P(gpu(pb)), 1e-5, P(pk_g), None)
+    assert torch.equal(pk_g.cpu()[0], pm) and torch.equal(pk_g.cpu(), pk_r)          # correctly rounded sqrt / divide on both sides
+    assert ref.skd_conv1x1_abn_pro_nhwc(M, K, N, P(x), P(w), P(r), P(o_r), P(mean), P(var), P(ga), P(be), 1e-5, P(pk_r), 3, 0.01, None)
     xg = gpu(x)
     assert hip.skd_conv1x1_abn_pro_nhwc(M, K, N, P(xg), P(gpu(w)), P(gpu(r)), P(o_g), P(gpu(mean)), P(gpu(var)), P(gpu(ga)), P(gpu(be)), 1e-5,
-                                        P(gpu(pm)), P(gpu(pv)), P(gpu(pw)), P(gpu(pb)), 1e-5, 3, 0.01, None)
+                                        P(pk_g), 3, 0.01, None)
     close(o_g, o_r, 3e-5, "bn+relu -> conv1x1 -> abn")
     assert torch.equal(xg.cpu(), x)
-    assert hip.skd_conv1x1_abn_pro_nhwc(M, K, N, P(xg), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, None, None, None, None, 1e-5, 3, 0.01, None) == 0
+    assert hip.skd_conv1x1_abn_pro_nhwc(M, K, N, P(xg), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, None, 3, 0.01, None) == 0
 
 
 def test_teacher_bottleneck_fused_tail_equals_unfused(monkeypatch):

@@ -234,6 +234,19 @@ static void conv_cases() {
       run_case(std::string("conv1x1_abn ") + tag, flops, bytes,
                [&] { skd_conv1x1_abn_nhwc(s.M, s.K, s.N, x, w, s.res ? r : nullptr, out, mean, var, gam, bet, eps, SKD_ACT_RELU, 0.f, nullptr); }, ex);
     }
+    if (s.res && skd_conv1x1_abn_supported(s.M, s.K, s.N)) {   // with the preceding BN + ReLU applied to x on the way in (timing only:
+      std::vector<float> hpv;                                    // parity is tests/test_kernels_gpu.py's job)
+      float *pm = dev_random(s.K, 0.2f), *pv = dev_random(s.K, 0.4f, &hpv), *pw = dev_random(s.K, 1.f), *pb = dev_random(s.K, 0.5f);
+      for (float &v : hpv) v = fabsf(v) + 0.3f;
+      CK(hipMemcpy(pv, hpv.data(), s.K * sizeof(float), hipMemcpyHostToDevice));
+      float *pk = dev_empty((size_t)4 * s.K);
+      skd_abn_pack_eval_params(s.K, pm, pv, pw, pb, eps, pk, nullptr);
+      run_case(std::string("conv1x1_abn_pro ") + tag, flops, bytes, [&] {
+        skd_conv1x1_abn_pro_nhwc(s.M, s.K, s.N, x, w, r, out, mean, var, gam, bet, eps, pk, SKD_ACT_RELU, 0.f, nullptr);
+      });
+      CK(hipDeviceSynchronize());
+      for (float *p : {pm, pv, pw, pb, pk}) CK(hipFree(p));
+    }
     {  // hipBLASLt, BN folded into the weights and a bias: w' = w * gamma / sigma, b' = beta - mean * gamma / sigma
       std::vector<float> wf((size_t)s.N * s.K), bf(s.N);
       for (int n = 0; n < s.N; ++n) {

@@ -19,16 +19,20 @@ struct Stg {
   float4 a[RA], b[RB];
 };
 
-template <int RA, int RB, int RPP>
+template <int RA, int RB, int RPP, int SEL = 3>
 __device__ __forceinline__ void lab_gload(Stg<RA, RB> &o, const float *__restrict__ X, const float *__restrict__ Wt, int64_t m0, int grow, int gkq,
                                           int64_t wrow0, int64_t M, int K, int k0) {
+  if (SEL & 1) {
 #pragma unroll
-  for (int h = 0; h < RA; ++h) {
-    const int64_t m = m0 + grow + RPP * h;
-    o.a[h] = *reinterpret_cast<const float4 *>(X + (m > M - 1 ? M - 1 : m) * K + k0 + gkq);
+    for (int h = 0; h < RA; ++h) {
+      const int64_t m = m0 + grow + RPP * h;
+      o.a[h] = *reinterpret_cast<const float4 *>(X + (m > M - 1 ? M - 1 : m) * K + k0 + gkq);
+    }
   }
+  if (SEL & 2) {
 #pragma unroll
-  for (int h = 0; h < RB; ++h) o.b[h] = *reinterpret_cast<const float4 *>(Wt + wrow0 + (int64_t)(RPP * h) * K + k0 + gkq);
+    for (int h = 0; h < RB; ++h) o.b[h] = *reinterpret_cast<const float4 *>(Wt + wrow0 + (int64_t)(RPP * h) * K + k0 + gkq);
+  }
 }
 template <int RA, int RB, int RPP, int LDK, int TM>
 __device__ __forceinline__ void lab_sstore(const Stg<RA, RB> v, float *stage, int srow) {
@@ -123,14 +127,35 @@ __global__ __launch_bounds__(256, MINWG) void tn_gemm_kernel(const float *__rest
           for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
     }
   } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 1 < nk;
-      if (MODE == 0 && more) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
-      mma(lds + stage * STAGE);
-      if (MODE <= 1) {
-        if (more) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
+    if (MODE == 6) {
+      // two K-tiles ahead: st holds tile kt + 1 (already loaded), st2 receives tile kt + 2 while tile kt is multiplied
+      Stg<RA, RB> st2;
+      if (nk > 1) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, BK);
+      for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st2, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 2) * BK);
+        mma(lds + stage * STAGE);
+        if (kt + 1 < nk) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
         __syncthreads();
         stage ^= 1;
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 3) * BK);
+        mma(lds + stage * STAGE);
+        if (kt + 2 < nk) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st2, lds + (stage ^ 1) * STAGE, srow);
+        __syncthreads();
+        stage ^= 1;
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (MODE == 0 && more) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+        if (MODE == 4 && more) lab_gload<RA, RB, ROWS_PER_PASS, 1>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+        if (MODE == 5 && more) lab_gload<RA, RB, ROWS_PER_PASS, 2>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+        mma(lds + stage * STAGE);
+        if (MODE != 2) {
+          if (more) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
+          __syncthreads();
+          stage ^= 1;
+        }
       }
     }
   }
@@ -181,6 +206,9 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 7: return launch_tn<32, 2, 4, 1, 0>(X, Wt, Y, M, K, N);    // 128 x 256 tile, wave tile 64 x 128
     case 8: return launch_tn<16, 4, 4, 1, 0>(X, Wt, Y, M, K, N);    // 256 x 256 x 16, wave tile 128 x 128 (256 accumulator registers)
     case 9: return launch_tn<32, 2, 2, 1, 0>(X, Wt, Y, M, K, N);    // shipped tile, 1 workgroup / CU allowed to use 512 registers
+    case 10: return launch_tn<32, 2, 2, 2, 4>(X, Wt, Y, M, K, N);   // only the A operand is loaded in the loop
+    case 11: return launch_tn<32, 2, 2, 2, 5>(X, Wt, Y, M, K, N);   // only the B operand
+    case 12: return launch_tn<32, 2, 2, 2, 6>(X, Wt, Y, M, K, N);   // loads issued two K-tiles ahead (two staging register sets)
     default: return -1;
   }
 }
@@ -188,6 +216,7 @@ extern "C" const char *lab_tn_name(int variant) {
   static const char *names[] = {"128x128x32 2wg/cu",          "128x128x32 no-gload",       "128x128x32 no-gload no-lds-write",
                                 "128x128x32 mfma-only",       "128x128x16 4wg/cu",         "128x128x16 3wg/cu",
                                 "256x128x32 1wg/cu",          "128x256x32 1wg/cu",         "256x256x16 1wg/cu",
-                                "128x128x32 1wg/cu"};
-  return variant >= 0 && variant < 10 ? names[variant] : nullptr;
+                                "128x128x32 1wg/cu",          "128x128x32 no-gload-B",     "128x128x32 no-gload-A",
+                                "128x128x32 2wg/cu 2-ahead"};
+  return variant >= 0 && variant < 13 ? names[variant] : nullptr;
 }
