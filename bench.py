@@ -13,9 +13,11 @@ train_and_eval.py:26.  N > 1: one process per GPU, weak scaling (8 images per ra
 all-reduce + cross-GPU InPlaceABNSync.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant hand-written kernel (abn_apply_kernel: normalise + affine + activation,
-                in place, 8 algorithmic bytes per element), timed live with HIP events on the launch
-                stream over the timed steps
+  roofline      the dominant hand-written kernel of the step, timed live with HIP events on the launch stream over the
+                timed steps: since round 3 the fused bottleneck-tail GEMM of the frozen teacher (conv1x1_abn_kernel:
+                bn2 + ReLU prologue, 1x1 convolution on fp32 MFMA, bn3 + residual + ReLU epilogue; 2*M*K*N algorithmic
+                flops per launch, bound "mfma"); with SKD_TEACHER_TAIL=0 the eval-mode ABN apply pass (8 algorithmic
+                bytes per element, bound "hbm") as in rounds 1-2
   kernels       the same measurement for the other hand-written kernels / kernel chains
   cpu_baseline  the CPU oracle (oracle/step_torch.py, a port of the reference step pinned to the
                 reference's own Python) timed on this host's cores on a bounded sample
@@ -159,6 +161,40 @@ def abn_pmc_ratio(case_prefix):
     return None
 
 
+def summarise_gemm(recs):
+    """[(ms, (M, K, N, x))] of the fused 1x1-convolution GEMM -> TFLOP/s over all launches (sum of 2*M*K*N / sum of time)
+    and per problem shape."""
+    if not recs:
+        return None
+    tot_ms = sum(ms for ms, _ in recs)
+    tot_f = sum(2.0 * d[0] * d[1] * d[2] for _, d in recs)
+    shapes = {}
+    for ms, d in recs:
+        e = shapes.setdefault((d[0], d[1], d[2]), [0, 0.0])
+        e[0] += 1
+        e[1] += ms
+    return {"launches": len(recs), "total_ms": round(tot_ms, 3), "avg_us": round(1e3 * tot_ms / len(recs), 2),
+            "achieved_TFLOPs": round(tot_f / (tot_ms * 1e-3) / 1e12, 2),
+            "per_shape": {"M=%d K=%d N=%d" % k: {"launches": n, "avg_us": round(1e3 * ms / n, 2),
+                                                  "TFLOPs": round(2.0 * k[0] * k[1] * k[2] / (ms / n * 1e-3) / 1e12, 2)}
+                          for k, (n, ms) in shapes.items()}}
+
+
+def gemm_pmc_traffic():
+    """HBM bytes per launch of conv1x1_abn_kernel from the committed counter passes over tools/gemm_lab
+    (profiles/*_gemm_lab_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, summarised by tools/summarise_lab_pmc.py)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_lab_pmc.json")), reverse=True):
+        try:
+            rows = [r for r in json.load(open(path)) if r["kernel"].startswith("conv1x1_abn_kernel<3, true") and "hbm_read_MB" in r]
+            if rows:
+                r = max(rows, key=lambda r: r.get("sq_insts_mfma", 0) if r["grid"] == 542720 else -1)
+                return {"MB": round(r["hbm_read_MB"] + r["hbm_write_MB"], 2), "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def summarise(recs, bytes_per_elem, nhwc=False):
     """[(ms, first four C-ABI args)] -> achieved GB/s over all launches (sum of algorithmic bytes / sum of time).
     NCHW entries: args = (N, C, S, ...); skd_abn_apply_nhwc: args = (rows, C, x, residual) with 8 B/element, 12 with
@@ -230,13 +266,15 @@ def main():
              "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx",
              "skd_abn_forward_train_nhwc", "skd_abn_backward_reduce_nhwc", "skd_abn_backward_dx_nhwc",
              "skd_abn_relu_backward_reduce_nhwc", "skd_abn_relu_backward_dx_nhwc",
-             "skd_abn_relu_backward_reduce_nhwc_x", "skd_abn_relu_backward_dx_nhwc_x"]
+             "skd_abn_relu_backward_reduce_nhwc_x", "skd_abn_relu_backward_dx_nhwc_x", "skd_abn_backward_nhwc",
+             "skd_abn_relu_backward_nhwc"]
     # Inside the timed region only the ROOFLINE entry is bracketed with HIP events (111 calls per step; bracketing all
     # ~700 hand-written calls costs 1.4 ms = 1.8 % of the step -- measured, profiles/r02 notes); the table of the other
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
     roofline_entry = "skd_abn_apply_nhwc"
+    gemm_entry = "skd_conv1x1_abn_pro_nhwc"
     if not a.no_kernel_timing and rank == 0:
-        _lib.enable_kernel_timing([roofline_entry])
+        _lib.enable_kernel_timing([roofline_entry, gemm_entry])
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -252,7 +290,7 @@ def main():
         # compute stream spends blocked on collectives (P.comm_timer: SyncABN exchanges, gradient all-reduce waits).
         d_stream, model._d_stream = model._d_stream, None
         if rank == 0:
-            _lib.enable_kernel_timing([n for n in timed if n != roofline_entry])
+            _lib.enable_kernel_timing([n for n in timed if n not in (roofline_entry, gemm_entry)])
             if world > 1:
                 P.comm_timer.enable()
         for i in range(3):
@@ -295,7 +333,23 @@ def main():
     line["step_tflop_per_image"] = {"reference_algorithm": STEP_TFLOP_PER_IMAGE, "executed": round(executed, 4)}
     line["step_fp32_mfma_frac"] = round(value / world * executed / MFMA_F32_PEAK_TFLOPS, 4)   # executed flops only
     ap = summarise(recs.get(roofline_entry, []), 8, nhwc="apply")
-    if ap:
+    gm = summarise_gemm(recs.get(gemm_entry, []))
+    if gm and (not ap or gm["total_ms"] > ap["launches"] * ap["avg_us"] * 1e-3):
+        # the dominant hand-written kernel since round 3: the frozen teacher's bottleneck tail as ONE fp32-MFMA GEMM
+        line["roofline"] = {"kernel": "conv1x1_abn_kernel<relu, residual, prologue> (skd_conv1x1_abn_pro_nhwc: relu(bn2(x)) applied to the A "
+                                      "operand on the way into LDS, 1x1 convolution on v_mfma_f32_32x32x2_f32, bn3 + residual + ReLU in the "
+                                      "epilogue; algorithmic flops 2*M*K*N per launch, M = B*H*W)",
+                            "bound": "mfma", "achieved": gm["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(gm["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "detail": gm}
+        pmc = gemm_pmc_traffic()
+        if pmc is not None:
+            line["roofline"]["traffic"] = pmc["MB"]
+            line["roofline"]["traffic_unit"] = "MB per launch of the layer-3 problem (M=33800, K=256, N=1024): HBM read + write"
+            line["roofline"]["traffic_source"] = pmc["source"]
+        if ap:
+            line["roofline"]["abn_apply_nhwc (previous dominant kernel, hbm-bound)"] = {
+                "achieved_GBs": ap["achieved_GBs"], "frac_hbm": round(ap["achieved_GBs"] / HBM_PEAK_GBS, 4), "detail": ap}
+    elif ap:
         # the dominant hand-written kernel of the step (3.9 of ~7 ms of InPlace-ABN time): ALL its launches of the timed
         # region, algorithmic bytes = 8 per element (12 with the residual read) x elements of the launch
         line["roofline"] = {"kernel": "abn_apply_nhwc_kernel (skd_abn_apply_nhwc: the frozen teacher's eval-mode InPlace-ABN + ReLU "
@@ -308,7 +362,10 @@ def main():
             line["roofline"]["traffic"] = round(pmc["ratio"] * 8 * ap["avg_elems"] / 1e6, 2)   # avg_elems is byte-weighted
             line["roofline"]["traffic_unit"] = "MB per average launch"
             line["roofline"]["traffic_source"] = pmc["source"]
+    if ap or gm:
         line["kernels"] = {
+            "skd_abn_backward_nhwc (leaky ABN, reduce + dx in one call: 20 B/elem two-pass algorithmic, 12 B/elem when register-resident)": summarise(recs.get("skd_abn_backward_nhwc", []), 20, nhwc="train"),
+            "skd_abn_relu_backward_nhwc (BN+ReLU[+res], reduce + dx in one call: >=20 B/elem two-pass algorithmic)": summarise(recs.get("skd_abn_relu_backward_nhwc", []), 20, nhwc="train"),
             "skd_abn_apply_residual (teacher block tails, 12 B/elem)": summarise(recs.get("skd_abn_apply_residual", []), 12),
             "skd_abn_forward_train (leaky-ReLU ABN: stats+finalize+apply, 12 B/elem)": summarise(recs.get("skd_abn_forward_train", []), 12),
             "skd_abn_backward (leaky-ReLU ABN: reduce+finalize+dx, 20 B/elem)": summarise(recs.get("skd_abn_backward", []), 20),

@@ -38,11 +38,11 @@ def _gemm_tail(x):
 
 
 def _fused_tail(x):
-    """SKD_TEACHER_TAIL=1: the frozen bottleneck's tail conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> relu] as ONE
+    """SKD_TEACHER_TAIL (default 1; 0 = convolution + two in-place ABN passes as in round 2): the frozen bottleneck's tail conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> relu] as ONE
     fp32-MFMA GEMM (csrc/conv1x1.hip, round 3): bn2 + ReLU applied to the raw 3x3-convolution output on its way into LDS,
     bn3 + residual + ReLU in the epilogue -- both InPlace-ABN passes of the block tail (33 + 33 per teacher forward) disappear.
-    Measured A/B: profiles/r03*_tail*.json."""
-    return (os.environ.get("SKD_TEACHER_TAIL", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
+    Measured A/B: profiles/r03c_bench_ab_teacher_tail{0,1}.json (-1.08 ms per step with the first version of the kernel)."""
+    return (os.environ.get("SKD_TEACHER_TAIL", "1") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
 
 
 def _blas_tail(module, x):
