@@ -325,7 +325,7 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     for k, v in out["config"]["losses_last_step"].items():
         assert v == v and abs(v) < 1e6, (k, v)          # finite
     # the N > 1 line explains its own efficiency: roofline stays, comm breakdown added
-    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and out["roofline"]["achieved"] > 0      # mfma: the fused bottleneck-tail GEMM (default)
     comm = out["comm"]
     assert comm["syncabn_collectives"] == 58 and comm["syncabn_ms"] > 0           # 29 training ABN layers, forward + backward
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"

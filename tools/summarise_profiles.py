@@ -20,7 +20,7 @@ P = os.path.join(ROOT, "profiles")
 
 def category(n):
     if "skd::" in n:
-        for key, name in (("abn", "skd InPlace-ABN"), ("maxpool3x3s2", "skd stem max-pool"), ("ppm_fold", "skd PSP bottleneck fold"), ("gram", "skd pair-wise"), ("pairwise", "skd pair-wise"), ("maxpool", "skd pair-wise"),
+        for key, name in (("conv1x1", "skd fused bottleneck-tail GEMM (conv1x1 + ABN)"), ("sync_", "skd SyncABN mailbox exchange"), ("abn", "skd InPlace-ABN"), ("maxpool3x3s2", "skd stem max-pool"), ("ppm_fold", "skd PSP bottleneck fold"), ("gram", "skd pair-wise"), ("pairwise", "skd pair-wise"), ("maxpool", "skd pair-wise"),
                           ("maxunpool", "skd pair-wise"), ("l2_norm", "skd pair-wise"), ("ce_", "skd CE+upsample (DSN)"),
                           ("ppm", "skd pyramid pooling"), ("pixelwise", "skd pixel-wise"), ("sn_", "skd spectral norm")):
             if key in n:
