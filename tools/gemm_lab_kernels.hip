@@ -190,6 +190,102 @@ int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N
   return hipGetLastError() == hipSuccess;
 }
 
+// ---- variant: operands DMA'd straight into LDS (global_load_lds_dwordx4: no VGPR round trip, no ds_write) ------------------
+// A wave-instruction writes 64 x 16 B = 1 KiB of CONTIGUOUS LDS (lane i -> base + 16 i), so the panels are unpadded
+// [128 rows][BK = 16 floats] and the bank spreading that the +4-float row padding gave is done by an XOR swizzle instead:
+// the 16-byte slot (row, q) holds k-quad q ^ ((row >> 2) & 3) -- chosen on the GLOBAL side (each lane picks which 16 bytes of
+// its row it fetches), undone on the read side.  ds_read_b128's 16-lane groups then hit 16 distinct 4-bank slots.
+template <int MINWG>
+__global__ __launch_bounds__(256, MINWG) void tn_gemm_glds_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                                  float *__restrict__ Y, int64_t M, int K, int N, int tiles_n) {
+  constexpr int BK = 16, TM = 128, TN = 128;
+  constexpr int PANEL = TM * BK;                 // floats per operand panel (8 KiB)
+  constexpr int STAGE = 2 * PANEL;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tn = blockIdx.x % tiles_n;
+  const int64_t tm = blockIdx.x / tiles_n;
+  const int64_t m0 = tm * TM;
+  const int n0 = tn * TN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const int nk = K / BK;
+  const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  // DMA geometry: wave w, instruction h in {0, 1} fills slots [(2 w + h) * 64, + 64) of a panel; slot s = (row s / 4, position s % 4)
+  int64_t ga[2], gb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int s = (2 * wid + h) * 64 + lane, row = s >> 2, kq = (s & 3) ^ ((row >> 2) & 3);
+    const int64_t m = m0 + row;
+    ga[h] = (m > M - 1 ? M - 1 : m) * K + 4 * kq;
+    gb[h] = (int64_t)(n0 + row) * K + 4 * kq;
+  }
+  auto dma = [&](float *stage, int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_global_load_lds(X + ga[h] + k0, stage + (2 * wid + h) * 256, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(Wt + gb[h] + k0, stage + PANEL + (2 * wid + h) * 256, 16, 0, 0);
+    }
+  };
+  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int half = lane >> 5, r = lane & 31;
+  const int fr = (r >> 2) & 3;                    // (row >> 2) & 3 of rows wi + r and wi + r + 32 alike
+  auto mma = [&](const float *stage) {
+    const float *pa = stage + (wi + r) * BK, *pb = stage + PANEL + (wj + r) * BK;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      const int q = ((2 * g + half) ^ fr) * 4;
+      const float4 a0 = *reinterpret_cast<const float4 *>(pa + q), a1 = *reinterpret_cast<const float4 *>(pa + 32 * BK + q);
+      const float4 b0 = *reinterpret_cast<const float4 *>(pb + q), b1 = *reinterpret_cast<const float4 *>(pb + 32 * BK + q);
+      const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+  dma(lds, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma(lds + (stage ^ 1) * STAGE, (kt + 1) * BK);
+    mma(lds + stage * STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wj + j * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + wi + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < M) Y[row * N + col] = acc[i][j][q];
+      }
+  }
+}
+
+template <int MINWG>
+int launch_glds(const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
+  constexpr size_t lds = sizeof(float) * 2 * 2 * 128 * 16;      // 32 KiB
+  if (K % 16 || N % 128) return 0;
+  const int tiles_n = N / 128;
+  const int64_t tiles_m = (M + 127) / 128;
+  tn_gemm_glds_kernel<MINWG><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n);
+  return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace lab
 
 // C-callable table for gemm_lab.cpp
@@ -209,6 +305,8 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 10: return launch_tn<32, 2, 2, 2, 4>(X, Wt, Y, M, K, N);   // only the A operand is loaded in the loop
     case 11: return launch_tn<32, 2, 2, 2, 5>(X, Wt, Y, M, K, N);   // only the B operand
     case 12: return launch_tn<32, 2, 2, 2, 6>(X, Wt, Y, M, K, N);   // loads issued two K-tiles ahead (two staging register sets)
+    case 13: return launch_glds<3>(X, Wt, Y, M, K, N);              // global -> LDS DMA, XOR-swizzled unpadded panels, 3 workgroups / CU
+    case 14: return launch_glds<4>(X, Wt, Y, M, K, N);              //   ... 4 workgroups / CU
     default: return -1;
   }
 }
@@ -217,6 +315,6 @@ extern "C" const char *lab_tn_name(int variant) {
                                 "128x128x32 mfma-only",       "128x128x16 4wg/cu",         "128x128x16 3wg/cu",
                                 "256x128x32 1wg/cu",          "128x256x32 1wg/cu",         "256x256x16 1wg/cu",
                                 "128x128x32 1wg/cu",          "128x128x32 no-gload-B",     "128x128x32 no-gload-A",
-                                "128x128x32 2wg/cu 2-ahead"};
-  return variant >= 0 && variant < 13 ? names[variant] : nullptr;
+                                "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu"};
+  return variant >= 0 && variant < 15 ? names[variant] : nullptr;
 }
