@@ -119,7 +119,9 @@ class SyncMailbox:
 
     @classmethod
     def get(cls, group, device):
-        key = id(group) if group is not None else 0
+        # keyed by the group AND its geometry: a process group that was destroyed and re-created (tests, elastic restarts) must not
+        # inherit the mailboxes of its predecessor
+        key = (id(group) if group is not None else 0, world_size(group), rank(group), str(torch.device(device)))
         if key not in cls._by_group:
             cls._by_group[key] = cls._create(group, device)
         return cls._by_group[key]
@@ -157,12 +159,13 @@ class SyncMailbox:
             blob = ctypes.create_string_buffer(b"".join(h for h, _ in everyone), nb * w)
             with on_device():
                 good = bool(lib.skd_sync_connect(ctx, ctypes.cast(blob, ctypes.c_void_p)))
-        if good:                                     # self-test: all-gather of [rank, rank + 0.5] through the mailboxes
-            src = torch.tensor([float(rk), rk + 0.5], device=device)
-            out = torch.full((w, 2), -1.0, device=device)
-            good = bool(lib.skd_sync_all_gather(ctx, 2, src.data_ptr(), out.data_ptr(), _lib.stream_of(src)))
-            want = torch.tensor([[float(r), r + 0.5] for r in range(w)])
-            good = good and torch.equal(out.cpu(), want)
+        if good:                                     # self-test: four all-gathers (both slot parities, growing payloads) of a known pattern
+            for n in (2, 64, 1024, lib.skd_sync_max_floats()):
+                src = (torch.arange(n, dtype=torch.float32) * 0.5 + rk * 4096.0).to(device)
+                out = torch.full((w, n), -1.0, device=device)
+                good = good and bool(lib.skd_sync_all_gather(ctx, n, src.data_ptr(), out.data_ptr(), _lib.stream_of(src)))
+                want = torch.stack([torch.arange(n, dtype=torch.float32) * 0.5 + r * 4096.0 for r in range(w)])
+                good = good and torch.equal(out.cpu(), want)
         verdict = torch.tensor([1.0 if good else 0.0], device=device if dist.get_backend(group) == "nccl" else "cpu")   # gloo: host
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
         if float(verdict) < 1.0:

@@ -2,7 +2,8 @@
     python tools/summarise_lab_pmc.py gpurun_out/<tag> [out.json]
 MFMA-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES-normalised GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs / ...):
 reported simply as SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256) -- busy cycles summed over the CUs' matrix pipes
-per active GPU cycle per CU (the convention of tools/summarise_pmc.py); HBM bytes = FETCH_SIZE / WRITE_SIZE x 32 (gfx950 unit)."""
+per active GPU cycle per CU; multiply by 2 for the convention of tools/summarise_pmc.py (GRBM_GUI_ACTIVE is summed over the 8
+XCCs, the chip has 4 SIMDs per CU); HBM bytes = 2 x FETCH_SIZE KB (reads) and WRITE_SIZE KB (writes)."""
 import collections
 import csv
 import glob
@@ -31,6 +32,7 @@ for (name, grid), d in agg.items():
         row["gpu_cycles"] = gui
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             row["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256.0) , 4)
+            row["mfma_pipe_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 256 * 4), 4)   # tools/summarise_pmc.py convention
         if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
             row["mfma_mops_f32_per_cycle_per_cu"] = round(m["SQ_INSTS_VALU_MFMA_MOPS_F32"] / gui / 256.0, 3)
     wc = m.get("SQ_WAVE_CYCLES")
@@ -41,9 +43,9 @@ for (name, grid), d in agg.items():
         if k in m:
             row[k.lower()] = m[k]
     if "FETCH_SIZE" in m:
-        row["hbm_read_MB"] = round(m["FETCH_SIZE"] * 32 / 1e6 * 2, 2)   # x2: the gfx950 correction of MI355X_MICROARCH.md
+        row["hbm_read_MB"] = round(m["FETCH_SIZE"] * 1024 * 2 / 1e6, 2)   # FETCH_SIZE is in KB; x2: the gfx950 correction of MI355X_MICROARCH.md (as tools/summarise_pmc.py)
     if "WRITE_SIZE" in m:
-        row["hbm_write_MB"] = round(m["WRITE_SIZE"] * 32 / 1e6 * 2, 2)
+        row["hbm_write_MB"] = round(m["WRITE_SIZE"] * 1024 / 1e6, 2)
     rows.append(row)
     print(json.dumps(row))
 if len(sys.argv) > 2:
