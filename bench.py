@@ -187,7 +187,7 @@ def gemm_pmc_traffic():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_lab_pmc.json")), reverse=True):
         try:
             rows = [r for r in json.load(open(path)) if r["kernel"].startswith("conv1x1_abn_kernel<3, true") and "hbm_read_MB" in r
-                    and r["grid"] == 2120 * 256]                       # 265 x 8 tiles of the layer-3 problem
+                    and r["grid"] in (2120 * 256, 2176 * 256)]         # 265 (padded to 272) x 8 tiles of the layer-3 problem
             rows.sort(key=lambda r: r["kernel"].endswith("true, true>"), reverse=True)    # the prologue form when it was profiled
             if rows:
                 r = rows[0]

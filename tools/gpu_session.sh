@@ -150,7 +150,9 @@ EOF
         (cd /tmp && timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/labpmc$i -o k -- $R/tools/gemm_lab pmc 2 > $O/labpmc$i.log 2>&1)
         stamp "lab_pmc pass $i ($set) rc=$?"
         find $O/labpmc$i -name "*kernel_trace.csv" -delete
-      done ;;
+      done
+      python tools/summarise_lab_pmc.py $O $O/gemm_lab_pmc.json > $O/gemm_lab_pmc.log 2>&1
+      stamp "lab_pmc summarised" ;;
     tail_ab)
       for v in "SKD_TEACHER_TAIL=1" "SKD_TEACHER_TAIL=0"; do
         (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
