@@ -164,7 +164,7 @@ int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const f
 /* reduce + dx in ONE call (round 3).  When the tensor fits the chip's register file (rows * C up to ~9.4 M elements) both
  * passes run as a single launch that keeps (y, dz) in VGPRs between them -- 12 instead of 20 bytes per element; larger
  * tensors run the two entries above back to back.  edz / eydz are written as well (16-byte aligned for the one-launch
- * path).  skd_abn_forward_train_nhwc takes the same register-resident route for up to ~18.8 M elements (8 instead of 12
+ * path).  skd_abn_forward_train_nhwc takes the same register-resident route for up to ~17.8 M elements (8 instead of 12
  * bytes per element).  SKD_ABN_FUSED=0 in the environment keeps the two-launch passes.
  * skd_abn_relu_backward_nhwc: out == NULL selects the mask-from-x form (then dres must be NULL). */
 int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,

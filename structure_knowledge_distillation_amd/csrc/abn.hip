@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(kRedThreads) void abn_grad_nhwc2_kernel(
 // The two-launch form above reads x for the statistics, ends the launch, and reads x again for the normalisation:
 // 12 bytes per element, and for the student's 4-70 MB tensors a second launch whose whole life is 8-20 us.  The chip's
 // register file is larger than those tensors (256 CUs x 512 KiB = 128 MiB): a launch of <= 256 workgroups x 1024
-// threads in which a thread keeps its NR <= 18 float4 of x in VGPRs can hold up to ~75 MB.  So:
+// threads in which a thread keeps its NR <= 17 float4 of x in VGPRs can hold up to ~71 MB.  So:
 //   phase 1  every thread loads its rows ONCE, accumulates the shifted sums, red_finish() as before;
 //   hand-off the channel block's last arriver finishes mean / var (+ running statistics), stores them write-through
 //            and bumps the block's generation word; the other workgroups of the block spin (bounded) on that word --
@@ -1752,7 +1752,7 @@ static bool fused_enabled() {
   }
   return mode == 1;
 }
-constexpr int kFuseFwdMaxNR = 18, kFuseBwdMaxNR = 10;
+constexpr int kFuseFwdMaxNR = 17, kFuseBwdMaxNR = 9;
 
 // returns -1 when the call does not take the fused path (not enabled, activation / size not covered), else ok()
 template <bool HAS_RES>
@@ -1770,9 +1770,9 @@ static int launch_fwd_fused(int act, int64_t rows, int C, const float *x, const 
                                                                         running_mean, running_var, weight, bias, rows, f.r, \
                                                                         f.nr, momentum, eps, slope)
 #define SKD_FWD_FUSED_NR(ACT_)                 \
-  if (f.nr <= 6) SKD_FWD_FUSED(ACT_, 6);       \
-  else if (f.nr <= 10) SKD_FWD_FUSED(ACT_, 10); \
-  else SKD_FWD_FUSED(ACT_, 18)
+  if (f.nr <= 5) SKD_FWD_FUSED(ACT_, 5);       \
+  else if (f.nr <= 9) SKD_FWD_FUSED(ACT_, 9);  \
+  else SKD_FWD_FUSED(ACT_, 17)
   if (act == SKD_ACT_RELU) {
     SKD_FWD_FUSED_NR(SKD_ACT_RELU);
   } else if (!HAS_RES && act == SKD_ACT_LEAKY_RELU) {
@@ -1799,14 +1799,16 @@ static int launch_bwd_fused(int64_t rows, int C, const float *a, const float *b,
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
   const dim3 grid((unsigned)(f.r.RG * f.r.CB)), block(kRedThreads);
-  if (f.nr <= 6)
-    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 6><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
+  // instantiations sized to the step's layers (5 rows per thread at C = 128, 9 at C = 64 / 256): one row more and the 18 registers
+  // per row (y, dz) of the NR = 10 form spilled 11-13 of them (PMC: 14.3 instead of 12 bytes per element)
+  if (f.nr <= 5)
+    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 5><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
                                                                                red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
                                                                                eps, slope, rows, f.r, f.nr, accumulate);
   else
-    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 10><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
-                                                                                red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
-                                                                                eps, slope, rows, f.r, f.nr, accumulate);
+    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 9><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
+                                                                               red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
+                                                                               eps, slope, rows, f.r, f.nr, accumulate);
   return ok();
 }
 
