@@ -431,7 +431,8 @@ def conv1x1_bn_blas(x, conv, bn, relu):
 def conv1x1_abn_supported(x, conv):
     """True when the fused 1x1-convolution + eval-ABN GEMM of csrc/conv1x1.hip takes this call: fp32 channels-last
     input, a plain stride-1 1x1 convolution without bias, Cin a multiple of 16 and Cout of 128."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+    if not ((x.is_cuda or _lib.test_backend_active()) and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):      # (CPU tensors only under the tests' C-ABI double)
         return False
     if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
             and conv.bias is None and conv.weight.dtype == torch.float32):
