@@ -42,15 +42,16 @@ __device__ __forceinline__ void lab_sstore(const Stg<RA, RB> v, float *stage, in
   for (int h = 0; h < RB; ++h) *reinterpret_cast<float4 *>(stage + TM * LDK + srow + RPP * h * LDK) = v.b[h];
 }
 
-template <int BK, int WM, int WN, int MINWG, int MODE>
-__global__ __launch_bounds__(256, MINWG) void tn_gemm_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
+template <int BK, int WM, int WN, int MINWG, int MODE, int WVM = 2, int WVN = 2>
+__global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
                                                              float *__restrict__ Y, int64_t M, int K, int N, int tiles_n) {
-  constexpr int TM = 64 * WM, TN = 64 * WN;      // 2 x 2 waves
+  constexpr int NT = 64 * WVM * WVN;             // threads
+  constexpr int TM = 32 * WM * WVM, TN = 32 * WN * WVN;
   constexpr int LDK = BK + 4;
   constexpr int STAGE = (TM + TN) * LDK;
-  constexpr int RA = TM * BK / 4 / 256, RB = TN * BK / 4 / 256;   // float4 per thread and K-tile
+  constexpr int RA = TM * BK / 4 / NT, RB = TN * BK / 4 / NT;     // float4 per thread and K-tile
   constexpr int QK = BK / 4;                                      // float4 per panel row
-  constexpr int ROWS_PER_PASS = 256 / QK;
+  constexpr int ROWS_PER_PASS = NT / QK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tn = blockIdx.x % tiles_n;
   const int64_t tm = blockIdx.x / tiles_n;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, MINWG) void tn_gemm_kernel(const float *__rest
   const int64_t wrow0 = (int64_t)(n0 + grow) * K;
   Stg<RA, RB> st;
   const int lane = t & (kWave - 1), wid = t / kWave;
-  const int wi = (wid >> 1) * 32 * WM, wj = (wid & 1) * 32 * WN;
+  const int wi = (wid / WVN) * 32 * WM, wj = (wid % WVN) * 32 * WN;
   const int half = lane >> 5, r = lane & 31;
   auto mma = [&](const float *stage) {
     const float *pa = stage + (wi + r) * LDK + half * 4;
@@ -173,20 +174,20 @@ __global__ __launch_bounds__(256, MINWG) void tn_gemm_kernel(const float *__rest
   }
 }
 
-template <int BK, int WM, int WN, int MINWG, int MODE>
+template <int BK, int WM, int WN, int MINWG, int MODE, int WVM = 2, int WVN = 2>
 int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
-  constexpr int TM = 64 * WM, TN = 64 * WN;
+  constexpr int TM = 32 * WM * WVM, TN = 32 * WN * WVN;
   constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
   if (K % BK || N % TN) return 0;
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(tn_gemm_kernel<BK, WM, WN, MINWG, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(tn_gemm_kernel<BK, WM, WN, MINWG, MODE, WVM, WVN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return 0;
     ready = true;
   }
   const int tiles_n = N / TN;
   const int64_t tiles_m = (M + TM - 1) / TM;
-  tn_gemm_kernel<BK, WM, WN, MINWG, MODE><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n);
+  tn_gemm_kernel<BK, WM, WN, MINWG, MODE, WVM, WVN><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WVM * WVN), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -307,6 +308,9 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 12: return launch_tn<32, 2, 2, 2, 6>(X, Wt, Y, M, K, N);   // loads issued two K-tiles ahead (two staging register sets)
     case 13: return launch_glds<3>(X, Wt, Y, M, K, N);              // global -> LDS DMA, XOR-swizzled unpadded panels, 3 workgroups / CU
     case 14: return launch_glds<4>(X, Wt, Y, M, K, N);              //   ... 4 workgroups / CU
+    case 15: return launch_tn<16, 2, 2, 2, 0, 4, 2>(X, Wt, Y, M, K, N);   // 256 x 128 x 16, 8 waves of 64 x 64, 2 workgroups / CU
+    case 16: return launch_tn<16, 2, 2, 2, 0, 2, 4>(X, Wt, Y, M, K, N);   // 128 x 256 x 16, 8 waves
+    case 17: return launch_tn<16, 2, 2, 1, 0, 4, 4>(X, Wt, Y, M, K, N);   // 256 x 256 x 16, 16 waves of 64 x 64, 1 workgroup / CU
     default: return -1;
   }
 }
@@ -315,6 +319,7 @@ extern "C" const char *lab_tn_name(int variant) {
                                 "128x128x32 mfma-only",       "128x128x16 4wg/cu",         "128x128x16 3wg/cu",
                                 "256x128x32 1wg/cu",          "128x256x32 1wg/cu",         "256x256x16 1wg/cu",
                                 "128x128x32 1wg/cu",          "128x128x32 no-gload-B",     "128x128x32 no-gload-A",
-                                "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu"};
-  return variant >= 0 && variant < 15 ? names[variant] : nullptr;
+                                "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu",
+                                "256x128x16 8 waves 2wg/cu",  "128x256x16 8 waves 2wg/cu", "256x256x16 16 waves 1wg/cu"};
+  return variant >= 0 && variant < 18 ? names[variant] : nullptr;
 }
