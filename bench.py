@@ -309,8 +309,10 @@ def main():
                 comm = {"syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": sa[1] // 3,
                         "allreduce_wait_ms": round(wa[0] / 3, 3), "buckets": nb, "gradient_MB": round(mb, 1),
                         "backend": dist.get_backend(),
+                        "syncabn_transport": ("ipc mailboxes, one kernel per exchange (csrc/sync.hip)"
+                                              if any(P.SyncMailbox._by_group.values()) else "torch.distributed all_gather / all_reduce"),
                         "note": "per step, from 3 extra untimed steps with the D step serial: time rank 0's compute stream was "
-                                "blocked in the SyncABN all-gather / all-reduce calls and in GradientAllReducer.finish() waits"}
+                                "blocked in the SyncABN exchanges (incl. waiting for the slowest rank) and in GradientAllReducer.finish() waits"}
         model._d_stream = d_stream
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
