@@ -127,18 +127,23 @@ def _mailbox_vs_collectives(rank, world):
                 IA._sync_grad_stats(gstat, group)
             res[mode] = (mean.clone(), var.clone(), rm, rv, gstat)
         for a, b in zip(res["1"], res["0"]):
-            assert torch.equal(a, b), "mailbox exchange differs from the collectives (round %d)" % rnd
+            if world == 2:          # two addends: any summation order gives the same bits
+                assert torch.equal(a, b), "mailbox exchange differs from the collectives (round %d)" % rnd
+            else:                   # the mailbox kernels add in rank order, a ring all-reduce in ring order
+                assert rel(a, b) < 1e-6, "mailbox exchange differs from the collectives (round %d)" % rnd
         out["rounds"].append(res["1"])
     os.environ["SKD_SYNC_IPC"] = "1"
     P.SyncMailbox.reset()
     return out
 
 
-def test_mailbox_exchange_is_bit_identical_to_the_collectives():
-    outs = _run("_mailbox_vs_collectives")
-    for a, b in zip(outs[0]["rounds"], outs[1]["rounds"]):
-        for ta, tb in zip(a, b):
-            assert torch.equal(ta, tb), "replicas must hold identical pooled statistics"
+@pytest.mark.parametrize("world", [2, 3])
+def test_mailbox_exchange_is_bit_identical_to_the_collectives(world):
+    outs = _run("_mailbox_vs_collectives", world)
+    for r in range(1, world):
+        for a, b in zip(outs[0]["rounds"], outs[r]["rounds"]):
+            for ta, tb in zip(a, b):
+                assert torch.equal(ta, tb), "replicas must hold identical pooled statistics"
 
 
 # ---------------------------------------------------------------------------------------------------
