@@ -159,6 +159,12 @@ class SyncMailbox:
             blob = ctypes.create_string_buffer(b"".join(h for h, _ in everyone), nb * w)
             with on_device():
                 good = bool(lib.skd_sync_connect(ctx, ctypes.cast(blob, ctypes.c_void_p)))
+        def agree(ok):                               # every rank or nobody: all-reduce(MIN) of the local verdicts
+            v = torch.tensor([1.0 if ok else 0.0], device=device if dist.get_backend(group) == "nccl" else "cpu")   # gloo: host
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+            return float(v) >= 1.0
+
+        good = agree(good)                           # a rank that could not connect must not leave the others spinning in the self-test
         if good:                                     # self-test: four all-gathers (both slot parities, growing payloads) of a known pattern
             for n in (2, 64, 1024, lib.skd_sync_max_floats()):
                 src = (torch.arange(n, dtype=torch.float32) * 0.5 + rk * 4096.0).to(device)
@@ -166,9 +172,8 @@ class SyncMailbox:
                 good = good and bool(lib.skd_sync_all_gather(ctx, n, src.data_ptr(), out.data_ptr(), _lib.stream_of(src)))
                 want = torch.stack([torch.arange(n, dtype=torch.float32) * 0.5 + r * 4096.0 for r in range(w)])
                 good = good and torch.equal(out.cpu(), want)
-        verdict = torch.tensor([1.0 if good else 0.0], device=device if dist.get_backend(group) == "nccl" else "cpu")   # gloo: host
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
-        if float(verdict) < 1.0:
+            good = agree(good)
+        if not good:
             if ctx:
                 lib.skd_sync_destroy(ctx)
             return None

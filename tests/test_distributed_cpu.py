@@ -137,6 +137,41 @@ def _mailbox_vs_collectives(rank, world):
     return out
 
 
+def _mailbox_fallback(rank, world):
+    """One rank cannot open its peer's mailbox: the WHOLE group must fall back to the collectives, quickly (no rank left
+    spinning in the self-test), and the synchronised statistics must still be right."""
+    import importlib
+    import time
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    real = _lib.get()
+    if rank == 1:
+        class Broken:
+            def __getattr__(self, name):
+                if name == "skd_sync_connect":
+                    return lambda ctx, handles: 0
+                return getattr(real, name)
+        _lib.install_test_backend(Broken())
+    t0 = time.perf_counter()
+    mb = P.SyncMailbox.get(dist.group.WORLD, torch.device("cpu"))
+    took = time.perf_counter() - t0
+    _lib.install_test_backend(real)
+    stat = torch.tensor([[1.0 + rank, 2.0], [0.5, 0.25 * (rank + 1)]])
+    rm, rv = torch.zeros(2), torch.ones(2)
+    mean, var = IA._sync_stats(stat.clone(), 2, 10, dist.group.WORLD, rm, rv, 0.1, real, None)
+    P.SyncMailbox.reset()
+    return {"mailbox": mb is not None, "took": took, "mean": mean.clone(), "var": var.clone()}
+
+
+def test_mailbox_setup_failure_on_one_rank_sends_the_group_to_the_collectives():
+    outs = _run("_mailbox_fallback")
+    assert not outs[0]["mailbox"] and not outs[1]["mailbox"]
+    assert max(o["took"] for o in outs) < 4.0, "no rank may sit in the 5 s self-test time-outs"
+    for o in outs:                                   # functions.py:196-197 on the two replicas' [mean, var]
+        assert torch.allclose(o["mean"], torch.tensor([1.5, 2.0])) and torch.allclose(o["var"], torch.tensor([0.75, 0.375]))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_mailbox_exchange_is_bit_identical_to_the_collectives(world):
     outs = _run("_mailbox_vs_collectives", world)
