@@ -2,7 +2,9 @@
 // starts in milliseconds on a gpurun box, so one call can time many variants and be wrapped in rocprofv3 --pmc cheaply).
 //
 //   build (here, cross-compiled):  tools/build_gemm_lab.sh     -> tools/gemm_lab (git-ignored, travels with gpurun)
-//   run   (GPU box):               tools/gemm_lab [time|pmc] [reps] [filter]
+//   run   (GPU box):               tools/gemm_lab [time|pmc] [reps] [filter] [variants-only]
+//                                  (filter: substring of the case name; variants-only: just the experiment kernels of
+//                                  tools/gemm_lab_kernels.hip)
 //
 // Cases: the pair-wise Gram / backward GEMMs at M = 1089 and 4225 (B = 8, Cs = 128, Ct = 512), the 1x1-convolution +
 // InPlace-ABN GEMM (skd_conv1x1_abn_nhwc) at the frozen teacher's shapes, and -- as the library baseline the fused kernel
