@@ -287,6 +287,118 @@ int launch_glds(const float *X, const float *Wt, float *Y, int64_t M, int K, int
   return hipGetLastError() == hipSuccess;
 }
 
+// ---- variant: persistent workgroups with a dynamic tile counter -------------------------------------------------------------
+// grid = 256 CUs x MINWG workgroups; each workgroup draws 128 x 128 tiles from an atomic counter until none is left (no
+// half-empty last round: M x N / (128 x 128) need not divide the workgroup slots) and issues the global loads of its NEXT
+// tile's first K-panel before the epilogue of the current one (the prologue latency hides under the stores).
+template <int MINWG>
+__global__ __launch_bounds__(256, MINWG) void tn_gemm_persistent_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                                        float *__restrict__ Y, int64_t M, int K, int N, int tiles_n,
+                                                                        int ntiles, unsigned *counter) {
+  constexpr int BK = 16, TM = 128, TN = 128, LDK = BK + 4, STAGE = (TM + TN) * LDK;
+  constexpr int QK = BK / 4, RPP = 256 / QK, RA = TM / RPP, RB = TN / RPP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int next_s;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int grow = t / QK, gkq = (t % QK) * 4, srow = grow * LDK + gkq;
+  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int half = lane >> 5, r = lane & 31;
+  const int nk = K / BK;
+  auto mma = [&](const float *stage, f32x16 (&acc)[2][2]) {
+    const float *pa = stage + (wi + r) * LDK + half * 4;
+    const float *pb = stage + (TM + wj + r) * LDK + half * 4;
+    float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 32 * LDK);
+    float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 32 * LDK);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (g + 1 < BK / 8) {
+        na0 = *reinterpret_cast<const float4 *>(pa + (g + 1) * 8);
+        na1 = *reinterpret_cast<const float4 *>(pa + 32 * LDK + (g + 1) * 8);
+        nb0 = *reinterpret_cast<const float4 *>(pb + (g + 1) * 8);
+        nb1 = *reinterpret_cast<const float4 *>(pb + 32 * LDK + (g + 1) * 8);
+      }
+      const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B0[u], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[u], B1[u], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B0[u], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[u], B1[u], acc[1][1], 0, 0, 0);
+      }
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (g + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    }
+  };
+  if (t == 0) next_s = (int)atomicAdd(counter, 1u);
+  __syncthreads();
+  int tile = next_s;
+  Stg<RA, RB> st;
+  if (tile < ntiles) {
+    const int64_t m0 = (int64_t)(tile / tiles_n) * TM;
+    lab_gload<RA, RB, RPP>(st, X, Wt, m0, grow, gkq, (int64_t)((tile % tiles_n) * TN + grow) * K, M, K, 0);
+  }
+  while (tile < ntiles) {
+    const int64_t m0 = (int64_t)(tile / tiles_n) * TM;
+    const int n0 = (tile % tiles_n) * TN;
+    const int64_t wrow0 = (int64_t)(n0 + grow) * K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    __syncthreads();                                   // every wave is done with next_s and with both LDS stages of the last tile
+    if (t == 0) next_s = (int)atomicAdd(counter, 1u);  // the tile after this one
+    lab_sstore<RA, RB, RPP, LDK, TM>(st, lds, srow);
+    __syncthreads();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) lab_gload<RA, RB, RPP>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+      mma(lds + stage * STAGE, acc);
+      if (more) lab_sstore<RA, RB, RPP, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
+      __syncthreads();
+      stage ^= 1;
+    }
+    const int nxt = next_s;
+    if (nxt < ntiles) {                                // the next tile's first panel travels while this tile is stored
+      const int64_t nm0 = (int64_t)(nxt / tiles_n) * TM;
+      lab_gload<RA, RB, RPP>(st, X, Wt, nm0, grow, gkq, (int64_t)((nxt % tiles_n) * TN + grow) * K, M, K, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wj + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int64_t row = m0 + wi + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          if (row < M) Y[row * N + col] = acc[i][j][q];
+        }
+    }
+    tile = nxt;
+  }
+}
+
+static unsigned *g_tile_counter = nullptr;
+template <int MINWG>
+int launch_persistent(const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
+  constexpr size_t lds = sizeof(float) * 2 * 256 * 20;
+  if (K % 16 || N % 128) return 0;
+  if (g_tile_counter == nullptr && hipMalloc(reinterpret_cast<void **>(&g_tile_counter), 4) != hipSuccess) return 0;
+  if (hipMemsetAsync(g_tile_counter, 0, 4, 0) != hipSuccess) return 0;
+  const int tiles_n = N / 128;
+  const int64_t tiles_m = (M + 127) / 128;
+  tn_gemm_persistent_kernel<MINWG><<<dim3(256 * MINWG), dim3(256), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n, (int)(tiles_m * tiles_n), g_tile_counter);
+  return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace lab
 
 // C-callable table for gemm_lab.cpp
@@ -311,6 +423,8 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 15: return launch_tn<16, 2, 2, 2, 0, 4, 2>(X, Wt, Y, M, K, N);   // 256 x 128 x 16, 8 waves of 64 x 64, 2 workgroups / CU
     case 16: return launch_tn<16, 2, 2, 2, 0, 2, 4>(X, Wt, Y, M, K, N);   // 128 x 256 x 16, 8 waves
     case 17: return launch_tn<16, 2, 2, 1, 0, 4, 4>(X, Wt, Y, M, K, N);   // 256 x 256 x 16, 16 waves of 64 x 64, 1 workgroup / CU
+    case 18: return launch_persistent<3>(X, Wt, Y, M, K, N);              // persistent 128 x 128 x 16, dynamic tile counter, 3 workgroups / CU
+    case 19: return launch_persistent<2>(X, Wt, Y, M, K, N);              //   ... 2 workgroups / CU
     default: return -1;
   }
 }
@@ -320,6 +434,7 @@ extern "C" const char *lab_tn_name(int variant) {
                                 "256x128x32 1wg/cu",          "128x256x32 1wg/cu",         "256x256x16 1wg/cu",
                                 "128x128x32 1wg/cu",          "128x128x32 no-gload-B",     "128x128x32 no-gload-A",
                                 "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu",
-                                "256x128x16 8 waves 2wg/cu",  "128x256x16 8 waves 2wg/cu", "256x256x16 16 waves 1wg/cu"};
-  return variant >= 0 && variant < 18 ? names[variant] : nullptr;
+                                "256x128x16 8 waves 2wg/cu",  "128x256x16 8 waves 2wg/cu", "256x256x16 16 waves 1wg/cu",
+                                "128x128x16 persistent 3wg/cu", "128x128x16 persistent 2wg/cu"};
+  return variant >= 0 && variant < 20 ? names[variant] : nullptr;
 }
