@@ -425,6 +425,9 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 17: return launch_tn<16, 2, 2, 1, 0, 4, 4>(X, Wt, Y, M, K, N);   // 256 x 256 x 16, 16 waves of 64 x 64, 1 workgroup / CU
     case 18: return launch_persistent<3>(X, Wt, Y, M, K, N);              // persistent 128 x 128 x 16, dynamic tile counter, 3 workgroups / CU
     case 19: return launch_persistent<2>(X, Wt, Y, M, K, N);              //   ... 2 workgroups / CU
+    case 20: return launch_tn<16, 4, 2, 2, 0>(X, Wt, Y, M, K, N);         // 256 x 128 x 16, 4 waves of 128 x 64 (128 accumulators), 2 workgroups / CU
+    case 21: return launch_tn<16, 2, 4, 2, 0>(X, Wt, Y, M, K, N);         // 128 x 256 x 16, 4 waves of 64 x 128
+    case 22: return launch_tn<16, 4, 4, 1, 0>(X, Wt, Y, M, K, N);         // (= 8) 256 x 256 x 16, 4 waves of 128 x 128, 1 workgroup / CU
     default: return -1;
   }
 }
@@ -435,6 +438,7 @@ extern "C" const char *lab_tn_name(int variant) {
                                 "128x128x32 1wg/cu",          "128x128x32 no-gload-B",     "128x128x32 no-gload-A",
                                 "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu",
                                 "256x128x16 8 waves 2wg/cu",  "128x256x16 8 waves 2wg/cu", "256x256x16 16 waves 1wg/cu",
-                                "128x128x16 persistent 3wg/cu", "128x128x16 persistent 2wg/cu"};
-  return variant >= 0 && variant < 20 ? names[variant] : nullptr;
+                                "128x128x16 persistent 3wg/cu", "128x128x16 persistent 2wg/cu",
+                                "256x128x16 4 waves 2wg/cu",  "128x256x16 4 waves 2wg/cu", "256x256x16 4 waves 1wg/cu"};
+  return variant >= 0 && variant < 23 ? names[variant] : nullptr;
 }
