@@ -645,6 +645,45 @@ def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
     print("parameters after step 0, two-stream vs serial: worst relative difference", worst)
 
 
+def test_d_stream_equals_serial_bit_for_bit_in_deterministic_mode(monkeypatch):
+    """The same question as the test above, asked where it has an exact answer: under SKD_DETERMINISTIC=1 (no atomics anywhere)
+    two steps with the D step on its own stream must give the SAME BITS as the strictly serial order -- every loss of both
+    steps, every student and discriminator parameter and buffer after them.  Any ordering mistake between the streams (a D
+    step released before the student loss has gone back through D, an SGD update seen half-way) changes bits."""
+    monkeypatch.setenv("SKD_DETERMINISTIC", "1")
+    try:
+        def run(flag):
+            monkeypatch.setenv("SKD_D_STREAM", flag)
+            torch.manual_seed(99)
+            args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
+            model = NetModel(args)
+            assert model.deterministic and (model._d_stream is not None) == (flag == "1")
+            with torch.no_grad():
+                model.D_model.attn1.gamma.fill_(0.25)
+                model.D_model.attn2.gamma.fill_(-0.5)
+            losses = []
+            for step in range(2):
+                images, labels = O.synthetic_batch(2, 512, 512, seed=step)
+                model.gp_alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step)).to(DEV)
+                model.adjust_learning_rate(args.lr_g, model.G_solver, step)
+                model.adjust_learning_rate(args.lr_d, model.D_solver, step)
+                torch.manual_seed(500 + step)                       # Dropout2d masks
+                model.set_input((images, labels, None, None))
+                model.optimize_parameters()
+                losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
+            torch.cuda.synchronize()
+            return losses, cpu_sd(model.student), cpu_sd(model.D_model)
+
+        serial, stream = run("0"), run("1")
+        assert serial[0] == stream[0], ("losses differ between the serial and the two-stream order", serial[0], stream[0])
+        for which, what in ((1, "student"), (2, "D")):
+            diff = [k for k, v in serial[which].items() if not torch.equal(v, stream[which][k])]
+            assert not diff, "%s state differs between the serial and the two-stream order: %s" % (what, diff[:8])
+    finally:
+        torch.backends.cudnn.enabled = True
+        torch.use_deterministic_algorithms(False)
+
+
 def test_evaluate_main_full_size_student_on_gpu():
     """networks/evaluate.py:106-113,156-206 (whole=True) with the REAL student at the Cityscapes tile size 1024 x 2048 on the
     GPU -- channels-last network, 129 x 257 feature maps through the NHWC pyramid / fold kernels, fused upsample + argmax +
