@@ -303,6 +303,25 @@ def test_netmodel_ho_step_two_ranks_vs_sharded_oracle(d_stream, monkeypatch):
     assert local_bn == 2, "the discriminator's BatchNorm statistics must stay local to the replica"
 
 
+def test_netmodel_ho_step_two_ranks_mailbox_equals_collectives_bit_for_bit(monkeypatch):
+    """The whole configs[3] step (Pi + Pa + Ho, SyncABN in every student BN, both gradient all-reduces) on two ranks, once with
+    the statistics travelling through the IPC mailboxes and once through torch.distributed, under SKD_DETERMINISTIC=1 (no
+    atomics anywhere): every loss, every averaged gradient, every parameter and running statistic after the step must have
+    the SAME BITS in both runs, on both ranks."""
+    monkeypatch.setenv("SKD_DETERMINISTIC", "1")
+    monkeypatch.setenv("SKD_D_STREAM", "1")
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SKD_SYNC_IPC", mode)
+        runs[mode] = _run("_netmodel_step")
+    for r in range(2):
+        a, b = runs["1"][r], runs["0"][r]
+        assert a["losses"] == b["losses"], (r, a["losses"], b["losses"])
+        for name in ("grads", "d_grads", "after", "d_after"):
+            diff = [k for k in a[name] if not torch.equal(a[name][k], b[name][k])]
+            assert not diff, "rank %d: %s differ between the mailbox and the collective exchange: %s" % (r, name, diff[:8])
+
+
 def test_bench_under_torchrun_two_ranks_over_gloo():
     """The exact command line the driver uses for its multi-GPU runs (python -m torch.distributed.run ... bench.py
     --gpus N), with two ranks sharing cuda:0 over gloo (SKD_DIST_BACKEND): rendezvous, replica broadcast, SyncABN
