@@ -352,6 +352,43 @@ def test_abn_nhwc_one_call_backward(hip, ref, rows, C):
     assert hip.skd_abn_relu_backward_nhwc(rows, C, P(xg), None, P(dzg), P(mg), P(vg), P(wg_), P(bg_), P(st_g[0]), P(st_g[1]), P(dxg), P(dxg), P(dwg), P(dbg), 1e-5, 0, P(ws_g), None) == 0
 
 
+@pytest.mark.parametrize("rows,C", [(8 * 65 * 65, 256), (8 * 65 * 65, 128), (8 * 129 * 129, 64), (2 * 33 * 33, 512)])
+def test_abn_one_launch_passes_are_repeatable_under_a_busy_second_stream(hip, rows, C):
+    """The register-resident one-launch passes hand statistics from a channel block's last arriver to its other workgroups
+    through memory (write-through stores, generation word, L1-bypassing loads).  A stale read would be rare and silent, so:
+    200 forward and 200 backward launches on the same inputs while a second stream keeps the CUs busy with GEMMs of varying
+    size (changing which workgroups are resident when) -- every launch must reproduce the first one's bits, and no NaN
+    (the time-out poison) may appear."""
+    g = torch.Generator().manual_seed(rows + 7 * C)
+    x = gpu(torch.randn(rows, C, generator=g) * 2 + torch.randn(1, C, generator=g) * 3)
+    r, dz = gpu(torch.randn(rows, C, generator=g)), gpu(torch.randn(rows, C, generator=g))
+    w, b = gpu(torch.randn(C, generator=g)), gpu(torch.randn(C, generator=g))
+    ws = torch.empty(max(1, hip.skd_abn_nhwc_workspace_floats(rows, C)), device=DEV)
+    side = torch.cuda.Stream(device=DEV)
+    mats = [torch.randn(n, n, device=DEV) for n in (512, 1024, 2048, 3072)]
+    first = None
+    for it in range(200):
+        with torch.cuda.stream(side):
+            m = mats[it % 4]
+            for _ in range(1 + it % 3):
+                m = (m @ mats[it % 4]) * 1e-3
+        out, st = torch.full((rows, C), float("nan"), device=DEV), torch.full((2, C), float("nan"), device=DEV)
+        assert hip.skd_abn_forward_train_nhwc(rows, C, P(x), P(r), P(out), P(w), P(b), None, None, P(st[0]), P(st[1]), 0.1, 1e-5, 3, 0.0, P(ws), None)
+        gst, dx, dres = torch.full((2, C), float("nan"), device=DEV), torch.full((rows, C), float("nan"), device=DEV), torch.full((rows, C), float("nan"), device=DEV)
+        dw, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        assert hip.skd_abn_relu_backward_nhwc(rows, C, P(x), P(out), P(dz), P(st[0]), P(st[1]), P(w), P(b), P(gst[0]), P(gst[1]), P(dx), P(dres),
+                                              P(dw), P(db), 1e-5, 0, P(ws), None)
+        cur = (out, st, gst, dx, dres, dw, db)
+        if first is None:
+            torch.cuda.synchronize()
+            first = cur
+            assert all(bool(torch.isfinite(t).all()) for t in cur)
+        else:
+            for name, a, c in zip(("out", "mean/var", "edz/eydz", "dx", "dres", "dweight", "dbias"), first, cur):
+                assert torch.equal(a, c), "launch %d: %s differs from the first launch" % (it, name)
+    torch.cuda.synchronize()
+
+
 def test_abn_single_sample_running_var_is_finite(hip):
     """One sample per channel (PSP 1x1 stage at batch 1, one replica): the reference's n / (n - 1) poisons
     running_var with NaN; here the biased variance (0) is kept -- DESIGN.md section 7."""
