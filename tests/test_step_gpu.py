@@ -337,12 +337,14 @@ def _check_grads(got, recs, what, bound=GRAD_BOUND, floor=GRAD_FLOOR):
 
 
 # The critic step with its convolutions on PyTorch's im2col + rocBLAS path and rocBLAS's atomics off (PyTorch's
-# deterministic-algorithms switch): every formula of the step against the fp64 oracle.  OPEN ITEM: the
+# deterministic-algorithms switch): every formula of the step against the fp64 oracle.  (DESIGN.md section 10, item 6:) the
 # result of this replica step is bimodal from run to run on the same tree -- err / |g| is either 4e-7 ... 8e-7 on every tensor
 # (the CPU fp32 oracle's own level; gpurun r03s and two of four back-to-back runs of r03fin2) or 1e-4 ... 3e-4 on most weight
 # gradients (the other two; once, r03fin, 3e-3 on the two input-side bias gradients, sums that cancel almost completely).
 # rocBLAS atomics are ruled out (off here), so are MIOpen (disabled here) and spectral.hip (no atomics; tools/d_step_error_probe.py
-# has every variant at 1e-6 on random logits).  Most likely a property of the comparison, not of a kernel: the critic's LeakyReLU
+# has every variant at 1e-6 on random logits).  It is a property of the function, not of a kernel
+# (tests/diagnostics/diag_dstep_sensitivity.py reproduces it in the fp64 CPU oracle alone: logits perturbed by 1e-6 move the
+# gradients by 3e-6 or by 2e-4 ... 3e-3, the same tensors first): the critic's LeakyReLU
 # has a discontinuous derivative, the gradient penalty differentiates THROUGH that derivative, and the logits this replica
 # step starts from differ from run to run at the 1e-6 level (MIOpen's forward split-K kernels add with atomics) -- a run in
 # which some pre-activation lies within rounding of zero evaluates its slope differently on the GPU and in the CPU oracle, a
