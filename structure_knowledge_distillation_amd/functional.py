@@ -444,7 +444,9 @@ def conv1x1_abn_supported(x, conv):
 def abn_pack_eval_params(bn):
     """(4, C) = [running_mean | 1 / sqrt(running_var + eps) | |weight| + eps | bias] of an eval-mode InPlace-ABN module (the
     constants of bn.cu:146-159), cached on the module and rebuilt when any of its tensors is written (their autograd version
-    counters) or moved: the frozen teacher packs each BatchNorm once."""
+    counters) or moved: the frozen teacher packs each BatchNorm once.  (A write through ``tensor.data`` does not bump the
+    version counter autograd keeps for ``tensor``: code that edits statistics that way must drop ``bn._skd_eval_pack`` itself;
+    ``load_state_dict``, optimizers and ordinary in-place ops are seen.)"""
     key = tuple((t.data_ptr(), t._version) if t is not None else None
                 for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias)) + (float(bn.eps),)
     cached = getattr(bn, "_skd_eval_pack", None)
