@@ -100,3 +100,61 @@ def test_step_config1_pa(gold):
             check(out["grads_S"][k], rec, 2e-6)
     for k, rec in G["after"].items():
         check(PS[k], rec, 1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tests/golden/gpu_suite_oracle.pt: the CPU-oracle records the -m gpu tests compare with (generator:
+# tests/golden/make_golden_gpu_suite.py).  Here, on CPU: the fixture belongs to THIS torch's RNG (the seeded weights
+# the GPU tests rebuild are the ones the recorded oracle saw), it is pinned to the reference-made fixture where the two
+# overlap (config 1), and its cheapest section is re-derived live.
+# ---------------------------------------------------------------------------------------------------------------
+def _suite():
+    import importlib.util
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_gpu_suite", os.path.join(d, "make_golden_gpu_suite.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen, torch.load(os.path.join(d, "gpu_suite_oracle.pt"), weights_only=False)
+
+
+def test_gpu_suite_fixture_weights_and_sections(gold):
+    gen, suite = _suite()
+    assert set(gen.SECTIONS) <= set(suite), "a section of make_golden_gpu_suite.py has not been generated"
+    assert suite["seeds"] == gen.SEEDS and suite["nsample"] == gen.NSAMPLE
+    same = lambda got, want: all(abs(v - want[k]) <= 1e-9 * max(1.0, abs(v)) for k, v in got.items())
+    for section in ("full_step", "sharded2"):
+        PS, PT, PD = gen.init_nets(section)
+        sums = suite["full_step_ho1" if section == "full_step" else section]["checksums"]
+        assert same(gen.checksum(PS), sums["student"]) and same(gen.checksum(PT), sums["teacher"]) and same(gen.checksum(PD), sums["D"])
+    assert suite["full_step_ho0"]["checksums"] == suite["full_step_ho1"]["checksums"]
+    PS, PT, _ = gen.networks_forward_inputs()
+    assert same(gen.checksum(PS), suite["networks_forward"]["checksums"]["student"])
+    assert same(gen.checksum(PT), suite["networks_forward"]["checksums"]["teacher"])
+    assert same(gen.checksum(gen.eval_full_inputs()[0]), suite["eval_full"]["checksums"])
+    # config 1 (Pi + Pa): the reference's OWN modules produced reference_vectors.pt from the fp64 weights; the suite's fp64 oracle
+    # started from the same weights rounded to fp32 (what the GPU holds): the three losses agree far inside the 1e-4 of north_star
+    ref = gold["step_config1_pa"]
+    for k, gk in (("mc_G_loss", "mc"), ("pi_G_loss", "pi"), ("pa_G_loss", "pa")):
+        assert abs(suite["config1_pa"]["losses64"][k] - float(ref[gk])) <= 2e-6 * abs(float(ref[gk])), k
+    assert suite["config1_pi"]["losses64"]["pa_G_loss"] == 0.0
+    assert abs(suite["config1_pi"]["losses64"]["pi_G_loss"] - suite["config1_pa"]["losses64"]["pi_G_loss"]) <= 1e-12
+    # two-step section: step 1 starts from step 0's update, so its losses differ from step 0's
+    s0, s1 = suite["full_step_ho1"]["steps"]
+    assert s0["losses64"]["G_loss"] != s1["losses64"]["G_loss"] and s1["losses64"]["D_loss"] != 0.0
+    # sharded section: two different shards, identical replicas' u / v (asserted by the generator), local D BatchNorm statistics
+    sh = suite["sharded2"]
+    assert sh["shard_losses"][0] != sh["shard_losses"][1]
+    k = "preprocess_additional.running_mean"
+    assert not torch.equal(sh["d_bn_running"][0][k], sh["d_bn_running"][1][k])
+    # every gradient record carries the fp32-vs-fp64 yard-stick the ONE bound needs
+    for sec in ("config1_pa", "config1_pi", "sharded2"):
+        assert all("base" in r and r["norm"] >= 0 for r in suite[sec]["grads_S"].values())
+
+
+def test_gpu_suite_networks_forward_section_rederived():
+    """The cheapest section re-derived on the spot (1 s): the committed records are what the generator produces today."""
+    gen, suite = _suite()
+    fresh = gen.gen_networks_forward()
+    for name in ("student", "teacher"):
+        for a, b in zip(fresh[name], suite["networks_forward"][name]):
+            assert a["shape"] == b["shape"] and torch.allclose(a["sample"], b["sample"], rtol=1e-9, atol=1e-12 * (b["norm"] + 1e-30))

@@ -187,28 +187,36 @@ def test_discriminator_step_vs_oracle():
 
 
 def test_networks_forward_vs_oracle():
-    torch.manual_seed(5)
-    S = pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [2, 2, 2, 2], 19).to(DEV).train()
+    """Student (train mode) and teacher (eval) forwards on a 161 x 129 input (odd sizes: 41 x 33 -> 21 x 17 maps) against the
+    fp64 oracle forward recorded in tests/golden/gpu_suite_oracle.pt["networks_forward"] (generator: make_golden_gpu_suite.py)."""
+    gen, gold = _suite()
+    fx = gold["networks_forward"]
+    PS, PT, x = gen.networks_forward_inputs()
+    for name, P in (("student", PS), ("teacher", PT)):
+        _same_weights(gen.checksum(P), fx["checksums"][name], name)
+    S = pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [2, 2, 2, 2], 19)
+    assert sorted(S.state_dict().keys()) == sorted(PS.keys())
+    S.load_state_dict(PS)
+    S = S.to(DEV).train()
     no_dropout(S)
-    assert sorted(S.state_dict().keys()) == sorted(O.pspnet_init(O.STUDENT, 19).keys())
-    P = cpu_sd(S, torch.float64)
-    x = torch.randn(2, 3, 161, 129) * 57
-    want = O.pspnet_forward(P, x.double(), O.STUDENT, True, dropout_p=0.0)
     got = S(x.to(DEV))
     assert len(got) == 7
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and rel(a, b) < 2e-5
+    for i, (a, r) in enumerate(zip(got, fx["student"])):
+        err, _ = _rec_err(a, r)
+        assert err <= 2e-5 * r["norm"], ("student", i, err / r["norm"])
     after = S.state_dict()
-    for k in P:
-        if "running" in k:
-            assert rel(after[k], P[k]) < 1e-5, k
-    T = pspnet_combine.Res_pspnet(pspnet_combine.Bottleneck, [3, 4, 23, 3], 19).to(DEV).eval()
-    assert sorted(T.state_dict().keys()) == sorted(O.pspnet_init(O.TEACHER, 19).keys())
+    for k, r in fx["running"].items():
+        err, _ = _rec_err(after[k], r)
+        assert err <= 1e-5 * r["norm"] + 1e-9, k
+    T = pspnet_combine.Res_pspnet(pspnet_combine.Bottleneck, [3, 4, 23, 3], 19)
+    assert sorted(T.state_dict().keys()) == sorted(PT.keys())
+    T.load_state_dict(PT)
+    T = T.to(DEV).eval()
     with torch.no_grad():
-        want = O.pspnet_forward(cpu_sd(T, torch.float64), x.double(), O.TEACHER, False)
         got = T(x.to(DEV))
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and rel(a, b) < 5e-5
+    for i, (a, r) in enumerate(zip(got, fx["teacher"])):
+        err, _ = _rec_err(a, r)
+        assert err <= 5e-5 * r["norm"], ("teacher", i, err / r["norm"])
     with pytest.raises(ValueError):
         pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [1, 1, 1, 1], 19)
 
@@ -216,65 +224,56 @@ def test_networks_forward_vs_oracle():
 @pytest.mark.parametrize("ho", [False, True])
 def test_full_step_vs_oracle(ho):
     """BASELINE configs 2 / 3 at B=2 (512x512, Pi+Pa[+Ho]); with Ho two consecutive steps (momentum, u/v and running
-    statistics carried over), without it one (the CPU oracle dominates this test's two minutes; the single Pi / Pi+Pa step is
-    also pinned by the config-1 golden tests below)."""
-    torch.manual_seed(1234)
+    statistics carried over), without it one.  The fp64 / fp32 CPU oracle of the same steps is NOT run here: its records
+    come from tests/golden/gpu_suite_oracle.pt["full_step_ho0/1"] (generator: tests/golden/make_golden_gpu_suite.py)."""
+    gen, gold = _suite()
+    fx = gold["full_step_ho%d" % int(ho)]
+    PS, PT, PD = gen.init_nets("full_step")
+    for name, P in (("student", PS), ("teacher", PT), ("D", PD)):
+        _same_weights(gen.checksum(P), fx["checksums"][name], name)
     B = 2
-    args = default_args(batch_size=B, device=DEV, ho=ho, weight_decay=5e-4, lambda_pa=0.5)
+    args = default_args(batch_size=B, device=DEV, ho=ho, weight_decay=fx["cfg"]["weight_decay"], lambda_pa=fx["cfg"]["lambda_pa"])
     model = NetModel(args)
     no_dropout(model.student)
-    with torch.no_grad():
-        model.D_model.attn1.gamma.fill_(0.25)
-        model.D_model.attn2.gamma.fill_(-0.5)
-    PS32, PT32, PD32 = cpu_sd(model.student), cpu_sd(model.teacher), cpu_sd(model.D_model)
-    PS64, PT64, PD64 = (cpu_sd(m, torch.float64) for m in (model.student, model.teacher, model.D_model))
-    cfg = O.StepConfig(ho=ho, weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
-    st32, st64 = {"G": {}, "D": {}}, {"G": {}, "D": {}}
-    for step in range(2 if ho else 1):
-        images, labels = O.synthetic_batch(B, 512, 512, seed=step)
-        alpha = torch.rand(B, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step))
+    _load_oracle_weights(model, PS, PT, PD)
+    assert len(fx["steps"]) == (2 if ho else 1)
+    for step, st in enumerate(fx["steps"]):
+        images, labels, alpha = gen.full_step_inputs(step)
         lr_g = model.adjust_learning_rate(args.lr_g, model.G_solver, step)
         lr_d = model.adjust_learning_rate(args.lr_d, model.D_solver, step)
+        assert lr_g == gen.lr_poly(gen.LR_G, step) and lr_d == gen.lr_poly(gen.LR_D, step)     # the rates the oracle stepped with
         model.gp_alpha = alpha.to(DEV)
         model.set_input((images, labels, None, None))
         # gradients of this step, before the optimizers overwrite anything we compare
         model.forward()
         model.G_solver.zero_grad()
         model.student_backward()
-        gS = {k: p.grad.detach().cpu().clone() for k, p in model.student.named_parameters()}
+        gS = {k: p.grad.detach().clone() for k, p in model.student.named_parameters()}
         model.G_solver.step()
         if ho:
             model.discriminator_backward()
-        o64 = O.distillation_step(PS64, PT64, PD64 if ho else None, images.double(), labels, cfg, st64,
-                                  alpha.double(), lr_g=lr_g, lr_d=lr_d)
-        o32 = O.distillation_step(PS32, PT32, PD32 if ho else None, images, labels, cfg, st32, alpha,
-                                  lr_g=lr_g, lr_d=lr_d)
+        o64, o32 = st["losses64"], st["losses32"]
         for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
             tol = 1e-4 * abs(o64[k]) if step == 0 else max(1e-4 * abs(o64[k]), 4 * abs(o32[k] - o64[k]))
             assert abs(getattr(model, k) - o64[k]) <= tol, (step, k, getattr(model, k), o64[k], o32[k])
         if ho:
             tol = 1e-4 * abs(o64["D_loss"]) if step == 0 else max(1e-3 * abs(o64["D_loss"]), 4 * abs(o32["D_loss"] - o64["D_loss"]))
             assert abs(model.D_loss - o64["D_loss"]) <= tol, (step, model.D_loss, o64["D_loss"], o32["D_loss"])
-        for a, b, c32 in zip(model.preds_S, o64["preds_S"], o32["preds_S"]):
-            assert rel(a, b) < (1e-4 if step == 0 else max(1e-4, 4 * rel(c32, b)))
-        worst = 0.0
-        for k, gw in o64["grads_S"].items():
-            base = float((o32["grads_S"][k].double() - gw).norm())
-            err = float((gS[k].double() - gw).norm())
-            # first step: the ONE bound (GRAD_BOUND / GRAD_FLOOR below); second step: the weights have already moved apart
-            # by the first update at that level, so the comparison widens to 8 x the CPU-fp32 deviation
-            assert err <= (GRAD_BOUND if step == 0 else 8.0) * base + GRAD_FLOOR * float(gw.norm()) + 1e-6, (step, k, err, base, float(gw.norm()))
-            worst = max(worst, err / (float(gw.norm()) + 1e-12))
+        for i, (a, r) in enumerate(zip(model.preds_S, st["preds_S"])):
+            err, _ = _rec_err(a, r)
+            assert err <= (1e-4 * r["norm"] if step == 0 else max(1e-4 * r["norm"], 4 * r["base"])), (step, i, err, r["norm"], r["base"])
+        # first step: the ONE bound (GRAD_BOUND / GRAD_FLOOR below); second step: the weights have already moved apart
+        # by the first update at that level, so the comparison widens to 8 x the CPU-fp32 deviation
+        _check_grads(gS, st["grads_S"], "B=2 ho=%s step %d student gradients" % (ho, step), bound=GRAD_BOUND if step == 0 else 8.0)
         after = model.student.state_dict()
-        for k in PS64:
-            if "running" in k:
-                assert rel(after[k], PS64[k]) < (1e-4 if step == 0 else max(1e-3, 10 * rel(PS32[k], PS64[k]))), (step, k)
+        for k, r in st["running"].items():
+            err, _ = _rec_err(after[k], r)
+            assert err <= (1e-4 * r["norm"] if step == 0 else max(1e-3 * r["norm"], 10 * r["base"])) + 1e-9, (step, k)
     # parameters after the optimizer step(s) track the fp64 oracle as well as the fp32 CPU oracle does
     after = model.student.state_dict()
-    for k in O.learnable_keys(PS64):
-        base = float((PS32[k].double() - PS64[k]).norm())
-        err = float((after[k].detach().cpu().double() - PS64[k]).norm())
-        assert err <= 8 * base + 1e-5 * float(PS64[k].norm()) + 1e-7, (k, err, base)
+    for k, r in fx["student_after"].items():
+        err, _ = _rec_err(after[k], r)
+        assert err <= 8 * r["base"] + 1e-5 * r["norm"] + 1e-7, (k, err, r["base"])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -284,6 +283,29 @@ import math
 import os
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_SUITE = {}
+
+
+def _load_generator(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLDEN_DIR, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                       # the generator's seeds / init functions; its main() is not run
+    return mod
+
+
+def _suite():
+    """(generator module, fixture) of tests/golden/gpu_suite_oracle.pt: the CPU-oracle records the GPU tests compare with.
+    No network forward / backward of the CPU oracle runs inside a GPU test."""
+    if not _SUITE:
+        _SUITE["gen"] = _load_generator("make_golden_gpu_suite")
+        _SUITE["gold"] = torch.load(os.path.join(GOLDEN_DIR, "gpu_suite_oracle.pt"), weights_only=False)
+    return _SUITE["gen"], _SUITE["gold"]
+
+
+def _same_weights(got, want, name):
+    for k, v in got.items():
+        assert abs(v - want[k]) <= 1e-9 * max(1.0, abs(v)), ("weight RNG drifted from the fixture generator's", name, k)
 # ONE gradient bound (SURVEY.md section 8c): the error of a GPU gradient tensor against the fp64 oracle is at most
 # GRAD_BOUND x the error of the CPU-fp32 oracle against the fp64 oracle for the same tensor, plus GRAD_FLOOR of the
 # tensor's norm (tensors the CPU happens to get almost exactly -- biases of 19 channels, BN vectors -- have a base
@@ -493,42 +515,31 @@ def test_full_step_b8_deterministic_mode_bit_equal_and_tight_bound(monkeypatch):
 
 def _config1_step(pa):
     """BASELINE configs[0] shape (batch 2, 256x256, 33x33 maps; Ho impossible at that size) on the GPU with the
-    weights / inputs of tests/golden/reference_vectors.pt["step_config1_pa"] (seeds 41, 42, 43)."""
-    s1, s2, s3 = 41, 42, 43
-    PS, PT = O.pspnet_init(O.STUDENT, 19, seed=s1, dtype=torch.float64), O.pspnet_init(O.TEACHER, 19, seed=s2, dtype=torch.float64)
-    x, y = O.synthetic_batch(2, 256, 256, seed=s3, dtype=torch.float64)
+    weights / inputs of tests/golden/reference_vectors.pt["step_config1_pa"] (seeds 41, 42, 43), rounded to fp32 (what the
+    GPU holds; the fixture's fp64 / fp32 oracle records start from the same rounded values)."""
+    gen, gold = _suite()
+    PS, PT, x, y = gen.config1_weights()
     args = default_args(batch_size=2, device=DEV, ho=False, pa=pa, weight_decay=5e-4, lambda_pa=0.5)
     model = NetModel(args)
     no_dropout(model.student)
-    _load_oracle_weights(model, {k: v.float() if v.is_floating_point() else v for k, v in PS.items()},
-                         {k: v.float() if v.is_floating_point() else v for k, v in PT.items()})
-    # the fp64 / fp32 CPU oracles start from the fp32-rounded weights the GPU holds
-    P64 = ({k: v.float().double() if v.is_floating_point() else v.clone() for k, v in PS.items()},
-           {k: v.float().double() if v.is_floating_point() else v.clone() for k, v in PT.items()})
-    P32 = ({k: v.float() if v.is_floating_point() else v.clone() for k, v in PS.items()},
-           {k: v.float() if v.is_floating_point() else v.clone() for k, v in PT.items()})
-    cfg = O.StepConfig(pi=True, pa=pa, ho=False, lambda_pa=0.5, weight_decay=5e-4, dropout_p=0.0)
-    o64 = O.distillation_step(P64[0], P64[1], None, x.float().double(), y, cfg)
-    o32 = O.distillation_step(P32[0], P32[1], None, x.float(), y, cfg)
-    model.set_input((x.float(), y, None, None))
+    _load_oracle_weights(model, PS, PT)
+    model.set_input((x, y, None, None))
     model.forward()
     model.G_solver.zero_grad()
     model.student_backward()
     gS = {k: p.grad.detach().cpu().double() for k, p in model.student.named_parameters()}
     model.G_solver.step()
-    return model, gS, o64, o32, P64, P32
+    return model, gS, gold["config1_pa" if pa else "config1_pi"]
 
 
-def _check_vs_live_oracle(model, gS, o64, o32, P64, P32, what):
-    for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
-        assert abs(getattr(model, k) - o64[k]) <= 1e-4 * abs(o64[k]) + 1e-12, (what, k, getattr(model, k), o64[k])
-    _report(what + " student gradients", [(k, float((gS[k] - gw).norm()), float((o32["grads_S"][k].double() - gw).norm()), float(gw.norm()))
-                                           for k, gw in o64["grads_S"].items()], GRAD_BOUND, GRAD_FLOOR)
+def _check_vs_oracle_records(model, gS, fx, what):
+    for k, want in fx["losses64"].items():
+        assert abs(getattr(model, k) - want) <= 1e-4 * abs(want) + 1e-12, (what, k, getattr(model, k), want)
+    _check_grads(gS, fx["grads_S"], what + " student gradients")
     after = model.student.state_dict()
-    for k in O.learnable_keys(P64[0]):
-        base = float((P32[0][k].double() - P64[0][k]).norm())
-        err = float((after[k].detach().cpu().double() - P64[0][k]).norm())
-        assert err <= GRAD_BOUND * base + 1e-5 * float(P64[0][k].norm()) + 1e-7, (what, k, err, base)
+    for k, r in fx["student_after"].items():
+        err, _ = _rec_err(after[k], r)
+        assert err <= GRAD_BOUND * r["base"] + 1e-5 * r["norm"] + 1e-7, (what, k, err, r["base"])
 
 
 def test_step_config1_vs_reference_golden():
@@ -538,30 +549,30 @@ def test_step_config1_vs_reference_golden():
     loss comparison -- 1e-4, north_star -- absorbs)."""
     gold = torch.load(os.path.join(GOLDEN_DIR, "reference_vectors.pt"), weights_only=False)["step_config1_pa"]
     assert tuple(gold["seeds"]) == (41, 42, 43)
-    model, gS, o64, o32, P64, P32 = _config1_step(pa=True)
+    model, gS, fx = _config1_step(pa=True)
     for k, gk in (("mc_G_loss", "mc"), ("pi_G_loss", "pi"), ("pa_G_loss", "pa")):
         want = float(gold[gk])
         print("config1 %-10s hip %.7g  reference %.7g  rel %.2e" % (k, getattr(model, k), want, abs(getattr(model, k) - want) / abs(want)))
         assert abs(getattr(model, k) - want) <= 1e-4 * abs(want), (k, getattr(model, k), want)
-    # gradients against the reference's strided samples; error budget from the live fp32-vs-fp64 CPU oracle
+    # gradients against the reference's strided samples; error budget = the recorded fp32-vs-fp64 CPU oracle deviation
     for k, rec in gold["grads"].items():
         if float(rec["norm"]) <= 1e-12:
             continue
-        base = float((o32["grads_S"][k].double() - o64["grads_S"][k]).norm())
+        base = fx["grads_S"][k]["base"]
         f = gS[k].reshape(-1)
         s = f[::rec["step"]][:rec["sample"].numel()]
         err = float((s - rec["sample"]).norm()) * math.sqrt(f.numel() / s.numel())
         # 16 samples per tensor: a coarse estimate, hence the factor 2 on top of the bound
         assert err <= 2 * (GRAD_BOUND * base + GRAD_FLOOR * float(rec["norm"])) + 1e-7, (k, err, base, float(rec["norm"]))
         assert abs(float(f.norm()) - float(rec["norm"])) <= GRAD_BOUND * base + GRAD_FLOOR * float(rec["norm"]) + 1e-7, k
-    _check_vs_live_oracle(model, gS, o64, o32, P64, P32, "config1 Pi+Pa")
+    _check_vs_oracle_records(model, gS, fx, "config1 Pi+Pa")
 
 
 def test_step_config1_pi_only():
     """BASELINE configs[0]: Pi only, batch 2, 256x256 -- the reference's own CPU-runnable case."""
-    model, gS, o64, o32, P64, P32 = _config1_step(pa=False)
-    assert model.pa_G_loss == 0.0
-    _check_vs_live_oracle(model, gS, o64, o32, P64, P32, "config1 Pi only")
+    model, gS, fx = _config1_step(pa=False)
+    assert model.pa_G_loss == 0.0 and fx["losses64"]["pa_G_loss"] == 0.0
+    _check_vs_oracle_records(model, gS, fx, "config1 Pi only")
 
 
 @pytest.mark.parametrize("C", [48, 2048, 6])
@@ -734,33 +745,20 @@ def test_teacher_stream_equals_serial_bit_for_bit_in_deterministic_mode(monkeypa
 def test_evaluate_main_full_size_student_on_gpu():
     """networks/evaluate.py:106-113,156-206 (whole=True) with the REAL student at the Cityscapes tile size 1024 x 2048 on the
     GPU -- channels-last network, 129 x 257 feature maps through the NHWC pyramid / fold kernels, fused upsample + argmax +
-    confusion -- against the float64 CPU oracle forward and the reference's numpy recipe.  Argmax near-ties may flip between
-    fp32 and fp64 logits: the confusion matrices must agree on all but 1e-4 of the pixels, mean IU to 1e-3."""
+    confusion -- against the confusion matrix of the float64 CPU oracle forward + the reference's numpy recipe, recorded in
+    tests/golden/gpu_suite_oracle.pt["eval_full"].  Argmax near-ties may flip between fp32 and fp64 logits: mean IU to 1e-3."""
     import numpy as np
     from structure_knowledge_distillation_amd.networks import evaluate as E
-    torch.manual_seed(8)
+    gen, gold = _suite()
+    fx = gold["eval_full"]
+    P, image, label, size = gen.eval_full_inputs()
+    _same_weights(gen.checksum(P), fx["checksums"], "student")
     S = pspnet_combine.Res_pspnet(pspnet_combine.BasicBlock, [2, 2, 2, 2], 19)
-    for k, v in S.state_dict().items():                       # trained-looking statistics: spread logits, fewer ties
-        if k.endswith("running_var"):
-            v.uniform_(0.5, 1.5)
-        elif k.endswith("running_mean"):
-            v.normal_(0, 0.1)
-    P64 = cpu_sd(S, torch.float64)
+    S.load_state_dict(P)
     S = S.to(DEV).to(memory_format=torch.channels_last)
-    H, W = 1024, 2048
-    g = torch.Generator().manual_seed(3)
-    image = torch.randn(1, 3, H, W, generator=g) * 57
-    label = torch.randint(0, 19, (1, H, W), generator=g)
-    label[0, :7] = 255
-    size = torch.tensor([[H - 10, W - 3, 3]])
     mean_iu, iu = E.evaluate_main(S, [(image, label, size, ["a"])], "0", "1024,2048", 19, whole=True)
-    with torch.no_grad():
-        logits = O.pspnet_forward(P64, image.double(), O.STUDENT, False)[0]
-        up = torch.nn.functional.interpolate(logits, size=(H, W), mode="bilinear", align_corners=True)
-    pred = up[0].permute(1, 2, 0).numpy().argmax(2).astype(np.uint8)              # evaluate.py:112, 186
-    gt = label[0].numpy()[:H - 10, :W - 3]
-    keep = gt != 255
-    cm = E.get_confusion_matrix(gt[keep], pred[:H - 10, :W - 3][keep], 19)         # evaluate.py:193-198
+    cm = fx["confusion"].numpy()
+    assert int(cm.sum()) == fx["pixels"]
     want_mean, want_iu = E.iou_from_confusion(cm)
     print("full-size evaluation: mean IU gpu %.6f oracle %.6f" % (mean_iu, want_mean))
     assert abs(mean_iu - want_mean) < 1e-3 and np.abs(np.asarray(iu) - np.asarray(want_iu)).max() < 2e-3
