@@ -304,13 +304,17 @@ def main():
             if world > 1:
                 spans = P.comm_timer.disable()
                 sa, wa = spans.get("syncabn", (0.0, 0)), spans.get("allreduce_wait", (0.0, 0))
+                sf = spans.get("syncabn_fused", (0.0, 0))
                 nb = len(model._s_reducer.buckets) + len(model._d_reducer.buckets)
                 mb = sum(b.flat.numel() * 4 for r in (model._s_reducer, model._d_reducer) for b in r.buckets) / 1e6
-                comm = {"syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": sa[1] // 3,
+                comm = {"syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": (sa[1] + sf[1]) // 3,
+                        # exchanges performed INSIDE the library's synchronised ABN calls (one register-resident launch when
+                        # the tensor fits); the span is the whole pass (statistics + exchange + normalise), not the exchange alone
+                        "syncabn_in_abn_calls": sf[1] // 3, "abn_sync_call_ms": round(sf[0] / 3, 3),
                         "allreduce_wait_ms": round(wa[0] / 3, 3), "buckets": nb, "gradient_MB": round(mb, 1),
                         "backend": dist.get_backend(),
                         "syncabn_transport": ("ipc mailboxes, one kernel per exchange (csrc/sync.hip)"
-                                              if any(P.SyncMailbox._by_group.values()) else "torch.distributed all_gather / all_reduce"),
+                                              if P.SyncMailbox.active() else "torch.distributed all_gather / all_reduce"),
                         "note": "per step, from 3 extra untimed steps with the D step serial: time rank 0's compute stream was "
                                 "blocked in the SyncABN exchanges (incl. waiting for the slowest rank) and in GradientAllReducer.finish() waits"}
         model._d_stream = d_stream

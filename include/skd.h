@@ -410,7 +410,8 @@ int skd_conv1x1_abn_pro_nhwc(int64_t M, int K, int N, const float *x, const floa
  *                              arguments and the arithmetic of skd_abn_combine_stats (bit-identical on the same data);
  *       skd_abn_sync_grad_stats stat (2, C) = [edz | eydz], in place <- sum_g w_g stat_g in rank order (w_g = weights[g],
  *                              or 1 / world when weights == NULL).
- *     A peer that does not arrive within 5 s poisons the outputs with NaN (no device hang).  world <= 16.
+ *     A peer that does not arrive within the context's limit (skd_sync_set_timeout) poisons the outputs with NaN (no
+ *     device hang) and raises status word 0 (section 13).  world <= 16.
  * ---------------------------------------------------------------------------------- */
 int skd_sync_handle_bytes(void);
 int skd_sync_max_floats(void);
@@ -421,6 +422,49 @@ int skd_sync_all_gather(void *ctx, int n, const float *src, float *gathered, skd
 int skd_abn_sync_stats(void *ctx, int C, const float *stat, const float *weights, float *mean, float *var,
                        float *running_mean, float *running_var, float momentum, double n, skd_stream_t stream);
 int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights, skd_stream_t stream);
+/* How long an exchange waits for a peer before it gives up (outputs NaN + status word 0 raised, section 13).  A fresh
+ * context waits 5 s -- its collective self-test must fail fast; the caller raises the limit to what torch.distributed
+ * would have waited once the group is known to work (utils/parallel.py: SKD_SYNC_TIMEOUT_S, default 600). */
+int skd_sync_set_timeout(void *ctx, double seconds);
+/* InPlaceABNSync (libs/functions.py:165-294) for channels-last tensors in ONE call per pass: the arguments of
+ * skd_abn_forward_train_nhwc / skd_abn_backward_nhwc / skd_abn_relu_backward_nhwc plus the mailbox context, the
+ * per-replica sample weights (NULL = equal shards) and -- forward -- n, the pooled sample count without weights / this
+ * replica's with (skd_abn_combine_stats).  When the tensor fits the register file the pass is ONE launch whose channel
+ * blocks' last arrivers exchange their block's statistics through the mailboxes inside it (8 / 12 bytes per element, no
+ * separate exchange launch); otherwise statistics -> skd_abn_sync_stats / skd_abn_sync_grad_stats -> normalise / dx.  Both
+ * forms are ONE exchange of the context's sequence and interoperate (per-channel-block flag words): ranks with ragged
+ * shards may take different forms.  SKD_ABN_SYNC_FUSED=0 keeps the three-launch form.  Backward: edz / eydz must be the
+ * two halves of one (2, C) buffer.  workspace: skd_abn_nhwc_workspace_floats(). */
+int skd_abn_forward_train_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *x, const float *residual, float *out,
+                                    const float *weight, const float *bias, float *running_mean, float *running_var,
+                                    float *mean, float *var, const float *replica_weights, float momentum, float eps,
+                                    int activation, float slope, double n, float *workspace, skd_stream_t stream);
+int skd_abn_backward_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *z, const float *dz, const float *var,
+                               const float *weight, const float *bias, float *edz, float *eydz, float *dx, float *dweight,
+                               float *dbias, const float *replica_weights, float eps, int activation, float slope,
+                               int accumulate, float *workspace, skd_stream_t stream);
+int skd_abn_relu_backward_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                    const float *mean, const float *var, const float *weight, const float *bias, float *edz,
+                                    float *eydz, float *dx, float *dres, float *dweight, float *dbias,
+                                    const float *replica_weights, float eps, int accumulate, float *workspace,
+                                    skd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * 13. Device-raised error words and the co-residency cap of the one-launch InPlace-ABN passes (round 4).
+ *     Two kinds of kernels wait inside a launch, both bounded: the mailbox exchanges (for a peer replica) and the
+ *     register-resident one-launch ABN passes (a grid barrier per channel block).  A wait that runs out writes NaN into
+ *     its outputs AND stores a code into a host-mapped buffer of skd_status_words() 32-bit words that the host reads
+ *     without synchronising the device: word 0 = an exchange timed out (value: sequence number | 0x80000000), word 1 = a
+ *     grid barrier timed out (the launch was not co-resident).  The Python side checks once per step and raises.
+ *     skd_abn_set_fused_max_workgroups(n): upper bound of the workgroups of a one-launch pass on top of the device's own
+ *     (its compute-unit count, queried per device -- a CPX partition or a CU-masked device gets a smaller grid or the
+ *     two-launch path, never a barrier that cannot complete); ranks sharing one device must share its compute units.
+ *     n > 0 sets the bound, n == 0 restores the default, n < 0 only queries; returns the effective cap on the current device.
+ * ---------------------------------------------------------------------------------- */
+int skd_status_words(void);
+int skd_status_read(unsigned *out);
+int skd_status_clear(void);
+int skd_abn_set_fused_max_workgroups(int n);
 
 /* ------------------------------------------------------------------------------------
  * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210

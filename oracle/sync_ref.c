@@ -27,8 +27,28 @@ typedef struct {
   size_t bytes;
   int world, rank;
   unsigned seq;
+  double timeout_s;        /* skd_sync_set_timeout: 5 s while a context is being set up */
   char name[HANDLE_BYTES];
 } sync_ctx;
+
+/* device-raised error words of csrc/status.hip (include/skd.h section 13), here plain host words */
+#define STATUS_WORDS 4
+static unsigned g_status[STATUS_WORDS];
+int skd_status_words(void) { return STATUS_WORDS; }
+int skd_status_read(unsigned *out) {
+  if (!out) return 0;
+  for (int i = 0; i < STATUS_WORDS; ++i) out[i] = __atomic_load_n(&g_status[i], __ATOMIC_ACQUIRE);
+  return 1;
+}
+int skd_status_clear(void) {
+  for (int i = 0; i < STATUS_WORDS; ++i) __atomic_store_n(&g_status[i], 0u, __ATOMIC_RELEASE);
+  return 1;
+}
+/* channel blocks of a C-channel statistics vector = flag words of its exchange (csrc/sync_dev.hpp) */
+static int channel_blocks(int C) {
+  if (C < 4 || (C & (C - 1)) || C > 1024) return 1;
+  return C >= 256 ? 4 : (C >= 128 ? 2 : 1);
+}
 
 int skd_sync_handle_bytes(void) { return HANDLE_BYTES; }
 int skd_sync_max_floats(void) { return MAX_FLOATS; }
@@ -44,6 +64,7 @@ void *skd_sync_create(int world, int rank, void *handle_out) {
   if (!c) return NULL;
   c->world = world;
   c->rank = rank;
+  c->timeout_s = 5.0;
   c->bytes = sizeof(float) * 2 * (size_t)world * SLOT_FLOATS;
   snprintf(c->name, sizeof c->name, "/skdsync_%ld_%u", (long)getpid(), counter++);
   const int fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -97,34 +118,52 @@ static int connected(const sync_ctx *c) {
   return 1;
 }
 
-/* steps (1)-(3) of csrc/sync.hip: payload into every mailbox, flags, wait for all flags of the own mailbox (5 s) */
-static int exchange(sync_ctx *c, unsigned seq, int n, const float *src) {
+int skd_sync_set_timeout(void *ctx, double seconds) {
+  sync_ctx *c = (sync_ctx *)ctx;
+  if (!c || !(seconds > 0.0) || seconds > 1e6) return 0;
+  c->timeout_s = seconds;
+  return 1;
+}
+
+/* steps (1)-(3) of csrc/sync_dev.hpp: payload into every mailbox, the sequence number into the `nwords` flag words (one per
+ * channel block) of this writer's slot, wait for the same words of all writers in the own mailbox (bounded: NaN + status word) */
+static int exchange(sync_ctx *c, unsigned seq, int n, const float *src, int nwords) {
   const int parity = (int)(seq & 1u);
   for (int r = 0; r < c->world; ++r) memcpy(slot_of(c->mail[r], c->world, parity, c->rank) + HEADER_FLOATS, src, sizeof(float) * (size_t)n);
   for (int r = 0; r < c->world; ++r)
-    __atomic_store_n((unsigned *)slot_of(c->mail[r], c->world, parity, c->rank), seq, __ATOMIC_RELEASE);
+    for (int w = 0; w < nwords; ++w)
+      __atomic_store_n((unsigned *)slot_of(c->mail[r], c->world, parity, c->rank) + w, seq, __ATOMIC_RELEASE);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int r = 0; r < c->world; ++r) {
-    const unsigned *flag = (const unsigned *)slot_of(c->mail[c->rank], c->world, parity, r);
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) return 0;
-      usleep(20);
+    for (int w = 0; w < nwords; ++w) {
+      const unsigned *flag = (const unsigned *)slot_of(c->mail[c->rank], c->world, parity, r) + w;
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > c->timeout_s) {
+          __atomic_store_n(&g_status[0], seq | 0x80000000u, __ATOMIC_RELEASE);
+          return 0;
+        }
+        usleep(20);
+      }
     }
   }
   return 1;
 }
 
-int skd_sync_all_gather(void *ctx, int n, const float *src, float *gathered, stream_t st) {
-  (void)st;
+static int gather_words(void *ctx, int n, const float *src, float *gathered, int nwords) {
   sync_ctx *c = (sync_ctx *)ctx;
   if (!connected(c) || n <= 0 || n > MAX_FLOATS || !src || !gathered) return 0;
   const unsigned seq = ++c->seq;
-  const int good = exchange(c, seq, n, src);
+  const int good = exchange(c, seq, n, src, nwords);
   for (int r = 0; r < c->world; ++r)
     for (int i = 0; i < n; ++i) gathered[(size_t)r * n + i] = good ? slot_of(c->mail[c->rank], c->world, (int)(seq & 1u), r)[HEADER_FLOATS + i] : NAN;
   return 1;
+}
+
+int skd_sync_all_gather(void *ctx, int n, const float *src, float *gathered, stream_t st) {
+  (void)st;
+  return gather_words(ctx, n, src, gathered, 1);
 }
 
 int skd_abn_combine_stats(int G, int C, const float *gathered, const float *weights, int rank, float *mean, float *var, float *rm,
@@ -136,18 +175,19 @@ int skd_abn_sync_stats(void *ctx, int C, const float *stat, const float *weights
   if (!connected(c) || C <= 0 || 2 * C > MAX_FLOATS || !stat || !mean || !var) return 0;
   float *g = (float *)malloc(sizeof(float) * (size_t)c->world * 2 * C);
   if (!g) return 0;
-  int r = skd_sync_all_gather(ctx, 2 * C, stat, g, st);
+  int r = gather_words(ctx, 2 * C, stat, g, channel_blocks(C));
   r = r && skd_abn_combine_stats(c->world, C, g, weights, c->rank, mean, var, running_mean, running_var, momentum, n, st);
   free(g);
   return r;
 }
 
 int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights, stream_t st) {
+  (void)st;
   sync_ctx *c = (sync_ctx *)ctx;
   if (!connected(c) || C <= 0 || 2 * C > MAX_FLOATS || !stat) return 0;
   float *g = (float *)malloc(sizeof(float) * (size_t)c->world * 2 * C);
   if (!g) return 0;
-  const int r = skd_sync_all_gather(ctx, 2 * C, stat, g, st);
+  const int r = gather_words(ctx, 2 * C, stat, g, channel_blocks(C));
   for (int i = 0; r && i < 2 * C; ++i) {
     float s = 0.f;
     for (int q = 0; q < c->world; ++q) {
@@ -161,3 +201,66 @@ int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights,
   free(g);
   return r;
 }
+
+/* ---- InPlaceABNSync for channels-last tensors in one call (include/skd.h section 2, "*_sync" entries): the product runs one
+ *      register-resident launch with the exchange inside it when the tensor fits; the arithmetic is statistics -> exchange +
+ *      combine -> normalise (forward) and reduce -> exchange + weighted sum -> dx (backward), restated here from the pieces ---- */
+int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C);
+int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *ws, stream_t st);
+int skd_abn_apply_nhwc_to(int64_t rows, int C, const float *x, const float *residual, float *out, const float *mean, const float *var,
+                          const float *weight, const float *bias, float eps, int act, float slope, stream_t st);
+int skd_abn_backward_reduce_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *weight, const float *bias,
+                                 float *edz, float *eydz, float eps, int act, float slope, float *ws, stream_t st);
+int skd_abn_backward_dx_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                             const float *bias, const float *edz, const float *eydz, float *dx, float *dweight, float *dbias, float eps,
+                             int act, float slope, int accumulate, stream_t st);
+int skd_abn_relu_backward_reduce_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
+                                      const float *var, float *edz, float *eydz, float eps, float *ws, stream_t st);
+int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
+                                  const float *var, const float *weight, const float *edz, const float *eydz, float *dx, float *dres,
+                                  float *dweight, float *dbias, float eps, int accumulate, stream_t st);
+int skd_abn_relu_backward_reduce_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean, const float *var,
+                                        const float *weight, const float *bias, float *edz, float *eydz, float eps, float *ws, stream_t st);
+int skd_abn_relu_backward_dx_nhwc_x(int64_t rows, int C, const float *x, const float *dout, const float *mean, const float *var,
+                                    const float *weight, const float *bias, const float *edz, const float *eydz, float *dx,
+                                    float *dweight, float *dbias, float eps, int accumulate, stream_t st);
+
+int skd_abn_forward_train_nhwc_sync(void *ctx, int64_t rows, int C, const float *x, const float *residual, float *out,
+                                    const float *weight, const float *bias, float *rm, float *rv, float *mean, float *var,
+                                    const float *replica_weights, float momentum, float eps, int act, float slope, double n, float *ws,
+                                    stream_t st) {
+  if (!ctx || !x || !out || !mean || !var) return 0;
+  float *local = (float *)malloc(sizeof(float) * 2 * (size_t)C);
+  if (!local) return 0;
+  int r = skd_abn_stats_nhwc(rows, C, x, local, local + C, ws, st);
+  r = r && skd_abn_sync_stats(ctx, C, local, replica_weights, mean, var, rm, rv, momentum, n, st);
+  free(local);
+  return r && skd_abn_apply_nhwc_to(rows, C, x, residual, out, mean, var, weight, bias, eps, act, slope, st);
+}
+
+int skd_abn_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                               const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias,
+                               const float *replica_weights, float eps, int act, float slope, int accumulate, float *ws, stream_t st) {
+  if (!ctx || eydz != edz + C) return 0;
+  if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, act, slope, ws, st)) return 0;
+  if (!skd_abn_sync_grad_stats(ctx, C, edz, replica_weights, st)) return 0;
+  return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, accumulate, st);
+}
+
+int skd_abn_relu_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                    const float *mean, const float *var, const float *weight, const float *bias, float *edz, float *eydz,
+                                    float *dx, float *dres, float *dweight, float *dbias, const float *replica_weights, float eps,
+                                    int accumulate, float *ws, stream_t st) {
+  if (!ctx || eydz != edz + C || (out == NULL && dres != NULL)) return 0;
+  if (out == NULL) {
+    if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, ws, st)) return 0;
+    if (!skd_abn_sync_grad_stats(ctx, C, edz, replica_weights, st)) return 0;
+    return skd_abn_relu_backward_dx_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, accumulate, st);
+  }
+  if (!skd_abn_relu_backward_reduce_nhwc(rows, C, x, out, dout, mean, var, edz, eydz, eps, ws, st)) return 0;
+  if (!skd_abn_sync_grad_stats(ctx, C, edz, replica_weights, st)) return 0;
+  return skd_abn_relu_backward_dx_nhwc(rows, C, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, accumulate, st);
+}
+
+/* the grid-barrier cap of the product's one-launch passes has no host counterpart: accepted, reports "whole device" */
+int skd_abn_set_fused_max_workgroups(int n) { (void)n; return 256; }

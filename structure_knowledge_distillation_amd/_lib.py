@@ -107,6 +107,14 @@ SIGNATURES = {
     "skd_sync_all_gather": (_I, [_P, _I, _P, _P, _P]),
     "skd_abn_sync_stats": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _D, _P]),
     "skd_abn_sync_grad_stats": (_I, [_P, _I, _P, _P, _P]),
+    "skd_sync_set_timeout": (_I, [_P, _D]),
+    "skd_abn_forward_train_nhwc_sync": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _F, _D, _P, _P]),
+    "skd_abn_backward_nhwc_sync": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _I, _P, _P]),
+    "skd_abn_relu_backward_nhwc_sync": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P]),
+    "skd_status_words": (_I, []),
+    "skd_status_read": (_I, [_P]),
+    "skd_status_clear": (_I, []),
+    "skd_abn_set_fused_max_workgroups": (_I, [_I]),
 }
 
 _lib = None
@@ -217,6 +225,39 @@ def install_test_backend(backend):
 
 def test_backend_active():
     return _test_backend is not None
+
+
+class SkdDeviceError(RuntimeError):
+    """A kernel gave up waiting inside a launch (include/skd.h section 13): its outputs are NaN from there on."""
+
+
+_STATUS_MEANING = {
+    0: "a cross-replica InPlace-ABN exchange timed out waiting for a peer rank (SKD_SYNC_TIMEOUT_S): a rank stalled, died or "
+       "called the synchronised layers in a different order; statistics are NaN from that exchange on",
+    1: "the grid barrier of a one-launch InPlace-ABN pass timed out: its workgroups were not co-resident (device shared with "
+       "another grid-barrier launch, partitioned or CU-masked device) -- set SKD_ABN_FUSED=0 or lower "
+       "skd_abn_set_fused_max_workgroups",
+}
+
+
+def device_status():
+    """The device-raised error words (no device synchronisation), or None when the buffer does not exist."""
+    lib = get()
+    n = lib.skd_status_words()
+    buf = (ctypes.c_uint * n)()
+    if not lib.skd_status_read(ctypes.cast(buf, ctypes.c_void_p)):
+        return None
+    return list(buf)
+
+
+def raise_on_device_errors():
+    """Called once per step (NetModel.optimize_parameters) and after a logged scalar has been read back: turns a timed-out
+    in-kernel wait into an exception instead of NaN that silently spreads through the gradient all-reduce."""
+    words = device_status()
+    if words and any(words):
+        get().skd_status_clear()
+        what = "; ".join("%s (code 0x%08x)" % (_STATUS_MEANING.get(i, "status word %d" % i), w) for i, w in enumerate(words) if w)
+        raise SkdDeviceError("structure_knowledge_distillation_amd: " + what)
 
 
 def check(ok, what):

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "skd_common.hpp"
+#include "sync_dev.hpp"
 
 namespace skd {
 namespace {
@@ -1419,12 +1420,15 @@ constexpr uint64_t kFuseSpinTicks = 200000000ull;   // wall_clock64(): 100 MHz
 __device__ __forceinline__ unsigned gen_load(const unsigned *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// thread 0 spins until the generation word moves on from gen0; false = timed out
-__device__ __forceinline__ bool gen_wait(const unsigned *p, unsigned gen0) {
+// thread 0 spins until the generation word moves on from gen0; false = timed out (status word kStatusFusedTimeout raised)
+__device__ __forceinline__ bool gen_wait(const unsigned *p, unsigned gen0, uint64_t ticks, unsigned *status) {
   const uint64_t t0 = wall_clock64();
   while (gen_load(p) == gen0) {
     __builtin_amdgcn_s_sleep(4);
-    if (wall_clock64() - t0 > kFuseSpinTicks) return false;
+    if (wall_clock64() - t0 > ticks) {
+      raise_status(status, kStatusFusedTimeout, 1u);
+      return false;
+    }
   }
   return true;
 }
@@ -1443,10 +1447,10 @@ struct FuseGeom {
 };
 
 // NRmax rows per thread: geometry with the most workgroups (<= 256 / CB per channel block) and the fewest rows each
-static bool make_fuse_geom(int64_t rows, int C, int nr_max, FuseGeom &f) {
-  if (!make_red_geom(rows, C, 1, f.r)) return false;
+static bool make_fuse_geom(int64_t rows, int C, int nr_max, int max_wg, FuseGeom &f) {
+  if (max_wg < kRedMaxCB || !make_red_geom(rows, C, 1, f.r)) return false;
   RedGeom &g = f.r;
-  const int64_t cap = kRedMaxWG / g.CB;
+  const int64_t cap = max_wg / g.CB;
   const int64_t want = cdiv(rows, g.rpp);
   g.RG = (int)(want < cap ? want : cap);
   const int64_t nr = cdiv(rows, (int64_t)g.RG * g.rpp);
@@ -1456,11 +1460,16 @@ static bool make_fuse_geom(int64_t rows, int C, int nr_max, FuseGeom &f) {
   return true;
 }
 
-template <int ACT, bool HAS_RES, int NR>
+// SYNC: the cross-replica exchange of InPlaceABNSync (libs/functions.py:185-209) happens INSIDE the launch: the channel
+// block's last arriver stores the block's local [mean | var] into every replica's mailbox, raises / awaits the block's flag
+// word (sync_dev.hpp) and applies the combine rule before it releases the block's workgroups -- the register-resident
+// one-launch form survives N > 1 (round 3 fell back to stats + exchange + apply: three launches, 12 B/element).
+template <int ACT, bool HAS_RES, int NR, bool SYNC>
 __global__ __launch_bounds__(kRedThreads) void abn_fwd_fused_nhwc_kernel(
     const float *x, const float *res, float *out, float *__restrict__ part, unsigned *counters, unsigned *gens,
     float *mean, float *var, float *running_mean, float *running_var, const float *__restrict__ weight,
-    const float *__restrict__ bias, int64_t rows, RedGeom g, int nr, float momentum, float eps, float slope) {
+    const float *__restrict__ bias, int64_t rows, RedGeom g, int nr, float momentum, float eps, float slope,
+    SyncArgs sy, const float *__restrict__ rweights, float n_pooled) {
   __shared__ double lds[kRedThreads * 4];
   __shared__ double fin[kRedThreads * 2];
   __shared__ unsigned ticket_s;
@@ -1497,6 +1506,7 @@ __global__ __launch_bounds__(kRedThreads) void abn_fwd_fused_nhwc_kernel(
   }
   const int CW = g.CW4 * 4;
   bool good = true;
+  float loc_m = 0.f, loc_v = 0.f;            // SYNC: this replica's statistics of channel cb * CW + t
   if (red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) {
     if (t < CW) {
       const int c = cb * CW + t;
@@ -1507,16 +1517,39 @@ __global__ __launch_bounds__(kRedThreads) void abn_fwd_fused_nhwc_kernel(
       const int64_t ldr = (int64_t)g.C4 * 4;
       const double Kc = (double)median3(x[c], x[(rows / 2) * ldr + c], x[(rows - 1) * ldr + c]);
       const float m_f = (float)(Kc + d), v_f = (float)vv;
-      store_wt4(mean + c, m_f);
-      store_wt4(var + c, v_f);
-      if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
-      if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v_f, (float)rows);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (SYNC) {
+        loc_m = m_f;
+        loc_v = v_f;
+      } else {
+        store_wt4(mean + c, m_f);
+        store_wt4(var + c, v_f);
+        if (running_mean != nullptr) running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * m_f;
+        if (running_var != nullptr) running_var[c] = running_var[c] * (1.f - momentum) + momentum * unbiased_of(v_f, (float)rows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    if (SYNC) {
+      const int Ct = g.C4 * 4, c = cb * CW + t;
+      const bool arrived = sync_exchange(sy, cb, 1, [&](float *dst) {
+        if (t < CW) {
+          store_sys(dst + c, loc_m);
+          store_sys(dst + Ct + c, loc_v);
+        }
+      }, &ticket_s);
+      if (t < CW) {
+        float m, v;
+        combine_channel(sy.d.world, Ct, c, [&](int gq, int j) { return sync_payload(sy.d, sy.seq, gq, j); }, rweights, sy.d.rank,
+                        n_pooled, momentum, m, v, arrived ? running_mean : nullptr, arrived ? running_var : nullptr);
+        store_wt4(mean + c, arrived ? m : __builtin_nanf(""));
+        store_wt4(var + c, arrived ? v : __builtin_nanf(""));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     if (t == 0) __hip_atomic_store(gens + cb, gen_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s) ? 1u : 0u;
+    // (SYNC: the block's last arriver may itself be waiting for a peer replica: its limit on top of the grid barrier's own)
+    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s, kFuseSpinTicks + (SYNC ? sy.spin_ticks : 0ull), sy.status) ? 1u : 0u;
     __syncthreads();
     good = ticket_s != 0u;
   }
@@ -1548,12 +1581,13 @@ __global__ __launch_bounds__(kRedThreads) void abn_fwd_fused_nhwc_kernel(
 
 // Backward, both passes in one launch.  MODE as in abn_grad_nhwc2_kernel / abn_grad_dx_nhwc_kernel; a thread keeps (y, dz) of
 // its NR rows -- the masked / activation-undone gradient and the normalised input -- between the phases.
-template <int ACT, int MODE, bool WRITE_RES, int NR>
+// SYNC: [edz | eydz] of the channel block are exchanged by the block's last arriver inside the launch (functions.py:263-280).
+template <int ACT, int MODE, bool WRITE_RES, int NR, bool SYNC>
 __global__ __launch_bounds__(kRedThreads) void abn_bwd_fused_nhwc_kernel(
     const float *a_, const float *b_, const float *c_, const float *__restrict__ mean, const float *__restrict__ var,
     const float *__restrict__ weight, const float *__restrict__ bias, float *__restrict__ part, unsigned *counters,
     unsigned *gens, float *edz, float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps, float slope,
-    int64_t rows, RedGeom g, int nr, int accumulate) {
+    int64_t rows, RedGeom g, int nr, int accumulate, SyncArgs sy, const float *__restrict__ rweights) {
   __shared__ double lds[kRedThreads * 4];
   __shared__ double fin[kRedThreads * 2];
   __shared__ unsigned ticket_s;
@@ -1639,11 +1673,29 @@ __global__ __launch_bounds__(kRedThreads) void abn_bwd_fused_nhwc_kernel(
   const int CW = g.CW4 * 4;
   bool good = true;
   if (red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) {
+    float loc_e = 0.f, loc_ey = 0.f;
+    if (t < CW) {
+      const double cnt = (double)rows;
+      loc_e = (float)(fin[(t >> 2) * 8 + (t & 3)] / cnt);          // bn.cu:176
+      loc_ey = (float)(fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt);     // bn.cu:177
+    }
+    bool arrived = true;
+    if (SYNC) {
+      const int Ct = g.C4 * 4, c = cb * CW + t;
+      arrived = sync_exchange(sy, cb, 1, [&](float *dst) {
+        if (t < CW) {
+          store_sys(dst + c, loc_e);
+          store_sys(dst + Ct + c, loc_ey);
+        }
+      }, &ticket_s);
+      if (t < CW) {
+        loc_e = arrived ? sync_weighted_sum(sy.d, sy.seq, c, rweights) : __builtin_nanf("");
+        loc_ey = arrived ? sync_weighted_sum(sy.d, sy.seq, Ct + c, rweights) : __builtin_nanf("");
+      }
+    }
     if (t < CW) {
       const int c = cb * CW + t;
-      const double cnt = (double)rows;
-      const float e_f = (float)(fin[(t >> 2) * 8 + (t & 3)] / cnt);          // bn.cu:176
-      const float ey_f = (float)(fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt);     // bn.cu:177
+      const float e_f = loc_e, ey_f = loc_ey;
       store_wt4(edz + c, e_f);
       store_wt4(eydz + c, ey_f);
       const float norm = (float)rows;
@@ -1658,7 +1710,7 @@ __global__ __launch_bounds__(kRedThreads) void abn_bwd_fused_nhwc_kernel(
     __syncthreads();
     if (t == 0) __hip_atomic_store(gens + cb, gen_s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s) ? 1u : 0u;
+    if (t == 0) ticket_s = gen_wait(gens + cb, gen_s, kFuseSpinTicks + (SYNC ? sy.spin_ticks : 0ull), sy.status) ? 1u : 0u;
     __syncthreads();
     good = ticket_s != 0u;
   }
@@ -1753,22 +1805,88 @@ static bool fused_enabled() {
   return mode == 1;
 }
 constexpr int kFuseFwdMaxNR = 17, kFuseBwdMaxNR = 9;
+// SKD_ABN_SYNC_FUSED=0: the synchronised entries keep the three-launch form (statistics, exchange kernel, normalise): A/B switch
+static bool sync_fused_enabled() {          // read on every call: tests switch it inside one process
+  const char *e = getenv("SKD_ABN_SYNC_FUSED");
+  return !(e != nullptr && e[0] == '0');
+}
 
-// returns -1 when the call does not take the fused path (not enabled, activation / size not covered), else ok()
-template <bool HAS_RES>
+// The grid barrier of the one-launch passes needs every workgroup of the launch co-resident: the grid is
+// capped by what THIS device can hold at one 1024-thread workgroup per compute unit -- 256 on a whole MI355X, 32 on a
+// CPX partition, fewer under HSA_CU_MASK -- queried once per device, never assumed.  skd_abn_set_fused_max_workgroups()
+// lowers it further (ranks that share one device must share its compute units: utils/parallel.py does that).  A cap too
+// small for a tensor (rows per thread > NR) simply sends that call to the two-launch path.
+struct FuseCap {
+  int cap[64];
+  bool known[64];
+};
+static FuseCap g_fuse_cap = {};
+static int g_fuse_user_cap = kRedMaxWG;
+
+static int fuse_wg_cap() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!g_fuse_cap.known[dev]) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      cus = 0;
+    }
+    const char *e = getenv("SKD_ABN_FUSED_MAXWG");
+    int env_cap = kRedMaxWG;
+    if (e != nullptr && e[0] != 0) env_cap = atoi(e);
+    int cap = cus < kRedMaxWG ? cus : kRedMaxWG;
+    if (env_cap < cap) cap = env_cap;
+    g_fuse_cap.cap[dev] = cap > 0 ? cap : 0;
+    g_fuse_cap.known[dev] = true;
+  }
+  const int cap = g_fuse_cap.cap[dev];
+  return cap < g_fuse_user_cap ? cap : g_fuse_user_cap;
+}
+
+// one workgroup per compute unit must actually be launchable for THIS instantiation (registers, LDS): checked once per
+// instantiation and device with the occupancy query, not assumed
+template <class K>
+static bool fuse_kernel_fits(K kernel, PerDeviceFlag &checked, PerDeviceFlag &fits) {
+  bool *c = checked.get(), *f = fits.get();
+  if (c == nullptr || f == nullptr) return false;
+  if (!*c) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void *>(kernel), kRedThreads, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      blocks = 0;
+    }
+    *f = blocks >= 1;
+    *c = true;
+  }
+  return *f;
+}
+#define SKD_FUSE_LAUNCH(KERNEL, ...)                                                        \
+  do {                                                                                      \
+    static PerDeviceFlag checked_, fits_;                                                   \
+    if (!fuse_kernel_fits(KERNEL, checked_, fits_)) return -1;                              \
+    KERNEL<<<grid, block, 0, st>>>(__VA_ARGS__);                                            \
+  } while (0)
+
+static SyncArgs no_sync() {
+  SyncArgs a = {};
+  a.status = status_words();
+  return a;
+}
+
+// returns -1 when the call does not take the fused path (not enabled, activation / size not covered), else ok().
+// sy != nullptr: the cross-replica exchange happens inside the launch (the caller has drawn sy with sync_next()).
+template <bool HAS_RES, bool SYNC>
 static int launch_fwd_fused(int act, int64_t rows, int C, const float *x, const float *res, float *out, float *mean,
                             float *var, float *running_mean, float *running_var, const float *weight, const float *bias,
-                            float momentum, float eps, float slope, float *workspace, hipStream_t st) {
-  if (!fused_enabled() || act == SKD_ACT_ELU || (HAS_RES && act != SKD_ACT_RELU)) return -1;
-  FuseGeom f;
-  if (!make_fuse_geom(rows, C, kFuseFwdMaxNR, f)) return -1;
+                            float momentum, float eps, float slope, float *workspace, hipStream_t st, const FuseGeom &f,
+                            const SyncArgs &sy, const float *rweights, float n_pooled) {
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
   const dim3 grid((unsigned)(f.r.RG * f.r.CB)), block(kRedThreads);
-#define SKD_FWD_FUSED(ACT_, NR_)                                                                                         \
-  abn_fwd_fused_nhwc_kernel<ACT_, HAS_RES, NR_><<<grid, block, 0, st>>>(x, res, out, workspace, cnt, red_gens(cnt), mean, var, \
-                                                                        running_mean, running_var, weight, bias, rows, f.r, \
-                                                                        f.nr, momentum, eps, slope)
+#define SKD_FWD_FUSED(ACT_, NR_)                                                                                              \
+  SKD_FUSE_LAUNCH((abn_fwd_fused_nhwc_kernel<ACT_, HAS_RES, NR_, SYNC>), x, res, out, workspace, cnt, red_gens(cnt), mean, var, \
+                  running_mean, running_var, weight, bias, rows, f.r, f.nr, momentum, eps, slope, sy, rweights, n_pooled)
 #define SKD_FWD_FUSED_NR(ACT_)                 \
   if (f.nr <= 5) SKD_FWD_FUSED(ACT_, 5);       \
   else if (f.nr <= 9) SKD_FWD_FUSED(ACT_, 9);  \
@@ -1787,28 +1905,33 @@ static int launch_fwd_fused(int act, int64_t rows, int C, const float *x, const 
   return ok();
 }
 
+// does this forward take the one-launch form?  (decided BEFORE a sequence number is drawn for the exchange)
+static bool fwd_fused_geom(int act, bool has_res, int64_t rows, int C, FuseGeom &f) {
+  if (!fused_enabled() || act == SKD_ACT_ELU || (has_res && act != SKD_ACT_RELU)) return false;
+  if (act != SKD_ACT_RELU && act != SKD_ACT_LEAKY_RELU && act != SKD_ACT_NONE) return false;
+  return make_fuse_geom(rows, C, kFuseFwdMaxNR, fuse_wg_cap(), f);
+}
+static bool bwd_fused_geom(int64_t rows, int C, FuseGeom &f) {
+  return fused_enabled() && make_fuse_geom(rows, C, kFuseBwdMaxNR, fuse_wg_cap(), f);
+}
+
 // MODE 0: (z, dz) of the in-place ABN; MODE 1: (x, out, dout); MODE 2: (x, dout).  -1 = not taken.
-template <int ACT, int MODE, bool WRITE_RES>
+template <int ACT, int MODE, bool WRITE_RES, bool SYNC>
 static int launch_bwd_fused(int64_t rows, int C, const float *a, const float *b, const float *c, const float *mean,
                             const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
                             float *dres, float *dweight, float *dbias, float eps, float slope, int accumulate,
-                            float *workspace, hipStream_t st) {
-  if (!fused_enabled()) return -1;
-  FuseGeom f;
-  if (!make_fuse_geom(rows, C, kFuseBwdMaxNR, f)) return -1;
+                            float *workspace, hipStream_t st, const FuseGeom &f, const SyncArgs &sy, const float *rweights) {
   unsigned *cnt = red_counters();
   if (cnt == nullptr) return 0;
   const dim3 grid((unsigned)(f.r.RG * f.r.CB)), block(kRedThreads);
   // instantiations sized to the step's layers (5 rows per thread at C = 128, 9 at C = 64 / 256): one row more and the 18 registers
   // per row (y, dz) of the NR = 10 form spilled 11-13 of them (PMC: 14.3 instead of 12 bytes per element)
   if (f.nr <= 5)
-    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 5><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
-                                                                               red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
-                                                                               eps, slope, rows, f.r, f.nr, accumulate);
+    SKD_FUSE_LAUNCH((abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 5, SYNC>), a, b, c, mean, var, weight, bias, workspace, cnt,
+                    red_gens(cnt), edz, eydz, dx, dres, dweight, dbias, eps, slope, rows, f.r, f.nr, accumulate, sy, rweights);
   else
-    abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 9><<<grid, block, 0, st>>>(a, b, c, mean, var, weight, bias, workspace, cnt,
-                                                                               red_gens(cnt), edz, eydz, dx, dres, dweight, dbias,
-                                                                               eps, slope, rows, f.r, f.nr, accumulate);
+    SKD_FUSE_LAUNCH((abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 9, SYNC>), a, b, c, mean, var, weight, bias, workspace, cnt,
+                    red_gens(cnt), edz, eydz, dx, dres, dweight, dbias, eps, slope, rows, f.r, f.nr, accumulate, sy, rweights);
   return ok();
 }
 
@@ -2070,8 +2193,9 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 int64_t skd_abn_nhwc_workspace_floats(int64_t rows, int C) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g)) return 0;
-  // workgroup-major partial rows of the one-launch reductions: CB * RG <= kRedMaxWG rows of 2 * C / CB floats
-  return (int64_t)kRedMaxWG * 2 * C;
+  // workgroup-major partial rows of the one-launch reductions: CB * RG <= kRedMaxWG rows of 2 * C / CB floats, then 2 * C floats
+  // for this replica's own [mean | var] in the synchronised entries' three-launch form
+  return (int64_t)kRedMaxWG * 2 * C + 2 * (int64_t)C;
 }
 
 int skd_abn_stats_nhwc(int64_t rows, int C, const float *x, float *mean, float *var, float *workspace,
@@ -2100,14 +2224,46 @@ int skd_abn_forward_train_nhwc(int64_t rows, int C, const float *x, const float 
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !mean || !var || !workspace) return 0;
   if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual))) return 0;
   hipStream_t st = as_stream(stream);
-  if (aligned16(mean) && aligned16(var)) {
-    const int r = residual ? launch_fwd_fused<true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
-                                                    weight, bias, momentum, eps, slope, workspace, st)
-                           : launch_fwd_fused<false>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
-                                                     weight, bias, momentum, eps, slope, workspace, st);
+  FuseGeom f;
+  if (aligned16(mean) && aligned16(var) && fwd_fused_geom(activation, residual != nullptr, rows, C, f)) {
+    const SyncArgs sy = no_sync();
+    const int r = residual ? launch_fwd_fused<true, false>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                           weight, bias, momentum, eps, slope, workspace, st, f, sy, nullptr, 0.f)
+                           : launch_fwd_fused<false, false>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                            weight, bias, momentum, eps, slope, workspace, st, f, sy, nullptr, 0.f);
     if (r >= 0) return r;
   }
   if (!launch_stats_nhwc2(rows, C, x, mean, var, running_mean, running_var, momentum, workspace, st)) return 0;
+  return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
+                  : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
+}
+
+// InPlaceABNSync forward (libs/functions.py:165-218) for a channels-last tensor in ONE call: the arguments of
+// skd_abn_forward_train_nhwc plus the mailbox context (skd_sync_create), the per-replica sample weights (NULL = equal
+// shards) and n (the pooled sample count without weights, this replica's with: skd_abn_combine_stats).  One
+// register-resident launch with the exchange inside it when the tensor fits; else statistics -> skd_abn_sync_stats ->
+// normalise.  Either way ONE exchange (one sequence number) in the same place of every rank's call order.
+int skd_abn_forward_train_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *x, const float *residual, float *out,
+                                    const float *weight, const float *bias, float *running_mean, float *running_var,
+                                    float *mean, float *var, const float *replica_weights, float momentum, float eps,
+                                    int activation, float slope, double n, float *workspace, skd_stream_t stream) {
+  NhwcGeom g;
+  if (!sync_ctx || !make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !out || !mean || !var || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual)) || 2 * C > kSyncMaxFloats) return 0;
+  hipStream_t st = as_stream(stream);
+  FuseGeom f;
+  if (sync_fused_enabled() && aligned16(mean) && aligned16(var) && fwd_fused_geom(activation, residual != nullptr, rows, C, f)) {
+    SyncArgs sy;
+    if (!sync_next(sync_ctx, sy)) return 0;
+    const int r = residual ? launch_fwd_fused<true, true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                          weight, bias, momentum, eps, slope, workspace, st, f, sy, replica_weights, (float)n)
+                           : launch_fwd_fused<false, true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
+                                                           weight, bias, momentum, eps, slope, workspace, st, f, sy, replica_weights, (float)n);
+    return r > 0 ? 1 : 0;          // (a sequence number has been drawn: "not taken" is no longer an option)
+  }
+  float *local = workspace + (int64_t)kRedMaxWG * 2 * C;       // this replica's [mean | var]
+  if (!launch_stats_nhwc2(rows, C, x, local, local + C, nullptr, nullptr, 0.f, workspace, st)) return 0;
+  if (!skd_abn_sync_stats(sync_ctx, C, local, replica_weights, mean, var, running_mean, running_var, momentum, n, stream)) return 0;
   return residual ? launch_apply_nhwc_train<true>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st)
                   : launch_apply_nhwc_train<false>(activation, x, residual, out, mean, var, weight, bias, eps, slope, rows, g, st);
 }
@@ -2227,59 +2383,137 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
 }
 
 // One-call channels-last backward (reduce + dx): ONE register-resident launch when the tensor fits (see "one launch with the
-// tensor held in registers" above), the two launches of the entries above otherwise.  edz / eydz are outputs as well
-// (functions.py:139-150 keeps them for the cross-replica path, which calls the two entries separately around its exchange).
-int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
-                          const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias, float eps,
-                          int activation, float slope, int accumulate, float *workspace, skd_stream_t stream) {
+// tensor held in registers" above), the two launches of the entries above otherwise.  edz / eydz are outputs as well.
+// sync_ctx != NULL (the *_sync entries below): InPlaceABNSync's backward (libs/functions.py:257-294) -- [edz | eydz] are
+// exchanged and averaged over the replicas between the reduction and the dx pass: inside the one launch, or by
+// skd_abn_sync_grad_stats between the two (edz, eydz must then be the two halves of ONE (2, C) buffer).
+static int abn_backward_nhwc_any(void *sync_ctx, const float *rweights, int64_t rows, int C, const float *z, const float *dz,
+                                 const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                                 float *dweight, float *dbias, float eps, int activation, float slope, int accumulate,
+                                 float *workspace, skd_stream_t stream) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !z || !dz || !var || !edz || !eydz || !dx || !workspace) return 0;
   if (!aligned16(z) || !aligned16(dz) || !aligned16(dx) || activation == SKD_ACT_RELU || (dweight && !weight)) return 0;
+  if (sync_ctx && (eydz != edz + C || 2 * C > kSyncMaxFloats)) return 0;
   hipStream_t st = as_stream(stream);
-  if (aligned16(edz) && aligned16(eydz) && activation != SKD_ACT_ELU) {
-    const int r = activation == SKD_ACT_LEAKY_RELU
-                      ? launch_bwd_fused<SKD_ACT_LEAKY_RELU, 0, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx,
-                                                                        nullptr, dweight, dbias, eps, slope, accumulate, workspace, st)
-                      : launch_bwd_fused<SKD_ACT_NONE, 0, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx,
-                                                                  nullptr, dweight, dbias, eps, slope, accumulate, workspace, st);
+  FuseGeom f;
+  if (aligned16(edz) && aligned16(eydz) && activation != SKD_ACT_ELU && (!sync_ctx || sync_fused_enabled()) && bwd_fused_geom(rows, C, f)) {
+    int r;
+    if (sync_ctx) {
+      SyncArgs sy;
+      if (!sync_next(sync_ctx, sy)) return 0;
+      r = activation == SKD_ACT_LEAKY_RELU
+              ? launch_bwd_fused<SKD_ACT_LEAKY_RELU, 0, false, true>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr,
+                                                                     dweight, dbias, eps, slope, accumulate, workspace, st, f, sy, rweights)
+              : launch_bwd_fused<SKD_ACT_NONE, 0, false, true>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr,
+                                                               dweight, dbias, eps, slope, accumulate, workspace, st, f, sy, rweights);
+      return r > 0 ? 1 : 0;
+    }
+    const SyncArgs sy = no_sync();
+    r = activation == SKD_ACT_LEAKY_RELU
+            ? launch_bwd_fused<SKD_ACT_LEAKY_RELU, 0, false, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr,
+                                                                    dweight, dbias, eps, slope, accumulate, workspace, st, f, sy, nullptr)
+            : launch_bwd_fused<SKD_ACT_NONE, 0, false, false>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr,
+                                                              dweight, dbias, eps, slope, accumulate, workspace, st, f, sy, nullptr);
     if (r >= 0) return r;
   }
   if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, activation, slope, workspace, stream)) return 0;
+  if (sync_ctx && !skd_abn_sync_grad_stats(sync_ctx, C, edz, rweights, stream)) return 0;
   return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, activation, slope,
                                   accumulate, stream);
 }
 
+int skd_abn_backward_nhwc(int64_t rows, int C, const float *z, const float *dz, const float *var, const float *weight,
+                          const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias, float eps,
+                          int activation, float slope, int accumulate, float *workspace, skd_stream_t stream) {
+  return abn_backward_nhwc_any(nullptr, nullptr, rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, activation,
+                               slope, accumulate, workspace, stream);
+}
+
+int skd_abn_backward_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *z, const float *dz, const float *var,
+                               const float *weight, const float *bias, float *edz, float *eydz, float *dx, float *dweight,
+                               float *dbias, const float *replica_weights, float eps, int activation, float slope, int accumulate,
+                               float *workspace, skd_stream_t stream) {
+  if (!sync_ctx) return 0;
+  return abn_backward_nhwc_any(sync_ctx, replica_weights, rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps,
+                               activation, slope, accumulate, workspace, stream);
+}
+
 // The same for the fused BN + ReLU (+ residual) op: out == NULL -> the mask is recomputed from x (forward without residual).
-int skd_abn_relu_backward_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
-                               const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
-                               float *dres, float *dweight, float *dbias, float eps, int accumulate, float *workspace,
-                               skd_stream_t stream) {
+static int abn_relu_backward_nhwc_any(void *sync_ctx, const float *rweights, int64_t rows, int C, const float *x, const float *out,
+                                      const float *dout, const float *mean, const float *var, const float *weight, const float *bias,
+                                      float *edz, float *eydz, float *dx, float *dres, float *dweight, float *dbias, float eps,
+                                      int accumulate, float *workspace, skd_stream_t stream) {
   NhwcGeom g;
   if (!make_nhwc_geom(rows, C, g) || rows > 2147483647 || !x || !dout || !mean || !var || !edz || !eydz || !dx || !workspace) return 0;
   if (!aligned16(x) || !aligned16(dout) || !aligned16(dx) || (out && !aligned16(out)) || (dres && !aligned16(dres)) || (dweight && !weight)) return 0;
   if (out == nullptr && dres != nullptr) return 0;
+  if (sync_ctx && (eydz != edz + C || 2 * C > kSyncMaxFloats)) return 0;
   hipStream_t st = as_stream(stream);
-  if (aligned16(edz) && aligned16(eydz)) {
+  FuseGeom f;
+  if (aligned16(edz) && aligned16(eydz) && (!sync_ctx || sync_fused_enabled()) && bwd_fused_geom(rows, C, f)) {
     int r;
+    if (sync_ctx) {
+      SyncArgs sy;
+      if (!sync_next(sync_ctx, sy)) return 0;
+      if (out == nullptr)
+        r = launch_bwd_fused<SKD_ACT_NONE, 2, false, true>(rows, C, x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                           dbias, eps, 0.f, accumulate, workspace, st, f, sy, rweights);
+      else if (dres != nullptr)
+        r = launch_bwd_fused<SKD_ACT_NONE, 1, true, true>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight, dbias,
+                                                          eps, 0.f, accumulate, workspace, st, f, sy, rweights);
+      else
+        r = launch_bwd_fused<SKD_ACT_NONE, 1, false, true>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                           dbias, eps, 0.f, accumulate, workspace, st, f, sy, rweights);
+      return r > 0 ? 1 : 0;
+    }
+    const SyncArgs sy = no_sync();
     if (out == nullptr)
-      r = launch_bwd_fused<SKD_ACT_NONE, 2, false>(rows, C, x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
-                                                   dbias, eps, 0.f, accumulate, workspace, st);
+      r = launch_bwd_fused<SKD_ACT_NONE, 2, false, false>(rows, C, x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                          dbias, eps, 0.f, accumulate, workspace, st, f, sy, nullptr);
     else if (dres != nullptr)
-      r = launch_bwd_fused<SKD_ACT_NONE, 1, true>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight, dbias,
-                                                  eps, 0.f, accumulate, workspace, st);
+      r = launch_bwd_fused<SKD_ACT_NONE, 1, true, false>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight, dbias,
+                                                         eps, 0.f, accumulate, workspace, st, f, sy, nullptr);
     else
-      r = launch_bwd_fused<SKD_ACT_NONE, 1, false>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
-                                                   dbias, eps, 0.f, accumulate, workspace, st);
+      r = launch_bwd_fused<SKD_ACT_NONE, 1, false, false>(rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
+                                                          dbias, eps, 0.f, accumulate, workspace, st, f, sy, nullptr);
     if (r >= 0) return r;
   }
   if (out == nullptr) {
     if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, workspace, stream)) return 0;
+    if (sync_ctx && !skd_abn_sync_grad_stats(sync_ctx, C, edz, rweights, stream)) return 0;
     return skd_abn_relu_backward_dx_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, accumulate,
                                            stream);
   }
   if (!skd_abn_relu_backward_reduce_nhwc(rows, C, x, out, dout, mean, var, edz, eydz, eps, workspace, stream)) return 0;
+  if (sync_ctx && !skd_abn_sync_grad_stats(sync_ctx, C, edz, rweights, stream)) return 0;
   return skd_abn_relu_backward_dx_nhwc(rows, C, x, out, dout, mean, var, weight, edz, eydz, dx, dres, dweight, dbias, eps, accumulate,
                                        stream);
+}
+
+int skd_abn_relu_backward_nhwc(int64_t rows, int C, const float *x, const float *out, const float *dout, const float *mean,
+                               const float *var, const float *weight, const float *bias, float *edz, float *eydz, float *dx,
+                               float *dres, float *dweight, float *dbias, float eps, int accumulate, float *workspace,
+                               skd_stream_t stream) {
+  return abn_relu_backward_nhwc_any(nullptr, nullptr, rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight, dbias,
+                                    eps, accumulate, workspace, stream);
+}
+
+int skd_abn_relu_backward_nhwc_sync(void *sync_ctx, int64_t rows, int C, const float *x, const float *out, const float *dout,
+                                    const float *mean, const float *var, const float *weight, const float *bias, float *edz,
+                                    float *eydz, float *dx, float *dres, float *dweight, float *dbias, const float *replica_weights,
+                                    float eps, int accumulate, float *workspace, skd_stream_t stream) {
+  if (!sync_ctx) return 0;
+  return abn_relu_backward_nhwc_any(sync_ctx, replica_weights, rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight,
+                                    dbias, eps, accumulate, workspace, stream);
+}
+
+// Upper bound of the workgroups of a one-launch (grid-barrier) pass, on top of the device's own limit (compute units):
+// ranks that share ONE device must share its compute units or their barrier kernels cannot all be resident.  n > 0 sets the
+// bound, n == 0 restores the default, n < 0 only queries.  Process-wide; returns the effective cap on the current device.
+int skd_abn_set_fused_max_workgroups(int n) {
+  if (n >= 0) g_fuse_user_cap = (n > 0 && n < kRedMaxWG) ? n : kRedMaxWG;
+  return fuse_wg_cap();
 }
 
 // ---- legacy drop-in entries ---------------------------------------------------------------------

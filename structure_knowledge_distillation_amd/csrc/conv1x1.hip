@@ -250,11 +250,13 @@ template <int ACT, bool HAS_RES, bool PRO>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
                   const float *weight, const float *bias, const float *ppack, float eps, float slope, int64_t M, int K, int N,
                   hipStream_t st) {
-  static bool ready = false;
-  if (!ready) {
+  static PerDeviceFlag ready;          // per instantiation AND per device
+  bool *rdy = ready.get();
+  if (rdy == nullptr) return 0;
+  if (!*rdy) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES, PRO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kConvLds + sizeof(float) * 4 * kProMaxK)) != hipSuccess) return 0;
-    ready = true;
+    *rdy = true;
   }
   const size_t lds_bytes = kConvLds + (PRO ? sizeof(float) * 4 * (size_t)K : 0);
   const int tiles_n = N / kTN;

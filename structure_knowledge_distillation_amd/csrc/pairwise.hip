@@ -711,7 +711,10 @@ int64_t skd_pairwise_workspace_floats(int B, int M) {
 }
 
 static bool gemm_lds_ready() {
-  static bool done = false;
+  static PerDeviceFlag flag;
+  bool *donep = flag.get();
+  if (donep == nullptr) return false;
+  bool &done = *donep;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<false>::lds_bytes) != hipSuccess) return false;

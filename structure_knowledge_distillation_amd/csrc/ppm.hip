@@ -784,11 +784,13 @@ int skd_ppm_concat_backward(int B, int Cout, int Cfeat, int H, int W, int nsizes
   }
   const size_t smem = sizeof(float) * ((size_t)H * W + (size_t)H * smax);
   if (smem > 150 * 1024) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_flag;
+  bool *attr_set = attr_flag.get();
+  if (attr_set == nullptr) return 0;
+  if (!*attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ppm_concat_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    *attr_set = true;
   }
   ppm_concat_bwd_kernel<<<dim3((unsigned)(B * nsizes * Cout)), dim3(kThreads), smem, as_stream(stream)>>>(
       gcat, gp, B, Cout, Cfeat, H, W, lv);

@@ -15,6 +15,28 @@ static inline hipStream_t as_stream(skd_stream_t s) { return reinterpret_cast<hi
 static inline int ok() { return hipGetLastError() == hipSuccess ? 1 : 0; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- device-raised error words (status.hip; include/skd.h section 13) -------------------------------------------
+constexpr int kStatusWords = 4;
+constexpr int kStatusSyncTimeout = 0;    // a cross-replica mailbox exchange gave up waiting for a peer (sync.hip, abn.hip)
+constexpr int kStatusFusedTimeout = 1;   // the grid barrier of a one-launch InPlace-ABN pass timed out: grid not co-resident
+// host-mapped, system-coherent buffer of kStatusWords words as a DEVICE pointer (nullptr: allocation failed -> not reported)
+unsigned *status_words();
+__device__ __forceinline__ void raise_status(unsigned *status, int which, unsigned code) {
+  if (status != nullptr) __hip_atomic_store(status + which, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One-time initialisation that is PER DEVICE (hipFuncSetAttribute, attribute queries): a process may drive several
+// devices (the reference's own threading model), so a plain `static bool` is wrong there.
+struct PerDeviceFlag {
+  bool done[64] = {};
+  // the current device's flag, or nullptr when the device cannot be determined
+  bool *get() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return &done[dev];
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = kWave / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, kWave);

@@ -6,9 +6,10 @@
 // message).  Per-channel statistics are tiny; what matters is latency.  On an 8 x MI355X node every GPU reaches every other
 // GPU in ONE xGMI hop and can store into its memory directly, so the exchange is a single small kernel:
 //
+// (Device side: sync_dev.hpp, shared with the fused forms in abn.hip.)
 //   mailbox   every rank owns one device buffer (uncached / fine-grained: hipDeviceMallocUncached, the allocation type RCCL
 //             uses for its own flags) and exports it with hipIpcGetMemHandle; every rank opens all the others'.
-//             Layout: [parity 2][writer G][ flag word | pad to 64 B | payload kSyncMaxFloats floats ].
+//             Layout: [parity 2][writer G][ 4 flag words (one per channel block) | pad to 64 B | payload kSyncMaxFloats floats ].
 //   exchange  ONE 256-thread workgroup on the caller's stream: (1) stores this rank's payload into slot [parity][rank] of
 //             EVERY rank's mailbox (system-scope write-through stores; own mailbox included), (2) drains them, fences at
 //             system scope and publishes the launch's sequence number in each of those slots' flag words, (3) spins
@@ -20,26 +21,20 @@
 //             (it needs the peer's flag of exchange s to finish s), so a slot written for exchange s + 2 has been read
 //             by its owner for exchange s.  Sequence numbers are a host-side counter per context: every rank calls the
 //             exchanges in the same order (they are collectives, like the calls they replace).
-// A spin that times out (a peer never arrived: 5 s) poisons the outputs with NaN instead of hanging the device.
+// A spin that times out (a peer never arrived within skd_sync_set_timeout's limit: 5 s while a context is being set up, then
+// as long as torch.distributed would have waited) poisons the outputs with NaN instead of hanging the device AND raises the
+// status word kStatusSyncTimeout (status.hip), which the host checks once per step and turns into an exception.
 // Single-device use (two ranks sharing one GPU, tests/test_distributed_gpu.py) runs the very same code: the "remote"
 // mailbox is then another process's allocation on the same device.
+#include <stdlib.h>
 #include <string.h>
 
-#include "skd_common.hpp"
+#include "sync_dev.hpp"
 
 namespace skd {
 namespace {
 
-constexpr int kSyncMaxWorld = 16;
-constexpr int kSyncMaxFloats = 4096;                 // payload floats per slot (2 * C for C <= 2048)
-constexpr int kSlotHeaderFloats = 16;                // flag word + padding: the payload starts 64 bytes into the slot
-constexpr int kSlotFloats = kSlotHeaderFloats + kSyncMaxFloats;
-constexpr uint64_t kSyncSpinTicks = 500000000ull;    // wall_clock64() at 100 MHz: 5 s
-
-struct SyncDev {           // passed to the kernels by value
-  float *mail[kSyncMaxWorld];   // mail[r] = rank r's mailbox as mapped into THIS process (mail[rank] = the local one)
-  int world, rank;
-};
+constexpr double kSetupTimeoutSeconds = 5.0;         // until skd_sync_set_timeout: the self-test of a fresh context must fail fast
 
 struct SyncCtx {
   SyncDev dev;
@@ -47,100 +42,74 @@ struct SyncCtx {
   void *opened[kSyncMaxWorld] = {};
   unsigned seq = 0;
   int device = 0;
+  uint64_t spin_ticks = (uint64_t)(kSetupTimeoutSeconds * (double)kSyncTicksPerSecond);
 };
 
-__device__ __forceinline__ float *slot_of(float *mailbox, int world, int parity, int writer) {
-  return mailbox + ((int64_t)parity * world + writer) * kSlotFloats;
-}
-__device__ __forceinline__ void store_sys(float *p, float v) {
-  asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ float load_sys(const float *p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-// Steps (1)-(3) of the header.  Returns false in every thread when a peer did not arrive in time.
-__device__ __forceinline__ bool exchange(const SyncDev &d, unsigned seq, int n, const float *__restrict__ src, unsigned *ok_s) {
-  const int t = threadIdx.x, parity = (int)(seq & 1u);
-  for (int r = 0; r < d.world; ++r) {
-    float *dst = slot_of(d.mail[r], d.world, parity, d.rank) + kSlotHeaderFloats;
-    for (int i = t; i < n; i += blockDim.x) store_sys(dst + i, src[i]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope
-  __syncthreads();
-  if (t < d.world) {
-    unsigned *flag = reinterpret_cast<unsigned *>(slot_of(d.mail[t], d.world, parity, d.rank));
-    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (t == 0) *ok_s = 1u;
-  __syncthreads();
-  if (t < d.world) {
-    const unsigned *flag = reinterpret_cast<const unsigned *>(slot_of(d.mail[d.rank], d.world, parity, t));
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > kSyncSpinTicks) {
-        *ok_s = 0u;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  return *ok_s != 0u;
-}
-
 // all-gather: gathered (G, n)
-__global__ __launch_bounds__(kThreads) void sync_gather_kernel(SyncDev d, unsigned seq, int n, const float *__restrict__ src,
+__global__ __launch_bounds__(kThreads) void sync_gather_kernel(SyncArgs a, int n, const float *__restrict__ src,
                                                                float *__restrict__ gathered) {
   __shared__ unsigned ok_s;
-  const bool good = exchange(d, seq, n, src, &ok_s);
-  const int parity = (int)(seq & 1u);
-  for (int r = 0; r < d.world; ++r) {
-    const float *p = slot_of(d.mail[d.rank], d.world, parity, r) + kSlotHeaderFloats;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) gathered[(int64_t)r * n + i] = good ? load_sys(p + i) : __builtin_nanf("");
-  }
+  const bool good = sync_exchange(a, 0, 1, [&](float *dst) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) store_sys(dst + i, src[i]);
+  }, &ok_s);
+  for (int r = 0; r < a.d.world; ++r)
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      gathered[(int64_t)r * n + i] = good ? sync_payload(a.d, a.seq, r, i) : __builtin_nanf("");
 }
 
 // forward statistics: stat = [mean (C), var (C)] of this replica -> the combined mean / var (+ running update), the arithmetic
 // of abn_combine_stats_kernel (abn.hip) term for term
-__global__ __launch_bounds__(kThreads) void sync_stats_kernel(SyncDev d, unsigned seq, int C, const float *__restrict__ stat,
+__global__ __launch_bounds__(kThreads) void sync_stats_kernel(SyncArgs a, int C, const float *__restrict__ stat,
                                                               const float *__restrict__ weights, float *__restrict__ mean,
                                                               float *__restrict__ var, float *running_mean, float *running_var,
                                                               float momentum, float nf) {
   __shared__ unsigned ok_s;
-  const bool good = exchange(d, seq, 2 * C, stat, &ok_s);
-  const int parity = (int)(seq & 1u), G = d.world;
+  const bool good = sync_exchange(a, 0, sync_channel_blocks(C), [&](float *dst) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) store_sys(dst + i, stat[i]);
+  }, &ok_s);
+  const int G = a.d.world;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float m, v;
-    combine_channel(G, C, c, [&](int g, int j) { return load_sys(slot_of(d.mail[d.rank], G, parity, g) + kSlotHeaderFloats + j); },
-                    weights, d.rank, nf, momentum, m, v, good ? running_mean : nullptr, good ? running_var : nullptr);
+    combine_channel(G, C, c, [&](int g, int j) { return sync_payload(a.d, a.seq, g, j); }, weights, a.d.rank, nf, momentum, m, v,
+                    good ? running_mean : nullptr, good ? running_var : nullptr);
     mean[c] = good ? m : __builtin_nanf("");
     var[c] = good ? v : __builtin_nanf("");
   }
 }
 
 // backward statistics: stat = [edz (C), eydz (C)] -> sum_g w_g stat_g (w_g = 1 / G without weights), in rank order, in place
-__global__ __launch_bounds__(kThreads) void sync_grad_stats_kernel(SyncDev d, unsigned seq, int C, float *__restrict__ stat,
+__global__ __launch_bounds__(kThreads) void sync_grad_stats_kernel(SyncArgs a, int C, float *__restrict__ stat,
                                                                    const float *__restrict__ weights) {
   __shared__ unsigned ok_s;
-  const bool good = exchange(d, seq, 2 * C, stat, &ok_s);
-  const int parity = (int)(seq & 1u), G = d.world;
+  const bool good = sync_exchange(a, 0, sync_channel_blocks(C), [&](float *dst) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) store_sys(dst + i, stat[i]);
+  }, &ok_s);
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) {
-      const float v = load_sys(slot_of(d.mail[d.rank], G, parity, g) + kSlotHeaderFloats + i);
-      s = __fadd_rn(s, weights ? __fmul_rn(weights[g], v) : v);     // product rounded, then added: the bits of mul_ + all_reduce(SUM)
-    }
-    if (!weights) s /= (float)G;
+    const float s = sync_weighted_sum(a.d, a.seq, i, weights);
     stat[i] = good ? s : __builtin_nanf("");
   }
 }
 
+static bool connected(const SyncCtx *ctx) {
+  if (!ctx) return false;
+  for (int r = 0; r < ctx->dev.world; ++r)
+    if (ctx->dev.mail[r] == nullptr) return false;
+  return true;
+}
+
 }  // namespace
+
+bool sync_next(void *ctx_, SyncArgs &out) {
+  SyncCtx *ctx = static_cast<SyncCtx *>(ctx_);
+  if (!connected(ctx)) return false;
+  out.d = ctx->dev;
+  out.seq = (++ctx->seq) & 0x7fffffffu;
+  if (out.seq == 0u) out.seq = ctx->seq = 2u;          // the mailbox starts zero-filled: 0 never names an exchange (keeps parity)
+  out.spin_ticks = ctx->spin_ticks;
+  out.status = status_words();
+  return true;
+}
+
 }  // namespace skd
 
 using namespace skd;
@@ -211,18 +180,20 @@ int skd_sync_destroy(void *ctx_) {
   return 1;
 }
 
-static bool connected(const SyncCtx *ctx) {
-  if (!ctx) return false;
-  for (int r = 0; r < ctx->dev.world; ++r)
-    if (ctx->dev.mail[r] == nullptr) return false;
-  return true;
+// How long an exchange waits for a peer before it gives up (NaN outputs + status word).  A fresh context waits 5 s (its
+// self-test must fail fast on a broken setup); the caller raises it once the group is known to work.
+int skd_sync_set_timeout(void *ctx_, double seconds) {
+  SyncCtx *ctx = static_cast<SyncCtx *>(ctx_);
+  if (!ctx || !(seconds > 0.0) || seconds > 1e6) return 0;
+  ctx->spin_ticks = (uint64_t)(seconds * (double)kSyncTicksPerSecond);
+  return 1;
 }
 
 // all-gather of n floats per rank: gathered (world, n).  Collective: every rank, same order.
 int skd_sync_all_gather(void *ctx_, int n, const float *src, float *gathered, skd_stream_t stream) {
-  SyncCtx *ctx = static_cast<SyncCtx *>(ctx_);
-  if (!connected(ctx) || n <= 0 || n > kSyncMaxFloats || !src || !gathered) return 0;
-  sync_gather_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(ctx->dev, ++ctx->seq, n, src, gathered);
+  SyncArgs a;
+  if (n <= 0 || n > kSyncMaxFloats || !src || !gathered || !sync_next(ctx_, a)) return 0;
+  sync_gather_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(a, n, src, gathered);
   return ok();
 }
 
@@ -230,18 +201,18 @@ int skd_sync_all_gather(void *ctx_, int n, const float *src, float *gathered, sk
 // skd_abn_combine_stats (same arguments: weights NULL or world floats, n = pooled count without weights, this rank's with) in ONE launch.
 int skd_abn_sync_stats(void *ctx_, int C, const float *stat, const float *weights, float *mean, float *var, float *running_mean,
                        float *running_var, float momentum, double n, skd_stream_t stream) {
-  SyncCtx *ctx = static_cast<SyncCtx *>(ctx_);
-  if (!connected(ctx) || C <= 0 || 2 * C > kSyncMaxFloats || !stat || !mean || !var) return 0;
-  sync_stats_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(ctx->dev, ++ctx->seq, C, stat, weights, mean, var, running_mean,
-                                                                        running_var, momentum, (float)n);
+  SyncArgs a;
+  if (C <= 0 || 2 * C > kSyncMaxFloats || !stat || !mean || !var || !sync_next(ctx_, a)) return 0;
+  sync_stats_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(a, C, stat, weights, mean, var, running_mean, running_var,
+                                                                        momentum, (float)n);
   return ok();
 }
 
 // stat (2, C) = this replica's [edz, eydz]  ->  in place: sum_g w_g stat_g (plain mean without weights), rank order
 int skd_abn_sync_grad_stats(void *ctx_, int C, float *stat, const float *weights, skd_stream_t stream) {
-  SyncCtx *ctx = static_cast<SyncCtx *>(ctx_);
-  if (!connected(ctx) || C <= 0 || 2 * C > kSyncMaxFloats || !stat) return 0;
-  sync_grad_stats_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(ctx->dev, ++ctx->seq, C, stat, weights);
+  SyncArgs a;
+  if (C <= 0 || 2 * C > kSyncMaxFloats || !stat || !sync_next(ctx_, a)) return 0;
+  sync_grad_stats_kernel<<<dim3(1), dim3(kThreads), 0, as_stream(stream)>>>(a, C, stat, weights);
   return ok();
 }
 

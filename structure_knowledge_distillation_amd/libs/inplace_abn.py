@@ -238,6 +238,22 @@ def _sync_stats(stat, c, count, group, running_mean, running_var, momentum, lib,
     return out[0], out[1]
 
 
+def _mailbox_for(geo, group, ref):
+    """The group's IPC mailbox context when this (channels-last) call can use the one-call synchronised entries of
+    include/skd.h section 12 (statistics exchange inside the library: ONE register-resident launch when the tensor fits)."""
+    if not geo.nhwc:
+        return None
+    from ..utils.parallel import SyncMailbox
+    mb = SyncMailbox.get(group, ref.device)
+    return mb if (mb is not None and geo.c <= mb.max_channels) else None
+
+
+def _pooled_count(count, group):
+    """(replica weights or None, n) as skd_abn_combine_stats wants them: n = this replica's count with weights, pooled without."""
+    w = _replica_weights(group)
+    return w, (float(count) if w is not None else float(count * _group_size(group)))
+
+
 def _sync_grad_stats(stat, group):
     """libs/functions.py:271-272: [edz, eydz] are averaged over the replicas -- weighted by the per-rank sample
     counts when they are known (the pooled expectation), plain mean otherwise."""
@@ -293,9 +309,20 @@ class _InPlaceABN(autograd.Function):
                 geo.forward_train(lib, x, None, x, weight, bias, running_mean, running_var, mean, var, float(momentum),
                                   ctx.eps, ctx.act, ctx.slope, ws, st)
             else:
-                geo.stats(lib, x, mean, var, ws, st)
-                mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
-                geo.apply_to(lib, x, None, x, mean, var, weight, bias, ctx.eps, ctx.act, ctx.slope, st)
+                mb = _mailbox_for(geo, ctx.group, x)
+                if mb is not None:
+                    from ..utils.parallel import comm_timer
+                    w, n = _pooled_count(geo.count, ctx.group)
+                    tok = comm_timer.begin("syncabn_fused", x)
+                    _lib.check(lib.skd_abn_forward_train_nhwc_sync(
+                        mb.ctx, geo.rows, c, x.data_ptr(), None, x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                        _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(), _lib.ptr(w),
+                        float(momentum), ctx.eps, ctx.act, ctx.slope, n, ws.data_ptr(), st), "skd_abn_forward_train_nhwc_sync")
+                    comm_timer.end(tok)
+                else:
+                    geo.stats(lib, x, mean, var, ws, st)
+                    mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
+                    geo.apply_to(lib, x, None, x, mean, var, weight, bias, ctx.eps, ctx.act, ctx.slope, st)
         else:
             var = running_var
             geo.apply_to(lib, x, None, x, running_mean, running_var, weight, bias, ctx.eps, ctx.act, ctx.slope, st)
@@ -341,6 +368,18 @@ class _InPlaceABN(autograd.Function):
                                                  _lib.ptr(dweight), _lib.ptr(dbias), ctx.eps, ctx.act, ctx.slope, 0,
                                                  ws.data_ptr(), st), "skd_abn_backward_nhwc")
             return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None, None
+        mb = _mailbox_for(geo, ctx.group, z) if (ctx.training and ctx.group is not None) else None
+        if mb is not None:
+            from ..utils.parallel import comm_timer
+            ws = geo.workspace(lib, z)
+            tok = comm_timer.begin("syncabn_fused", z)
+            _lib.check(lib.skd_abn_backward_nhwc_sync(mb.ctx, geo.rows, c, z.data_ptr(), dz.data_ptr(), var.data_ptr(),
+                                                      _lib.ptr(weight), _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(),
+                                                      dx.data_ptr(), _lib.ptr(dweight), _lib.ptr(dbias),
+                                                      _lib.ptr(_replica_weights(ctx.group)), ctx.eps, ctx.act, ctx.slope, 0,
+                                                      ws.data_ptr(), st), "skd_abn_backward_nhwc_sync")
+            comm_timer.end(tok)
+            return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None, None
         if ctx.training:
             ws = geo.workspace(lib, z)
             geo.backward_reduce(lib, z, dz, weight, bias, edz, eydz, ctx.eps, ctx.act, ctx.slope, ws, st)
@@ -385,9 +424,20 @@ class _ABNRelu(autograd.Function):
             geo.forward_train(lib, x, residual, out, weight, bias, running_mean, running_var, mean, var, float(momentum),
                               ctx.eps, relu, 0.0, ws, st)
         else:
-            geo.stats(lib, x, mean, var, ws, st)
-            mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
-            geo.apply_to(lib, x, residual, out, mean, var, weight, bias, ctx.eps, relu, 0.0, st)
+            mb = _mailbox_for(geo, ctx.group, x)
+            if mb is not None:
+                from ..utils.parallel import comm_timer
+                w, n = _pooled_count(geo.count, ctx.group)
+                tok = comm_timer.begin("syncabn_fused", x)
+                _lib.check(lib.skd_abn_forward_train_nhwc_sync(
+                    mb.ctx, geo.rows, c, x.data_ptr(), _lib.ptr(residual), out.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                    _lib.ptr(running_mean), _lib.ptr(running_var), mean.data_ptr(), var.data_ptr(), _lib.ptr(w),
+                    float(momentum), ctx.eps, relu, 0.0, n, ws.data_ptr(), st), "skd_abn_forward_train_nhwc_sync")
+                comm_timer.end(tok)
+            else:
+                geo.stats(lib, x, mean, var, ws, st)
+                mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
+                geo.apply_to(lib, x, residual, out, mean, var, weight, bias, ctx.eps, relu, 0.0, st)
         ctx.has_residual = residual is not None
         # without a residual the ReLU mask is a function of x alone: the channels-last backward recomputes it instead of
         # reading `out` (which stays alive anyway as the next layer's input, but is not touched again here)
@@ -420,6 +470,16 @@ class _ABNRelu(autograd.Function):
                                                       eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight),
                                                       _lib.ptr(dbias), ctx.eps, 0, ws.data_ptr(), st),
                        "skd_abn_relu_backward_nhwc")
+            return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
+        mb = _mailbox_for(geo, ctx.group, x) if ctx.group is not None else None
+        if mb is not None:
+            from ..utils.parallel import comm_timer
+            tok = comm_timer.begin("syncabn_fused", x)
+            _lib.check(lib.skd_abn_relu_backward_nhwc_sync(
+                mb.ctx, geo.rows, c, x.data_ptr(), _lib.ptr(out), dout.data_ptr(), mean.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+                _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(dweight), _lib.ptr(dbias),
+                _lib.ptr(_replica_weights(ctx.group)), ctx.eps, 0, ws.data_ptr(), st), "skd_abn_relu_backward_nhwc_sync")
+            comm_timer.end(tok)
             return (dx if need_dx else None), dweight, dbias, None, None, dres, None, None, None
         geo.relu_backward_reduce(lib, x, out, dout, mean, var, edz, eydz, ctx.eps, ws, st, weight=weight, bias=bias)
         if ctx.group is not None:

@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn  # noqa: F401
 import torch.optim as optim
 
+from .. import _lib
 from ..utils import parallel as parallel_old
 from ..utils.criterion import (CriterionAdditionalGP, CriterionAdv, CriterionAdvForG, CriterionDSN,
                                CriterionPairWiseforWholeFeatAfterPool, CriterionPixelWise)
@@ -241,6 +242,7 @@ class NetModel():
         if torch.is_tensor(v):
             v = v.item()
             self._scalars[key] = v
+            _lib.raise_on_device_errors()      # the .item() above synchronised: a timed-out in-kernel wait of this step is visible
         return v
 
     mc_G_loss = property(lambda self: self._get_scalar("mc_G_loss"))
@@ -353,6 +355,8 @@ class NetModel():
         self.D_solver.step()
 
     def optimize_parameters(self):
+        if torch.device(self.args.device).type == "cuda":
+            _lib.raise_on_device_errors()      # a host load, no synchronisation: errors of the steps already executed
         try:
             self._optimize_parameters()
         finally:

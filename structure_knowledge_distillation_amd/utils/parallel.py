@@ -34,7 +34,10 @@ def init_distributed(backend=None):
     rk = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # more ranks than GPUs: ranks share devices
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local % ndev)   # more ranks than GPUs: ranks share devices
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+        share_device(-(-local_world // ndev))
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -47,6 +50,18 @@ def init_distributed(backend=None):
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
     return rk, ws, local
+
+
+def share_device(ranks_per_device):
+    """Ranks that share ONE device (tests, bench.py --gpus N on a 1-GPU box) must share its compute units: the one-launch
+    InPlace-ABN passes hold a grid barrier (and, synchronised, wait for the PEER's launch inside it), so every rank's grid
+    is capped at its share -- include/skd.h section 13.  One rank per device (production): no cap beyond the device's own."""
+    if ranks_per_device <= 1 or not torch.cuda.is_available():
+        return None
+    from .. import _lib
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    # a little under the even share: the other streams of a rank (D step) and the exchange kernels need slots too
+    return _lib.get().skd_abn_set_fused_max_workgroups(max(4, (cus - 16) // ranks_per_device))
 
 
 def world_size(group=None):
@@ -119,16 +134,35 @@ class SyncMailbox:
 
     @classmethod
     def get(cls, group, device):
-        # keyed by the group AND its geometry: a process group that was destroyed and re-created (tests, elastic restarts) must not
-        # inherit the mailboxes of its predecessor
-        key = (id(group) if group is not None else 0, world_size(group), rank(group), str(torch.device(device)))
-        if key not in cls._by_group:
-            cls._by_group[key] = cls._create(group, device)
-        return cls._by_group[key]
+        # Keyed by the group's geometry AND validated against the group OBJECT through a weak reference: after
+        # destroy_process_group + init_process_group a new group can reuse the id() of the old one with the same world / rank /
+        # device -- its predecessor's context (IPC handles into dead mailboxes, a sequence counter the restarted peers do not
+        # share) must not be inherited.  The default group (None) is validated against dist.group.WORLD.
+        import weakref
+        g = group if group is not None else (dist.group.WORLD if dist.is_available() and dist.is_initialized() else None)
+        key = (world_size(group), rank(group), str(torch.device(device)), id(g))
+        hit = cls._by_group.get(key)
+        if hit is not None:
+            ref, mb = hit
+            if (ref is None and g is None) or (ref is not None and ref() is g):
+                return mb
+            if mb:                                  # same id, different object: the old group is gone
+                mb.lib.skd_sync_destroy(mb.ctx)
+        try:
+            ref = weakref.ref(g) if g is not None else None
+        except TypeError:                           # not weak-referenceable: fall back to a strong reference (keeps the id unique)
+            ref = (lambda obj: (lambda: obj))(g)
+        mb = cls._create(group, device)
+        cls._by_group[key] = (ref, mb)
+        return mb
+
+    @classmethod
+    def active(cls):
+        return any(mb for _, mb in cls._by_group.values())
 
     @classmethod
     def reset(cls):
-        for mb in cls._by_group.values():
+        for _, mb in cls._by_group.values():
             if mb:
                 mb.lib.skd_sync_destroy(mb.ctx)
         cls._by_group.clear()
@@ -151,12 +185,20 @@ class SyncMailbox:
         on_device = (lambda: torch.cuda.device(device)) if on_gpu else contextlib.nullcontext
         with on_device():
             ctx = lib.skd_sync_create(w, rk, ctypes.cast(buf, ctypes.c_void_p))
-        mine = (bytes(buf.raw) if ctx else None, socket.gethostname())
+        dev_id = None
+        if on_gpu:
+            props = torch.cuda.get_device_properties(torch.device(device))
+            dev_id = str(getattr(props, "uuid", "")) or "index %d" % torch.device(device).index
+        mine = (bytes(buf.raw) if ctx else None, socket.gethostname(), dev_id)
         everyone = [None] * w
         dist.all_gather_object(everyone, mine, group=group)
-        good = bool(ctx) and all(h is not None and host == mine[1] for h, host in everyone)
+        good = bool(ctx) and all(h is not None and host == mine[1] for h, host, _ in everyone)
+        if on_gpu:
+            # ranks of this group that sit on MY device: their grid-barrier launches (which, synchronised, wait for each other
+            # inside the kernel) must fit the device together
+            share_device(sum(1 for _, host, d in everyone if host == mine[1] and d == dev_id))
         if good:
-            blob = ctypes.create_string_buffer(b"".join(h for h, _ in everyone), nb * w)
+            blob = ctypes.create_string_buffer(b"".join(h for h, _, _ in everyone), nb * w)
             with on_device():
                 good = bool(lib.skd_sync_connect(ctx, ctypes.cast(blob, ctypes.c_void_p)))
         def agree(ok):                               # every rank or nobody: all-reduce(MIN) of the local verdicts
@@ -177,6 +219,10 @@ class SyncMailbox:
             if ctx:
                 lib.skd_sync_destroy(ctx)
             return None
+        # The group works: from here on an exchange waits for a late peer as long as torch.distributed would have (a loader
+        # stall, a MIOpen JIT on one rank, a slow checkpoint filesystem -- ADVICE r03); a wait that still runs out poisons the
+        # statistics AND raises the device status word that NetModel checks every step (_lib.raise_on_device_errors).
+        lib.skd_sync_set_timeout(ctx, float(os.environ.get("SKD_SYNC_TIMEOUT_S", "600")))
         return cls(ctx, lib, w, rk)
 
 

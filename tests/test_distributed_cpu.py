@@ -95,6 +95,74 @@ def test_sync_abn_two_ranks_equals_one_rank_on_the_whole_batch():
 
 
 # ---------------------------------------------------------------------------------------------------
+def _sync_abn_nhwc(rank, world):
+    """Channels-last tensors take the ONE-CALL synchronised entries (skd_abn_forward_train_nhwc_sync / skd_abn_backward_nhwc_sync /
+    skd_abn_relu_backward_nhwc_sync, include/skd.h section 12) whenever the group has mailboxes: in-place leaky form, fused
+    BN + ReLU with and without residual."""
+    from structure_knowledge_distillation_amd import libs
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    g = torch.Generator().manual_seed(0)
+    n = 2 * world
+    x = torch.randn(n, 8, 5, 3, generator=g) * 2 + 1
+    r = torch.randn(n, 8, 5, 3, generator=g)
+    gz = torch.randn(n, 8, 5, 3, generator=g)
+    w, b = torch.randn(8, generator=g), torch.randn(8, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    assert P.SyncMailbox.get(dist.group.WORLD, torch.device("cpu")) is not None
+    out = {}
+    for kind in ("leaky", "relu", "relu_res"):
+        mod = libs.InPlaceABNSync(8, activation="leaky_relu" if kind == "leaky" else "none").train()
+        with torch.no_grad():
+            mod.weight.copy_(w); mod.bias.copy_(b)
+        xs = x[sl].clone().requires_grad_(True)
+        rs = r[sl].clone().requires_grad_(True)
+        P.comm_timer.enable()
+        if kind == "leaky":
+            z = mod(cl(xs * 1.0))
+        else:
+            z = mod.forward_relu(cl(xs * 1.0), cl(rs * 1.0) if kind == "relu_res" else None)
+        (z * gz[sl]).sum().backward()
+        spans = P.comm_timer.disable()
+        assert spans["syncabn_fused"][1] == 2 and "syncabn" not in spans     # one call forward, one backward, exchange inside
+        out[kind] = {"z": z.detach().contiguous(), "dx": xs.grad, "dr": rs.grad, "dw": mod.weight.grad, "db": mod.bias.grad,
+                     "rm": mod.running_mean.clone(), "rv": mod.running_var.clone()}
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sync_abn_channels_last_one_call_entries(world):
+    from oracle import abn_torch
+    outs = _run("_sync_abn_nhwc", world)
+    g = torch.Generator().manual_seed(0)
+    n = 2 * world
+    x = torch.randn(n, 8, 5, 3, generator=g) * 2 + 1
+    r = torch.randn(n, 8, 5, 3, generator=g)
+    gz = torch.randn(n, 8, 5, 3, generator=g)
+    w, b = torch.randn(8, generator=g), torch.randn(8, generator=g)
+    for kind in ("leaky", "relu", "relu_res"):
+        xo, ro = x.double().requires_grad_(True), r.double().requires_grad_(True)
+        wo, bo = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        rm, rv = torch.zeros(8, dtype=torch.float64), torch.ones(8, dtype=torch.float64)
+        zo = abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, "leaky_relu" if kind == "leaky" else "none", 0.01)
+        if kind != "leaky":
+            zo = torch.relu(zo + ro if kind == "relu_res" else zo)
+        (zo * gz.double()).sum().backward()
+        for rk in range(world):
+            sl = slice(2 * rk, 2 * rk + 2)
+            o = outs[rk][kind]
+            assert rel(o["z"], zo[sl]) < 1e-5, (kind, rk)
+            assert rel(o["dx"], xo.grad[sl]) < 1e-4, (kind, rk)
+            if kind == "relu_res":
+                assert rel(o["dr"], ro.grad[sl]) < 1e-5, (kind, rk)
+            assert rel(o["rm"], rm) < 1e-6 and rel(o["rv"], rv) < 1e-6, (kind, rk)       # n = N * S * world
+            assert torch.equal(o["rm"], outs[0][kind]["rm"]) and torch.equal(o["rv"], outs[0][kind]["rv"])   # replicas agree bit for bit
+        # parameter gradients: the mean over ranks (what the gradient all-reduce produces) is 1 / world of the whole-batch gradient
+        assert rel(sum(outs[rk][kind]["dw"] for rk in range(world)), wo.grad) < 1e-4, kind
+        assert rel(sum(outs[rk][kind]["db"] for rk in range(world)), bo.grad) < 1e-4, kind
+
+
+# ---------------------------------------------------------------------------------------------------
 def _mailbox_vs_collectives(rank, world):
     """The one-hop mailbox exchange (include/skd.h section 12; here oracle/sync_ref.c over POSIX shared memory) against the
     torch.distributed collectives it replaces, on the same data, bit for bit: forward statistics (+ running update) and
@@ -172,7 +240,7 @@ def test_mailbox_setup_failure_on_one_rank_sends_the_group_to_the_collectives():
         assert torch.allclose(o["mean"], torch.tensor([1.5, 2.0])) and torch.allclose(o["var"], torch.tensor([0.75, 0.375]))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_mailbox_exchange_is_bit_identical_to_the_collectives(world):
     outs = _run("_mailbox_vs_collectives", world)
     for r in range(1, world):
@@ -243,11 +311,13 @@ def _reducer(rank, world):
     return {"avg": out, "local": params[0].grad.clone()}
 
 
-def test_gradient_allreducer_buckets_and_unused_params():
-    outs = _run("_reducer")
-    for r in range(2):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_allreducer_buckets_and_unused_params(world):
+    outs = _run("_reducer", world)
+    mean_rank = (world + 1) / 2.0                        # mean over ranks of (rank + 1)
+    for r in range(world):
         for i, g in enumerate(outs[r]["avg"]):
-            want = 0.0 if i == 2 else 1.5 * (i + 1)
+            want = 0.0 if i == 2 else mean_rank * (i + 1)
             assert g is not None and torch.allclose(g, torch.full_like(g, want)), (r, i)
         assert torch.allclose(outs[r]["local"], torch.full((5,), float(r + 1)))
 
@@ -394,3 +464,62 @@ def test_netmodel_step_two_ranks_matches_reference_dp_semantics():
             g = want["grads_D"][k]
             assert float((a.double() - PD[k]).norm()) <= 1e-6 * float(PD[k].norm()) + 3e-2 * cfg.lr_d * float(g.norm()) + 1e-12, k
     assert local_bn == 2, "the discriminator's BatchNorm statistics must stay local to the replica"
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[3]'s world size: EIGHT ranks.  Pi + Pa on 8 x 1 images of 128 x 128 (the
+# discriminator needs 65 x 65 logits, i.e. 512 x 512 images: the Ho path is covered at world 2 above and on the GPU).
+def _netmodel_step_w8(rank, world):
+    from oracle import step_torch as O
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    torch.manual_seed(20 + rank)
+    model = NetModel(default_args(batch_size=world, ho=False, device=torch.device("cpu"), weight_decay=5e-4, lambda_pa=0.5))
+    for m in model.student.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    init, teacher = _snap(model.student), _snap(model.teacher)
+    x, y = O.synthetic_batch(world, 128, 128, seed=5)
+    model.set_input((x[rank:rank + 1], y[rank:rank + 1], None, None))
+    model.optimize_parameters()
+    return {"init": init if rank == 0 else None, "teacher": teacher if rank == 0 else None,
+            "first": {k: v for k, v in list(init.items())[:3]},
+            "grads": {k: p.grad.clone() for k, p in model.student.named_parameters()},
+            "losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss")},
+            "running": {k: v for k, v in _snap(model.student).items() if "running" in k}}
+
+
+@pytest.mark.timeout(900)
+def test_netmodel_step_eight_ranks_matches_reference_dp_semantics():
+    """Eight ranks (gloo, C-ABI double): replica broadcast, SyncABN over 8 replicas in every student BN (pooled n = 8 N S),
+    bucketed gradient averaging over 8 ranks == the reference's DataParallel semantics (sharded fp64 oracle, 8 shards)."""
+    from oracle import step_torch as O
+    world = 8
+    outs = _run("_netmodel_step_w8", world)
+    for r in range(1, world):
+        for k, v in outs[0]["first"].items():
+            assert torch.equal(v, outs[r]["first"][k]), "replicas must start identical: %s" % k
+    dbl = lambda P: {k: v.double() if v.is_floating_point() else v.clone() for k, v in P.items()}
+    PS, PT = dbl(outs[0]["init"]), dbl(outs[0]["teacher"])
+    x, y = O.synthetic_batch(world, 128, 128, seed=5)
+    cfg = O.StepConfig(ho=False, weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
+    want = O.distillation_step_sharded(PS, PT, None, x.double(), y, cfg, [slice(r, r + 1) for r in range(world)])
+    for r in range(world):
+        for k, ref in want["shards"][r].items():
+            got = outs[r]["losses"][k]
+            assert abs(got - ref) <= 1e-4 * abs(ref) + 1e-12, (r, k, got, ref)
+    assert len({round(o["losses"]["G_loss"], 6) for o in outs}) == world         # eight different shards
+    worst = (0.0, "")
+    for k, g in want["grads_S"].items():
+        if g is None:
+            continue
+        for r in range(1, world):
+            assert torch.equal(outs[0]["grads"][k], outs[r]["grads"][k]), "averaged gradients must be identical on every rank: %s" % k
+        err = float((outs[0]["grads"][k].double() - g).norm())
+        if float(g.norm()) > 1e-9:
+            worst = max(worst, (err / float(g.norm()), k))
+        assert err <= 3e-2 * float(g.norm()) + 1e-6, (k, err, float(g.norm()))     # fp32 product vs fp64 oracle (SURVEY.md section 4)
+    print("world 8: worst gradient error vs the fp64 sharded oracle:", worst)
+    for k, v in outs[0]["running"].items():
+        for r in range(1, world):
+            assert torch.equal(v, outs[r]["running"][k]), k
+        assert rel(v, PS[k]) < 1e-5, k

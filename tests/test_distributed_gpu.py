@@ -28,6 +28,7 @@ def _worker(rank, world, port, fn_name, outdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", MIOPEN_LOG_LEVEL="3")
+    os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "30")      # tests: a protocol mistake must cost seconds of GPU-box time, not 600 s per exchange
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -90,6 +91,130 @@ def test_sync_abn_two_ranks_hip_kernels():
             assert rel(outs[r][kind]["rm"], rm) < 1e-5 and rel(outs[r][kind]["rv"], rv) < 1e-5, kind
         assert rel(outs[0][kind]["dw"] + outs[1][kind]["dw"], wo.grad) < 1e-4, kind
         assert rel(outs[0][kind]["db"] + outs[1][kind]["db"], bo.grad) < 1e-4, kind
+
+
+# ---------------------------------------------------------------------------------------------------
+def _sync_abn_nhwc_forms(rank, world):
+    """Channels-last InPlaceABNSync through the one-call entries (include/skd.h section 12) in the three ways two ranks can
+    take an exchange: both in the ONE-launch form (statistics exchanged by the channel blocks' last arrivers inside the
+    register-resident kernel), both in the three-launch form, and MIXED (rank 0 one launch, rank 1 three) -- the protocol
+    (one sequence number, per-channel-block flag words) must not care."""
+    from structure_knowledge_distillation_amd import libs, _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dev = torch.device("cuda", 0)
+    mb = P.SyncMailbox.get(dist.group.WORLD, dev)
+    assert mb is not None
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cap = _lib.get().skd_abn_set_fused_max_workgroups(-1)           # query: what SyncMailbox's device-sharing detection left in place
+    out = {"cap": cap, "cus": cus}
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for C, hw in ((64, 65), (256, 33), (128, 65)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(4, C, hw, hw, generator=g) * 2 + 1
+        r = torch.randn(4, C, hw, hw, generator=g)
+        gz = torch.randn(4, C, hw, hw, generator=g)
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        sl = slice(rank * 2, rank * 2 + 2)
+        for form in ("fused", "three", "mixed"):
+            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "three": "0", "mixed": "1" if rank == 0 else "0"}[form]
+            for kind in ("leaky", "relu", "relu_res"):
+                mod = libs.InPlaceABNSync(C, activation="leaky_relu" if kind == "leaky" else "none").to(dev).train()
+                with torch.no_grad():
+                    mod.weight.copy_(w); mod.bias.copy_(b)
+                xs = x[sl].to(dev).requires_grad_(True)
+                rs = r[sl].to(dev).requires_grad_(True)
+                if kind == "leaky":
+                    z = mod(cl(xs * 1.0))
+                else:
+                    z = mod.forward_relu(cl(xs * 1.0), cl(rs * 1.0) if kind == "relu_res" else None)
+                (z * gz[sl].to(dev)).sum().backward()
+                torch.cuda.synchronize()
+                out[(C, form, kind)] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "dr": None if rs.grad is None else rs.grad.cpu(),
+                                        "dw": mod.weight.grad.cpu(), "db": mod.bias.grad.cpu(),
+                                        "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
+    os.environ.pop("SKD_ABN_SYNC_FUSED", None)
+    out["status"] = _lib.device_status()
+    return out
+
+
+def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
+    from oracle import abn_torch
+    outs = _run("_sync_abn_nhwc_forms")
+    # two ranks on one device: SyncMailbox must have split the compute units between them (grid barrier + in-kernel wait for the peer)
+    assert outs[0]["cap"] <= (outs[0]["cus"] - 16) // 2 and outs[0]["cap"] == outs[1]["cap"], (outs[0]["cap"], outs[0]["cus"])
+    assert not any(outs[0]["status"]) and not any(outs[1]["status"]), "an in-kernel wait timed out"
+    for C, hw in ((64, 65), (256, 33), (128, 65)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(4, C, hw, hw, generator=g) * 2 + 1
+        r = torch.randn(4, C, hw, hw, generator=g)
+        gz = torch.randn(4, C, hw, hw, generator=g)
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        for kind in ("leaky", "relu", "relu_res"):
+            xo, ro = x.double().requires_grad_(True), r.double().requires_grad_(True)
+            wo, bo = w.double().requires_grad_(True), b.double().requires_grad_(True)
+            rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+            zo = abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, "leaky_relu" if kind == "leaky" else "none", 0.01)
+            if kind != "leaky":
+                zo = torch.relu(zo + ro if kind == "relu_res" else zo)
+            (zo * gz.double()).sum().backward()
+            for form in ("fused", "three", "mixed"):
+                o = [outs[rk][(C, form, kind)] for rk in range(2)]
+                for rk in range(2):
+                    sl = slice(2 * rk, 2 * rk + 2)
+                    assert rel(o[rk]["z"], zo[sl]) < 1e-5, (C, form, kind)
+                    assert rel(o[rk]["dx"], xo.grad[sl]) < 1e-4, (C, form, kind)
+                    if kind == "relu_res":
+                        assert rel(o[rk]["dr"], ro.grad[sl]) < 1e-5, (C, form, kind)
+                    assert rel(o[rk]["rm"], rm) < 1e-5 and rel(o[rk]["rv"], rv) < 1e-5, (C, form, kind)
+                # every replica combined the same exchanged numbers in the same order: identical running statistics, bit for bit
+                assert torch.equal(o[0]["rm"], o[1]["rm"]) and torch.equal(o[0]["rv"], o[1]["rv"]), (C, form, kind)
+                assert rel(o[0]["dw"] + o[1]["dw"], wo.grad) < 1e-4 and rel(o[0]["db"] + o[1]["db"], bo.grad) < 1e-4, (C, form, kind)
+            # the one-launch form against the three-launch form: the same numbers up to the rounding of the partial sums
+            for rk in range(2):
+                a, c = outs[rk][(C, "fused", kind)], outs[rk][(C, "three", kind)]
+                for k in ("z", "dx", "dw", "db", "rm", "rv"):
+                    assert rel(a[k], c[k]) < 5e-6, (C, kind, k)
+
+
+def _sync_timeout(rank, world):
+    """A peer that never arrives: the exchange gives up after the context's time limit, the statistics are NaN AND the device
+    status word is raised -- _lib.raise_on_device_errors() turns it into an exception (no silent NaN)."""
+    import importlib
+    import time
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dev = torch.device("cuda", 0)
+    mb = P.SyncMailbox.get(dist.group.WORLD, dev)
+    assert mb is not None and mb.lib.skd_sync_set_timeout(mb.ctx, 1.0)
+    out = {"before": _lib.device_status()}
+    if rank == 0:
+        stat = torch.ones(2, 8, device=dev)
+        t0 = time.perf_counter()
+        IA._sync_grad_stats(stat, dist.group.WORLD)          # rank 1 does not call it
+        torch.cuda.synchronize()
+        out["took"] = time.perf_counter() - t0
+        out["nan"] = bool(torch.isnan(stat).all())
+        out["after"] = _lib.device_status()
+        try:
+            _lib.raise_on_device_errors()
+            out["raised"] = None
+        except _lib.SkdDeviceError as e:
+            out["raised"] = str(e)
+        out["cleared"] = _lib.device_status()
+    else:
+        time.sleep(3.0)
+    dist.barrier()
+    P.SyncMailbox.reset()
+    return out
+
+
+def test_exchange_timeout_raises_a_device_status_word_and_an_exception():
+    outs = _run("_sync_timeout")
+    o = outs[0]
+    assert not any(o["before"]) and o["nan"] and 0.9 < o["took"] < 2.9, o
+    assert o["after"][0] != 0 and o["raised"] is not None and "timed out waiting for a peer" in o["raised"], o
+    assert not any(o["cleared"]) and not any(outs[1]["before"])
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -165,11 +290,14 @@ def test_mailbox_exchange_over_hip_ipc_is_bit_identical_to_the_collectives():
 GRAD_BOUND, GRAD_FLOOR = 3.0, 5e-3        # the ONE gradient bound of tests/test_step_gpu.py (reason stated there)
 _B = 2
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-# variant -> environment of the step: D stream off / on in the default mode; the deterministic mode (no atomics anywhere)
-# with the SyncABN statistics through the IPC mailboxes or through torch.distributed
+# variant -> environment of the step: D stream off / on in the default mode (SyncABN = the one-launch form with the exchange
+# inside the kernel); the deterministic mode (no atomics anywhere) with the SyncABN statistics through the IPC mailboxes in the
+# three-launch form, through torch.distributed, and in the one-launch form (twice: run-to-run bit equality)
 VARIANTS = {"d0": {"SKD_D_STREAM": "0"}, "d1": {"SKD_D_STREAM": "1"},
-            "det_ipc1": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1"},
-            "det_ipc0": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "0"}}
+            "det_ipc1": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "0"},
+            "det_ipc0": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "0"},
+            "det_fused": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "1"},
+            "det_fused_again": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "1"}}
 
 
 def _generator():
@@ -363,6 +491,28 @@ def test_netmodel_ho_step_two_ranks_mailbox_equals_collectives_bit_for_bit():
             assert not diff, "rank %d: %s differ between the mailbox and the collective exchange: %s" % (r, name, diff[:8])
 
 
+def test_netmodel_ho_step_two_ranks_one_launch_syncabn_is_deterministic_and_matches_three_launch():
+    """SKD_DETERMINISTIC=1, SyncABN in the ONE-launch form (exchange inside the register-resident kernels): two runs give the
+    same bits (losses, averaged gradients, parameters, running statistics), both replicas stay identical, and the step agrees
+    with the three-launch form to the rounding of the partial sums (the two forms cut a tensor into different per-thread
+    partial sums, so bit equality between them is not defined; between runs and between replicas it is)."""
+    a, b, three = _variant("det_fused"), _variant("det_fused_again"), _variant("det_ipc1")
+    for r in range(2):
+        assert a[r]["ipc"] and a[r]["losses"] == b[r]["losses"], (r, a[r]["losses"], b[r]["losses"])
+        for name in ("grads", "d_grads", "after", "d_after"):
+            diff = [k for k in a[r][name] if not torch.equal(a[r][name][k], b[r][name][k])]
+            assert not diff, "rank %d: %s differ between two deterministic runs of the one-launch SyncABN form: %s" % (r, name, diff[:8])
+        for k, v in a[r]["losses"].items():
+            assert abs(v - three[r]["losses"][k]) <= 2e-6 * abs(v), (r, k, v, three[r]["losses"][k])
+    for k in a[0]["after"]:
+        assert torch.equal(a[0]["after"][k], a[1]["after"][k]), "student replicas diverged: %s" % k
+        if "running" in k:
+            assert rel(a[0]["after"][k], three[0]["after"][k]) < 1e-5, k
+    worst = max((rel(a[0]["grads"][k], three[0]["grads"][k]), k) for k in a[0]["grads"] if float(three[0]["grads"][k].norm()) > 1e-12)
+    print("one-launch vs three-launch SyncABN, deterministic mode: worst relative gradient difference", worst)
+    assert worst[0] < 5e-3      # (ill-conditioned pre-BN gradients amplify the 1e-7 differences of the statistics, SURVEY.md section 4)
+
+
 def test_bench_under_torchrun_two_ranks_over_gloo():
     """The exact command line the driver uses for its multi-GPU runs (python -m torch.distributed.run ... bench.py
     --gpus N), with two ranks sharing cuda:0 over gloo (SKD_DIST_BACKEND): rendezvous, replica broadcast, SyncABN
@@ -387,5 +537,6 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     # the N > 1 line explains its own efficiency: roofline stays, comm breakdown added
     assert out["roofline"]["bound"] in ("mfma", "hbm") and out["roofline"]["achieved"] > 0      # mfma: the fused bottleneck-tail GEMM (default)
     comm = out["comm"]
-    assert comm["syncabn_collectives"] == 58 and comm["syncabn_ms"] > 0           # 29 training ABN layers, forward + backward
+    assert comm["syncabn_collectives"] == 58                                      # 29 training ABN layers, forward + backward
+    assert comm["syncabn_in_abn_calls"] == 58 and comm["abn_sync_call_ms"] > 0     # all channels-last: exchanged inside the ABN calls
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"

@@ -389,6 +389,45 @@ def test_abn_one_launch_passes_are_repeatable_under_a_busy_second_stream(hip, ro
     torch.cuda.synchronize()
 
 
+def test_fused_abn_grid_cap_and_device_status_words(hip):
+    """include/skd.h section 13: the one-launch passes size their grid barrier by what the DEVICE can hold (its
+    compute-unit count, queried -- not the constant 256), a caller can lower the cap (ranks sharing a device), a tensor that
+    no longer fits takes the two-launch path with the same numbers; the device-raised error words exist and are clear."""
+    import ctypes
+    n = hip.skd_status_words()
+    words = (ctypes.c_uint * n)()
+    assert n >= 2 and hip.skd_status_read(ctypes.cast(words, ctypes.c_void_p)) and not any(words)
+    assert _lib.device_status() == [0] * n
+    _lib.raise_on_device_errors()                        # nothing raised
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert hip.skd_abn_set_fused_max_workgroups(0) == min(256, cus)
+    rows, C = 8 * 65 * 65, 256
+    g = torch.Generator().manual_seed(5)
+    x = gpu(torch.randn(rows, C, generator=g) * 3 + 1)
+    dz = gpu(torch.randn(rows, C, generator=g))
+    w, b = gpu(torch.randn(C, generator=g)), gpu(torch.randn(C, generator=g))
+    ws = torch.empty(hip.skd_abn_nhwc_workspace_floats(rows, C), device=DEV)
+
+    def run():
+        z, st = x.clone(), torch.empty(2, C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        assert hip.skd_abn_forward_train_nhwc(rows, C, P(z), None, P(z), P(w), P(b), P(rm), P(rv), P(st[0]), P(st[1]), 0.1, 1e-5, 1, 0.01, P(ws), None)
+        e, dx, dw, db = torch.empty(2, C, device=DEV), torch.empty(rows, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        assert hip.skd_abn_backward_nhwc(rows, C, P(z), P(dz), P(st[1]), P(w), P(b), P(e[0]), P(e[1]), P(dx), P(dw), P(db), 1e-5, 1, 0.01, 0, P(ws), None)
+        torch.cuda.synchronize()
+        return z, st, rm, rv, e, dx, dw, db
+
+    whole = run()
+    try:
+        assert hip.skd_abn_set_fused_max_workgroups(16) == 16      # 16 workgroups x 1024 threads x 17 rows cannot hold 33800 x 256
+        capped = run()
+    finally:
+        assert hip.skd_abn_set_fused_max_workgroups(0) == min(256, cus)
+    for a, c, name in zip(whole, capped, ("z", "stat", "rm", "rv", "e", "dx", "dw", "db")):
+        close(c, a, 2e-5, name + " (grid cap 16 -> two-launch path)", floor=float(a.abs().max()) * 1e-2)
+    assert _lib.device_status() == [0] * n
+
+
 def test_abn_single_sample_running_var_is_finite(hip):
     """One sample per channel (PSP 1x1 stage at batch 1, one replica): the reference's n / (n - 1) poisons
     running_var with NaN; here the biased variance (0) is kept -- DESIGN.md section 7."""
