@@ -540,3 +540,176 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     assert comm["syncabn_collectives"] == 58                                      # 29 training ABN layers, forward + backward
     assert comm["syncabn_in_abn_calls"] == 58 and comm["abn_sync_call_ms"] > 0     # all channels-last: exchanged inside the ABN calls
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"
+
+
+# ---------------------------------------------------------------------------------------------------
+# Real multi-GPU: backend "nccl" (= RCCL over xGMI), one rank per device, hipIpcOpenMemHandle ACROSS devices.  Runs only
+# where the box has at least two GPUs (the build container and the 1-GPU test boxes skip it); the first multi-GPU box that
+# runs `pytest -m gpu` exercises RCCL, the cross-device mailboxes and the in-kernel SyncABN exchange immediately
+# (VERDICT r03 item 3b).
+def _ngpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def _worker_nccl(rank, world, port, fn_name, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), MIOPEN_LOG_LEVEL="3")
+    os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "60")
+    os.environ.pop("SKD_DIST_BACKEND", None)
+    torch.set_num_threads(4)
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    P.init_distributed()                    # picks "nccl", one device per rank, exactly like bench.py under torchrun
+    assert dist.get_backend() == "nccl" and torch.cuda.current_device() == rank
+    try:
+        out = globals()[fn_name](rank, world)
+        torch.save(out, os.path.join(outdir, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_nccl(fn_name, world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_nccl, args=(world, _free_port(), fn_name, d), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, "r%d.pt" % r)) for r in range(world)]
+
+
+def _multi_gpu_plumbing(rank, world):
+    import importlib
+    IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
+    from structure_knowledge_distillation_amd import libs, _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dev = torch.device("cuda", rank)
+    lib, group = _lib.get(), dist.group.WORLD
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    # (1) the mailboxes across devices, against RCCL's own collectives on the same data
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["SKD_SYNC_IPC"] = mode
+        P.SyncMailbox.reset()
+        mb = P.SyncMailbox.get(group, dev)
+        out["mailbox_" + mode] = mb is not None
+        C = 512
+        stat = (torch.randn(2, C, generator=torch.Generator().manual_seed(100 + rank)).abs() + 0.1).to(dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        mean, var = IA._sync_stats(stat.clone(), C, 7, group, rm, rv, 0.1, lib, st)
+        gstat = torch.randn(2, C, generator=torch.Generator().manual_seed(7000 + rank)).to(dev)
+        IA._sync_grad_stats(gstat, group)
+        torch.cuda.synchronize()
+        res[mode] = [t.cpu() for t in (mean, var, rm, rv, gstat)]
+    out["stats"] = res
+    os.environ["SKD_SYNC_IPC"] = "1"
+    P.SyncMailbox.reset()
+    # (2) channels-last InPlaceABNSync through the one-call entries: the exchange inside the register-resident kernels over xGMI
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(1)
+    n = 2 * world
+    x = torch.randn(n, 64, 33, 33, generator=g) * 2 + 1
+    gz = torch.randn(n, 64, 33, 33, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    mod = libs.InPlaceABNSync(64, activation="leaky_relu").to(dev).train()
+    xs = x[sl].to(dev).requires_grad_(True)
+    z = mod(cl(xs * 1.0))
+    (z * gz[sl].to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    out["abn"] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
+    out["cap"] = lib.skd_abn_set_fused_max_workgroups(-1)
+    # (3) bucketed gradient averaging over RCCL
+    params = [torch.nn.Parameter(torch.full((n_,), float(rank + 1), device=dev)) for n_ in (5, 3000000, 7, 1000)]
+    red = P.GradientAllReducer(params, bucket_bytes=1 << 20)
+    red.arm()
+    sum((i + 1) * (rank + 1) * p.sum() for i, p in enumerate(params)).backward()
+    red.finish()
+    torch.cuda.synchronize()
+    out["avg"] = [float(p.grad[0]) for p in params]
+    out["status"] = _lib.device_status()
+    return out
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs at least two GPUs (RCCL + cross-device HIP IPC)")
+def test_multi_gpu_rccl_and_cross_device_mailboxes():
+    from oracle import abn_torch
+    world = min(_ngpus(), 8)
+    outs = _run_nccl("_multi_gpu_plumbing", world)
+    for o in outs:
+        assert o["mailbox_1"] and not o["mailbox_0"], "cross-device IPC mailboxes could not be set up"
+        assert not any(o["status"]) and o["cap"] == min(256, torch.cuda.get_device_properties(0).multi_processor_count)
+        for a, b in zip(o["stats"]["1"], o["stats"]["0"]):
+            assert rel(a, b) < 1e-6                      # RCCL's ring order vs the mailboxes' rank order: rounding only
+        for a, b in zip(o["stats"]["1"], outs[0]["stats"]["1"]):
+            assert torch.equal(a, b), "replicas must hold identical pooled statistics"
+        mean_rank = (world + 1) / 2.0
+        assert all(abs(v - (i + 1) * mean_rank) < 1e-5 * mean_rank * (i + 1) for i, v in enumerate(o["avg"])), o["avg"]
+    g = torch.Generator().manual_seed(1)
+    n = 2 * world
+    x = torch.randn(n, 64, 33, 33, generator=g) * 2 + 1
+    gz = torch.randn(n, 64, 33, 33, generator=g)
+    xo = x.double().requires_grad_(True)
+    rm, rv = torch.zeros(64, dtype=torch.float64), torch.ones(64, dtype=torch.float64)
+    zo = abn_torch.abn_autograd(xo, torch.ones(64, dtype=torch.float64), torch.zeros(64, dtype=torch.float64), rm, rv, True, 0.1, 1e-5,
+                                "leaky_relu", 0.01)
+    (zo * gz.double()).sum().backward()
+    for r, o in enumerate(outs):
+        sl = slice(2 * r, 2 * r + 2)
+        assert rel(o["abn"]["z"], zo[sl]) < 1e-5 and rel(o["abn"]["dx"], xo.grad[sl]) < 1e-4
+        assert rel(o["abn"]["rm"], rm) < 1e-5 and rel(o["abn"]["rv"], rv) < 1e-5
+        assert torch.equal(o["abn"]["rm"], outs[0]["abn"]["rm"])
+
+
+def _multi_gpu_step(rank, world):
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    from oracle import step_torch as O
+    dev = torch.device("cuda", rank)
+    torch.manual_seed(10 + rank)
+    model = NetModel(default_args(batch_size=_B * world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
+    for m in model.student.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    if world == 2:                          # the recorded sharded oracle (tests/golden/gpu_suite_oracle.pt["sharded2"]) applies
+        gen = _generator()
+        PS, PT, PD = gen.init_nets("sharded2")
+        model.student.load_state_dict(PS); model.teacher.load_state_dict(PT); model.D_model.load_state_dict(PD)
+        x, y, alpha, shards = gen.sharded2_inputs()
+        sl = shards[rank]
+    else:
+        x, y = O.synthetic_batch(_B * world, 512, 512, seed=3)
+        alpha = torch.rand(_B * world, 1, 1, 1, generator=torch.Generator().manual_seed(17))
+        sl = slice(rank * _B, (rank + 1) * _B)
+    losses = []
+    for step in range(2):
+        model.gp_alpha = alpha[sl].to(dev)
+        model.set_input((x[sl], y[sl], None, None))
+        model.optimize_parameters()
+        losses.append({k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")})
+    torch.cuda.synchronize()
+    from structure_knowledge_distillation_amd import _lib
+    return {"losses": losses, "after": _snap(model.student), "d_after": _snap(model.D_model), "status": _lib.device_status(),
+            "grads": {k: p.grad.detach().cpu() for k, p in list(model.student.named_parameters())[:8]}}
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs at least two GPUs (RCCL + cross-device HIP IPC)")
+def test_multi_gpu_netmodel_steps_over_rccl():
+    """Two full Pi + Pa + Ho steps, one rank per GPU over RCCL: replicas stay bit-identical (student, discriminator incl. u / v),
+    no in-kernel wait times out; with exactly two GPUs the first step's per-shard losses meet the recorded sharded oracle."""
+    world = min(_ngpus(), 8)
+    outs = _run_nccl("_multi_gpu_step", world)
+    for o in outs:
+        assert not any(o["status"])
+        assert all(v == v and abs(v) < 1e6 for step in o["losses"] for v in step.values())
+    for k in outs[0]["after"]:
+        for o in outs[1:]:
+            assert torch.equal(outs[0]["after"][k], o["after"][k]), "student replicas diverged over RCCL: %s" % k
+    for k in outs[0]["d_after"]:
+        if not k.startswith("preprocess_additional.running"):
+            for o in outs[1:]:
+                assert torch.equal(outs[0]["d_after"][k], o["d_after"][k]), "discriminator replicas diverged over RCCL: %s" % k
+    if world == 2:
+        fx = torch.load(os.path.join(GOLDEN_DIR, "gpu_suite_oracle.pt"), weights_only=False)["sharded2"]
+        for r in range(2):
+            for k, ref in fx["shard_losses"][r].items():
+                got = outs[r]["losses"][0][k]
+                assert abs(got - ref) <= 1e-4 * abs(ref), (r, k, got, ref)
