@@ -277,6 +277,18 @@ int skd_spectral_norm_forward(int h, int w, const float *w_bar, float *u, float 
 int skd_spectral_norm_backward(int h, int w, const float *w_bar, const float *u, const float *v,
                                const float *sigma, const float *grad_w, float *grad_w_bar,
                                float *workspace, skd_stream_t stream);
+/* All spectrally normalised layers of a network in ONE call (round 4): the discriminator normalises four weights per
+ * forward and runs four forwards per step -- 72 launches of 3-35 us per step with the single-layer entries.  The layers
+ * are independent, so each phase runs for all of them in one launch (a workgroup looks its layer up in a by-value table):
+ * 3 launches forward, 2 backward for any L <= 8; per layer the same arithmetic, bit-identical results.  h / w: HOST
+ * arrays of L ints; the pointer arguments are HOST arrays of L DEVICE pointers (w_out may be NULL: u / v / sigma only).
+ * workspace: sum over the layers of skd_spectral_workspace_floats(h_k, w_k) floats. */
+int skd_spectral_norm_forward_multi(int L, const int *h, const int *w, const float *const *w_bar, float *const *u,
+                                    float *const *v, float *const *sigma, float *const *w_out, float *workspace,
+                                    skd_stream_t stream);
+int skd_spectral_norm_backward_multi(int L, const int *h, const int *w, const float *const *w_bar, const float *const *u,
+                                     const float *const *v, const float *const *sigma, const float *const *grad_w,
+                                     float *const *grad_w_bar, float *workspace, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 7. CriterionDSN, utils/criterion.py:179-188, fused:
@@ -465,6 +477,8 @@ int skd_status_words(void);
 int skd_status_read(unsigned *out);
 int skd_status_clear(void);
 int skd_abn_set_fused_max_workgroups(int n);
+/* out[0] / out[1]: synchronised (*_sync) calls that ran as one launch with the exchange inside / as three launches (host counters) */
+int skd_abn_sync_form_counts(int64_t *out);
 
 /* ------------------------------------------------------------------------------------
  * 10. Training-sample transform of the Cityscapes loader on the device, dataset/datasets.py:173-210

@@ -276,6 +276,24 @@ int skd_spectral_norm_backward(int h, int w, const float *wb, const float *u, co
   return 1;
 }
 
+/* all layers of a network in one call (the product runs 3 / 2 launches for all of them): layer by layer here */
+int skd_spectral_norm_forward_multi(int L, const int *h, const int *w, const float *const *wb, float *const *u, float *const *v,
+                                    float *const *sigma, float *const *w_out, float *ws, stream_t st) {
+  if (L <= 0 || L > 8 || !h || !w || !wb || !u || !v || !sigma) return 0;
+  for (int k = 0; k < L; ++k)
+    if (!skd_spectral_norm_forward(h[k], w[k], wb[k], u[k], v[k], sigma[k], w_out ? w_out[k] : NULL, ws, st)) return 0;
+  return 1;
+}
+
+int skd_spectral_norm_backward_multi(int L, const int *h, const int *w, const float *const *wb, const float *const *u,
+                                     const float *const *v, const float *const *sigma, const float *const *gw, float *const *gwb,
+                                     float *ws, stream_t st) {
+  if (L <= 0 || L > 8 || !h || !w || !wb || !u || !v || !sigma || !gw || !gwb) return 0;
+  for (int k = 0; k < L; ++k)
+    if (!skd_spectral_norm_backward(h[k], w[k], wb[k], u[k], v[k], sigma[k], gw[k], gwb[k], ws, st)) return 0;
+  return 1;
+}
+
 /* ---- CriterionDSN: bilinear upsample (align_corners) + cross-entropy(ignore_index), utils/criterion.py:179-188 ---- */
 int64_t skd_ce_dsn_workspace_floats(int B, int C, int h, int w, int H, int W) {
   (void)B; (void)C; (void)h; (void)w; (void)H; (void)W;

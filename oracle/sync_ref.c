@@ -202,6 +202,8 @@ int skd_abn_sync_grad_stats(void *ctx, int C, float *stat, const float *weights,
   return r;
 }
 
+static int64_t g_three_step_calls = 0;
+
 /* ---- InPlaceABNSync for channels-last tensors in one call (include/skd.h section 2, "*_sync" entries): the product runs one
  *      register-resident launch with the exchange inside it when the tensor fits; the arithmetic is statistics -> exchange +
  *      combine -> normalise (forward) and reduce -> exchange + weighted sum -> dx (backward), restated here from the pieces ---- */
@@ -230,6 +232,7 @@ int skd_abn_forward_train_nhwc_sync(void *ctx, int64_t rows, int C, const float 
                                     const float *replica_weights, float momentum, float eps, int act, float slope, double n, float *ws,
                                     stream_t st) {
   if (!ctx || !x || !out || !mean || !var) return 0;
+  ++g_three_step_calls;
   float *local = (float *)malloc(sizeof(float) * 2 * (size_t)C);
   if (!local) return 0;
   int r = skd_abn_stats_nhwc(rows, C, x, local, local + C, ws, st);
@@ -242,6 +245,7 @@ int skd_abn_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float *z, c
                                const float *bias, float *edz, float *eydz, float *dx, float *dweight, float *dbias,
                                const float *replica_weights, float eps, int act, float slope, int accumulate, float *ws, stream_t st) {
   if (!ctx || eydz != edz + C) return 0;
+  ++g_three_step_calls;
   if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, act, slope, ws, st)) return 0;
   if (!skd_abn_sync_grad_stats(ctx, C, edz, replica_weights, st)) return 0;
   return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, act, slope, accumulate, st);
@@ -252,6 +256,7 @@ int skd_abn_relu_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float 
                                     float *dx, float *dres, float *dweight, float *dbias, const float *replica_weights, float eps,
                                     int accumulate, float *ws, stream_t st) {
   if (!ctx || eydz != edz + C || (out == NULL && dres != NULL)) return 0;
+  ++g_three_step_calls;
   if (out == NULL) {
     if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, ws, st)) return 0;
     if (!skd_abn_sync_grad_stats(ctx, C, edz, replica_weights, st)) return 0;
@@ -264,3 +269,11 @@ int skd_abn_relu_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float 
 
 /* the grid-barrier cap of the product's one-launch passes has no host counterpart: accepted, reports "whole device" */
 int skd_abn_set_fused_max_workgroups(int n) { (void)n; return 256; }
+
+/* the host double always runs the three-step form */
+int skd_abn_sync_form_counts(int64_t *out) {
+  if (!out) return 0;
+  out[0] = 0;
+  out[1] = g_three_step_calls;
+  return 1;
+}

@@ -70,14 +70,36 @@ def _private_miopen_db():
                 shutil.rmtree(tmp, ignore_errors=True)
                 for other in _os.listdir(base):                    # garbage-collect copies of superseded databases
                     path = _os.path.join(base, other)
-                    if (other.startswith("miopen_db_") and path != dst and _os.path.isdir(path)
-                            and time.time() - _os.path.getmtime(path) > 7 * 86400):
+                    if other.startswith("miopen_db_") and path != dst and _os.path.isdir(path) and _idle_for(path) > 7 * 86400:
                         shutil.rmtree(path, ignore_errors=True)
             if _os.path.isdir(dst) and _os.access(dst, _os.W_OK):
+                try:
+                    _os.utime(dst, None)       # "in use now": a directory's own mtime does not move when MIOpen appends to the files inside
+                except OSError:
+                    pass
                 return dst
         except OSError:
             continue
     return None
+
+
+def _idle_for(path):
+    """Seconds since anything in a private database copy was used: the newest mtime of the directory itself (touched by every
+    process that selects it, see above) and of the files MIOpen writes inside it (the db files, cache/) -- a job that runs for
+    more than a week keeps its live MIOPEN_USER_DB_PATH."""
+    import time
+    newest = 0.0
+    try:
+        newest = _os.path.getmtime(path)
+        for root, _, files in _os.walk(path):
+            for f in files:
+                try:
+                    newest = max(newest, _os.path.getmtime(_os.path.join(root, f)))
+                except OSError:
+                    pass
+    except OSError:
+        return 0.0
+    return time.time() - newest
 
 
 def check_miopen_db(warn=True):

@@ -74,6 +74,8 @@ SIGNATURES = {
     "skd_spectral_workspace_floats": (_L, [_I, _I]),
     "skd_spectral_norm_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "skd_spectral_norm_backward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "skd_spectral_norm_forward_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "skd_spectral_norm_backward_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "skd_ce_dsn_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "skd_ce_dsn_forward": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
     "skd_ppm_pooled_floats": (_L, [_I, _I, _P]),
@@ -115,6 +117,7 @@ SIGNATURES = {
     "skd_status_read": (_I, [_P]),
     "skd_status_clear": (_I, []),
     "skd_abn_set_fused_max_workgroups": (_I, [_I]),
+    "skd_abn_sync_form_counts": (_I, [_P]),
 }
 
 _lib = None
@@ -248,6 +251,13 @@ def device_status():
     if not lib.skd_status_read(ctypes.cast(buf, ctypes.c_void_p)):
         return None
     return list(buf)
+
+
+def sync_form_counts():
+    """(one-launch, three-launch) counts of the synchronised InPlace-ABN calls so far (include/skd.h section 13)."""
+    buf = (ctypes.c_int64 * 2)()
+    get().skd_abn_sync_form_counts(ctypes.cast(buf, ctypes.c_void_p))
+    return int(buf[0]), int(buf[1])
 
 
 def raise_on_device_errors():

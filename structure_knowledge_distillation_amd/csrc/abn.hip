@@ -1868,6 +1868,9 @@ static bool fuse_kernel_fits(K kernel, PerDeviceFlag &checked, PerDeviceFlag &fi
     KERNEL<<<grid, block, 0, st>>>(__VA_ARGS__);                                            \
   } while (0)
 
+// how often the synchronised entries took each form (tests and bench.py report it: "did the exchange really run inside the kernel?")
+static int64_t g_sync_form_calls[2] = {0, 0};     // [one launch with the exchange inside, statistics + exchange kernel + normalise]
+
 static SyncArgs no_sync() {
   SyncArgs a = {};
   a.status = status_words();
@@ -2255,12 +2258,14 @@ int skd_abn_forward_train_nhwc_sync(void *sync_ctx, int64_t rows, int C, const f
   if (sync_fused_enabled() && aligned16(mean) && aligned16(var) && fwd_fused_geom(activation, residual != nullptr, rows, C, f)) {
     SyncArgs sy;
     if (!sync_next(sync_ctx, sy)) return 0;
+    ++g_sync_form_calls[0];
     const int r = residual ? launch_fwd_fused<true, true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
                                                           weight, bias, momentum, eps, slope, workspace, st, f, sy, replica_weights, (float)n)
                            : launch_fwd_fused<false, true>(activation, rows, C, x, residual, out, mean, var, running_mean, running_var,
                                                            weight, bias, momentum, eps, slope, workspace, st, f, sy, replica_weights, (float)n);
     return r > 0 ? 1 : 0;          // (a sequence number has been drawn: "not taken" is no longer an option)
   }
+  ++g_sync_form_calls[1];
   float *local = workspace + (int64_t)kRedMaxWG * 2 * C;       // this replica's [mean | var]
   if (!launch_stats_nhwc2(rows, C, x, local, local + C, nullptr, nullptr, 0.f, workspace, st)) return 0;
   if (!skd_abn_sync_stats(sync_ctx, C, local, replica_weights, mean, var, running_mean, running_var, momentum, n, stream)) return 0;
@@ -2402,6 +2407,7 @@ static int abn_backward_nhwc_any(void *sync_ctx, const float *rweights, int64_t 
     if (sync_ctx) {
       SyncArgs sy;
       if (!sync_next(sync_ctx, sy)) return 0;
+      ++g_sync_form_calls[0];
       r = activation == SKD_ACT_LEAKY_RELU
               ? launch_bwd_fused<SKD_ACT_LEAKY_RELU, 0, false, true>(rows, C, z, dz, nullptr, nullptr, var, weight, bias, edz, eydz, dx, nullptr,
                                                                      dweight, dbias, eps, slope, accumulate, workspace, st, f, sy, rweights)
@@ -2418,6 +2424,7 @@ static int abn_backward_nhwc_any(void *sync_ctx, const float *rweights, int64_t 
     if (r >= 0) return r;
   }
   if (!skd_abn_backward_reduce_nhwc(rows, C, z, dz, weight, bias, edz, eydz, eps, activation, slope, workspace, stream)) return 0;
+  if (sync_ctx) ++g_sync_form_calls[1];
   if (sync_ctx && !skd_abn_sync_grad_stats(sync_ctx, C, edz, rweights, stream)) return 0;
   return skd_abn_backward_dx_nhwc(rows, C, z, dz, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, activation, slope,
                                   accumulate, stream);
@@ -2456,6 +2463,7 @@ static int abn_relu_backward_nhwc_any(void *sync_ctx, const float *rweights, int
     if (sync_ctx) {
       SyncArgs sy;
       if (!sync_next(sync_ctx, sy)) return 0;
+      ++g_sync_form_calls[0];
       if (out == nullptr)
         r = launch_bwd_fused<SKD_ACT_NONE, 2, false, true>(rows, C, x, dout, nullptr, mean, var, weight, bias, edz, eydz, dx, nullptr, dweight,
                                                            dbias, eps, 0.f, accumulate, workspace, st, f, sy, rweights);
@@ -2479,6 +2487,7 @@ static int abn_relu_backward_nhwc_any(void *sync_ctx, const float *rweights, int
                                                           dbias, eps, 0.f, accumulate, workspace, st, f, sy, nullptr);
     if (r >= 0) return r;
   }
+  if (sync_ctx) ++g_sync_form_calls[1];
   if (out == nullptr) {
     if (!skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dout, mean, var, weight, bias, edz, eydz, eps, workspace, stream)) return 0;
     if (sync_ctx && !skd_abn_sync_grad_stats(sync_ctx, C, edz, rweights, stream)) return 0;
@@ -2506,6 +2515,15 @@ int skd_abn_relu_backward_nhwc_sync(void *sync_ctx, int64_t rows, int C, const f
   if (!sync_ctx) return 0;
   return abn_relu_backward_nhwc_any(sync_ctx, replica_weights, rows, C, x, out, dout, mean, var, weight, bias, edz, eydz, dx, dres, dweight,
                                     dbias, eps, accumulate, workspace, stream);
+}
+
+// out[0] = synchronised calls that ran as ONE launch with the exchange inside, out[1] = as statistics + exchange kernel +
+// normalise (three launches), since the library was loaded.  Host counters, process-wide.
+int skd_abn_sync_form_counts(int64_t *out) {
+  if (!out) return 0;
+  out[0] = g_sync_form_calls[0];
+  out[1] = g_sync_form_calls[1];
+  return 1;
 }
 
 // Upper bound of the workgroups of a one-launch (grid-barrier) pass, on top of the device's own limit (compute units):

@@ -23,6 +23,9 @@
 // shape and epilogue reaches 0.60-0.86 of the nominal 157.3 TFLOP/s depending on how well M x N / (128 x 128) divides the
 // 256 CUs and on the sustained clock.
 // Bound: fp32 MFMA (157.3 TFLOP/s); algorithmic flops 2*M*N*K; epilogue traffic 4*M*N (+ 4*M*N residual) bytes.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "skd_common.hpp"
 
 namespace skd {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
     const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
     const float *__restrict__ bias, const float *__restrict__ ppack, float eps, float slope, int64_t M, int K, int N,
-    int tiles_n) {
+    int tiles_n, int pm, int ct) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md; used for traffic only, any
   // placement is correct) and every XCD has its own L2: the tiles_n workgroups that share one 128 x K activation panel are
@@ -173,10 +176,23 @@ __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
   // Counters before (profiles/r03d_gemm_lab_pmc.json, K = 256, N = 1024): 421 MB fetched for 174 MB of algorithmic reads
   // (8 x the 35 MB of activations); time-neutral in isolation (the Infinity Cache absorbs the fills), less traffic beside the
   // D stream.  Row panel p lives on XCD p % 8; the grid is padded to a multiple of 8 panels, the padding exits here.
+  //
+  // Round 4: for WIDE outputs that order thrashes the weights instead.  At K = 512, N = 2048 the 16 column
+  // tiles of a panel stream all of W (4 MB = one XCD's whole L2) past every panel: counters showed 850 MB fetched for 350 MB of
+  // algorithmic reads.  So an XCD walks SUPER-TILES: groups of `pm` row panels (<= 2 MB of activations) x chunks of `ct` column
+  // tiles (<= 1 MB of weights): for group: for chunk: for panel in group: for column tile in chunk.  A weight chunk is reused
+  // by pm panels back to back, a panel group stays L2-resident across the chunks; W traffic falls from ~one sweep per panel to one
+  // per group.  ct == tiles_n (narrow outputs, e.g. K = 256 / N = 1024: 23 of the 33 launches of a teacher forward) degenerates
+  // to the panel-major order above.
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int tn = j % tiles_n;
-  const int64_t tm = (int64_t)(j / tiles_n) * 8 + xcd;
-  if (tm * kTM >= M) return;
+  const int per_group = pm * tiles_n;
+  const int group = j / per_group, r = j - group * per_group;
+  const int per_chunk = pm * ct;
+  const int chunk = r / per_chunk, r2 = r - chunk * per_chunk;
+  const int pl = r2 / ct;
+  const int tn = chunk * ct + (r2 - pl * ct);
+  const int64_t tm = ((int64_t)group * pm + pl) * 8 + xcd;
+  if (tm * kTM >= M || tn >= tiles_n) return;
   const int64_t m0 = tm * kTM;
   const int n0 = tn * kTN;
   f32x16 acc[2][2];
@@ -246,6 +262,17 @@ __global__ void pack_eval_params_kernel(int K, const float *__restrict__ mean, c
   pack[3 * (int64_t)K + k] = bias != nullptr ? bias[k] : 0.f;
 }
 
+// SKD_GEMM_TILE_ORDER="ct,pm" overrides the super-tile geometry (counter experiments: tools/conv1x1_bench.py); "0" = the
+// round-3 panel-major order everywhere
+static void tile_order_override(int &ct, int &pm) {
+  const char *e = getenv("SKD_GEMM_TILE_ORDER");
+  if (e == nullptr || e[0] == 0) return;
+  int a = 0, b = 0;
+  const int n = sscanf(e, "%d,%d", &a, &b);
+  if (n == 1 && a == 0) { ct = 1 << 20; pm = 1; }
+  else if (n == 2 && a > 0 && b > 0) { ct = a; pm = b; }
+}
+
 template <int ACT, bool HAS_RES, bool PRO>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
                   const float *weight, const float *bias, const float *ppack, float eps, float slope, int64_t M, int K, int N,
@@ -261,10 +288,19 @@ static int launch(const float *X, const float *Wt, const float *R, float *Y, con
   const size_t lds_bytes = kConvLds + (PRO ? sizeof(float) * 4 * (size_t)K : 0);
   const int tiles_n = N / kTN;
   const int64_t tiles_m = cdiv(M, kTM);
-  if ((tiles_m + 8) * tiles_n > 2147483647) return 0;
-  const int64_t grid = cdiv(tiles_m, 8) * 8 * tiles_n;     // row panels padded to a multiple of the 8 XCDs
+  // super-tile geometry (see the kernel): column-tile chunks of <= 1 MB of weights, panel groups of <= 2 MB of activations
+  const int64_t tile_bytes = (int64_t)kTN * K * sizeof(float);
+  int ct = (int)((1 << 20) / tile_bytes), pm = (int)((2 << 20) / tile_bytes);
+  tile_order_override(ct, pm);
+  if (ct < 1) ct = 1;
+  if (pm < 1) pm = 1;
+  if (ct >= tiles_n) { ct = tiles_n; pm = 1; }              // narrow output: plain panel-major order
+  while (tiles_n % ct) --ct;                                // chunks of equal width (tiles_n is a power of two in this network)
+  const int64_t panels_per_xcd = cdiv(cdiv(tiles_m, 8), pm) * pm;   // row panels padded to whole groups on each of the 8 XCDs
+  if (panels_per_xcd * 8 * tiles_n > 2147483647) return 0;
+  const int64_t grid = panels_per_xcd * 8 * tiles_n;
   conv1x1_abn_kernel<ACT, HAS_RES, PRO><<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(
-      X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n);
+      X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n, pm, ct);
   return ok();
 }
 

@@ -778,6 +778,54 @@ def spectral_normalize(w_bar, u, v):
     return _SpectralNormalize.apply(w_bar, u, v)
 
 
+class _SpectralNormalizeMulti(Function):
+    """``_SpectralNormalize`` for ALL spectrally normalised layers of a network at once (skd_spectral_norm_*_multi): three
+    launches forward and two backward for the whole set instead of per layer.  ``us`` / ``vs``: lists of the layers' u / v
+    tensors (held by reference and read again at backward time, like the single-layer op); returns one normalised weight per
+    layer."""
+
+    @staticmethod
+    def forward(ctx, us, vs, *w_bars):
+        _lib.require_device(*w_bars, *us, *vs)
+        wbs = [_f32c(w, "spectral_normalize_multi") for w in w_bars]
+        hs = [w.shape[0] for w in wbs]
+        ws_ = [w.numel() // h for w, h in zip(wbs, hs)]
+        for u, v, h, wd in zip(us, vs, hs, ws_):
+            if not (u.is_contiguous() and v.is_contiguous()) or u.numel() != h or v.numel() != wd:
+                raise ValueError("spectral_normalize: u/v must be contiguous vectors of length (out, in*kh*kw)")
+        lib, st = _lib.get(), _lib.stream_of(wbs[0])
+        sigmas = wbs[0].new_empty((len(wbs),))
+        outs = [torch.empty_like(w) for w in wbs]
+        work = wbs[0].new_empty((sum(max(1, lib.skd_spectral_workspace_floats(h, wd)) for h, wd in zip(hs, ws_)),))
+        sig = [sigmas[k:k + 1] for k in range(len(wbs))]
+        _lib.check(lib.skd_spectral_norm_forward_multi(len(wbs), _lib.int_array(hs), _lib.int_array(ws_), _lib.ptr_array(wbs),
+                                                       _lib.ptr_array(us), _lib.ptr_array(vs), _lib.ptr_array(sig),
+                                                       _lib.ptr_array(outs), work.data_ptr(), st), "skd_spectral_norm_forward_multi")
+        ctx.us, ctx.vs, ctx.hs, ctx.ws_ = list(us), list(vs), hs, ws_
+        ctx.save_for_backward(sigmas, *wbs)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gws):
+        sigmas, *wbs = ctx.saved_tensors
+        lib, st = _lib.get(), _lib.stream_of(wbs[0])
+        gws = [torch.zeros_like(w) if g is None else _f32c(g, "spectral_normalize backward") for g, w in zip(gws, wbs)]
+        gwbs = [torch.empty_like(w) for w in wbs]
+        work = wbs[0].new_empty((sum(max(1, lib.skd_spectral_workspace_floats(h, wd)) for h, wd in zip(ctx.hs, ctx.ws_)),))
+        sig = [sigmas[k:k + 1] for k in range(len(wbs))]
+        _lib.check(lib.skd_spectral_norm_backward_multi(len(wbs), _lib.int_array(ctx.hs), _lib.int_array(ctx.ws_), _lib.ptr_array(wbs),
+                                                        _lib.ptr_array(ctx.us), _lib.ptr_array(ctx.vs), _lib.ptr_array(sig),
+                                                        _lib.ptr_array(gws), _lib.ptr_array(gwbs), work.data_ptr(), st),
+                   "skd_spectral_norm_backward_multi")
+        return (None, None) + tuple(gwbs)
+
+
+def spectral_normalize_multi(w_bars, us, vs):
+    """[w_bar_k / sigma_k] after one power iteration per layer (u_k, v_k updated in place): all layers in 3 launches."""
+    return _SpectralNormalizeMulti.apply(list(us), list(vs), *w_bars)
+
+
 def spectral_power_iteration(w_bar, u, v):
     """u, v update only (extra iterations when power_iterations > 1); returns sigma (0-dim)."""
     _lib.require_device(w_bar, u, v)

@@ -45,6 +45,16 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
                                   "train_and_eval.py evaluates with whole=True")
     if type != "val":
         raise NotImplementedError("test-split prediction dump (evaluate.py:187-191) is host-side tooling")
+    if world > 1:
+        # Sharding by ``index % world`` assumes every rank walks the SAME sequence of batches.  A loader that already shards
+        # (DistributedSampler) or shuffles would have each rank skip most of its own subset and score a silently smaller set
+        # (ADVICE r03): refuse it.
+        sampler = getattr(loader, "sampler", None)
+        from torch.utils.data import RandomSampler
+        from torch.utils.data.distributed import DistributedSampler
+        if isinstance(sampler, (DistributedSampler, RandomSampler)) or isinstance(getattr(loader, "batch_sampler", None), DistributedSampler):
+            raise ValueError("evaluate_main shards the validation set itself (batch i on rank i %% world): hand it a plain, "
+                             "unshuffled, unsharded loader (got sampler %s)" % type(sampler).__name__)
     device = torch.device("cuda", int(gpu_id) if str(gpu_id).isdigit() else 0) if torch.cuda.is_available() \
         else next(model.parameters()).device
     was_training = model.training
@@ -55,31 +65,60 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
     # whole-image forward (features 129 x 257 at 1024 x 2048) stays on the NHWC ABN / pyramid / fold kernels
     w4 = [p for p in model.parameters() if p.dim() == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1]
     cl_model = device.type == "cuda" and bool(w4) and all(p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() for p in w4)
+    seen, failure = 0, None
     with torch.no_grad():
         for index, batch in enumerate(loader):
             if index % world != rank:
                 continue
-            image, label, size = batch[0], batch[1], batch[2]
-            lab_np = np.asarray(label) if not torch.is_tensor(label) else label.numpy() if label.device.type == "cpu" else None
-            if lab_np is not None and bool(((lab_np != ignore_label) & ((lab_np < 0) | (lab_np >= num_classes))).any()):
-                # np.bincount of evaluate.py:188-198 would count such labels (and index out of the matrix); the fused
-                # kernel skips them -- refuse instead of scoring a quietly smaller set (raw label ids not mapped to trainIds?)
-                raise ValueError("label values outside [0, %d) other than ignore_label %d" % (num_classes, ignore_label))
-            image = torch.as_tensor(np.asarray(image) if not torch.is_tensor(image) else image).float().to(device)
-            label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).long().to(device)
-            sz = np.asarray(size[0] if (torch.is_tensor(size) or isinstance(size, (list, tuple))) else size).reshape(-1)
-            hh, ww = int(sz[0]), int(sz[1])
-            if cl_model and image.dim() == 4:
-                image = image.contiguous(memory_format=torch.channels_last)   # keep the network on its channels-last kernels
-            logits = model(image)
-            if isinstance(logits, (list, tuple)):
-                logits = logits[0]
-            # predict_whole upsamples to the tile size (1024, 2048); only [:h, :w] of the label is scored (evaluate.py:194)
-            full = label.new_full(label.shape, ignore_label)
-            full[:, :hh, :ww] = label[:, :hh, :ww]
-            SF.seg_confusion(logits.float(), full, ignore_label, confusion, want_pred=False)
+            if failure is not None:
+                continue
+            seen += 1
+            try:
+                _score_batch(model, batch, device, num_classes, cl_model, confusion)
+            except Exception as e:                    # reported AFTER the collective below, so that no rank is left hanging in it
+                if world <= 1:
+                    raise
+                failure = e
     if was_training:
         model.train()
     if world > 1:
-        torch.distributed.all_reduce(confusion, group=group)           # exact: int64 counts
+        # one exchange: the confusion counts (exact, int64), how many batches were scored, and whether any rank failed
+        extra = torch.tensor([seen, 1 if failure is not None else 0], dtype=torch.int64, device=device)
+        flat = torch.cat([confusion.reshape(-1), extra])
+        torch.distributed.all_reduce(flat, group=group)
+        confusion = flat[:-2].reshape(num_classes, num_classes)
+        total, failed = int(flat[-2]), int(flat[-1])
+        if failure is not None:
+            raise failure
+        if failed:
+            raise RuntimeError("evaluate_main: %d other rank(s) failed while scoring their share of the validation set" % failed)
+        try:
+            expected = len(loader)
+        except TypeError:
+            expected = None
+        if expected is not None and total != expected:
+            raise RuntimeError("evaluate_main: the ranks scored %d batches together but the loader holds %d" % (total, expected))
     return iou_from_confusion(confusion.cpu().numpy())
+
+
+def _score_batch(model, batch, device, num_classes, cl_model, confusion):
+    """One validation batch: forward on the whole image, fused upsample + argmax + confusion accumulation (csrc/evaluate.hip)."""
+    image, label, size = batch[0], batch[1], batch[2]
+    lab_np = np.asarray(label) if not torch.is_tensor(label) else label.numpy() if label.device.type == "cpu" else None
+    if lab_np is not None and bool(((lab_np != ignore_label) & ((lab_np < 0) | (lab_np >= num_classes))).any()):
+        # np.bincount of evaluate.py:188-198 would count such labels (and index out of the matrix); the fused
+        # kernel skips them -- refuse instead of scoring a quietly smaller set (raw label ids not mapped to trainIds?)
+        raise ValueError("label values outside [0, %d) other than ignore_label %d" % (num_classes, ignore_label))
+    image = torch.as_tensor(np.asarray(image) if not torch.is_tensor(image) else image).float().to(device)
+    label = torch.as_tensor(np.asarray(label) if not torch.is_tensor(label) else label).long().to(device)
+    sz = np.asarray(size[0] if (torch.is_tensor(size) or isinstance(size, (list, tuple))) else size).reshape(-1)
+    hh, ww = int(sz[0]), int(sz[1])
+    if cl_model and image.dim() == 4:
+        image = image.contiguous(memory_format=torch.channels_last)   # keep the network on its channels-last kernels
+    logits = model(image)
+    if isinstance(logits, (list, tuple)):
+        logits = logits[0]
+    # predict_whole upsamples to the tile size (1024, 2048); only [:h, :w] of the label is scored (evaluate.py:194)
+    full = label.new_full(label.shape, ignore_label)
+    full[:, :hh, :ww] = label[:, :hh, :ww]
+    SF.seg_confusion(logits.float(), full, ignore_label, confusion, want_pred=False)

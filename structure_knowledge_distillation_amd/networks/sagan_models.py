@@ -6,7 +6,9 @@ double backward through them keeps working).  The unused ``Generator`` is out of
 import torch
 import torch.nn as nn
 
-from .spectral import SpectralNorm
+import os
+
+from .spectral import SpectralNorm, normalize_together
 
 
 class Self_Attn(nn.Module):
@@ -76,6 +78,11 @@ class Discriminator(nn.Module):
             raise ValueError("preprocess_GAN_mode should be 1:bn or 2:tanh or 3:-1 - 1")
 
     def forward(self, x):
+        # the four spectrally normalised weights of this forward in 3 launches instead of 12 (csrc/spectral.hip, "several layers
+        # per launch"); SKD_SN_TOGETHER=0 keeps one wrapper at a time
+        if os.environ.get("SKD_SN_TOGETHER", "1") == "1":
+            normalize_together([blk[0] for blk in (self.l1, self.l2, self.l3, getattr(self, "l4", None))
+                                if blk is not None and isinstance(blk[0], SpectralNorm)])
         x = self.preprocess_additional(x)
         out = self.l3(self.l2(self.l1(x)))
         out, p1 = self.attn1(out)

@@ -61,9 +61,33 @@ class SpectralNorm(nn.Module):
         return getattr(layer, name + "_bar"), getattr(layer, name + "_u"), getattr(layer, name + "_v")
 
     def forward(self, *args):
+        if getattr(self, "_prepared", False):
+            # normalize_together() has advanced u, v and installed the normalised weight for THIS forward already
+            self._prepared = False
+            return self.module.forward(*args)
         w_bar, u, v = self._parts()
         for _ in range(self.power_iterations - 1):
             SF.spectral_power_iteration(w_bar, u.data, v.data)
         # the final power step, sigma and w_bar / sigma in one fused op; u.data / v.data are overwritten in place
         setattr(self.module, self.name, SF.spectral_normalize(w_bar, u.data, v.data))
         return self.module.forward(*args)
+
+
+def normalize_together(wrappers):
+    """One power step + ``weight = weight_bar / sigma`` for SEVERAL ``SpectralNorm`` wrappers in three kernel launches
+    (functional.spectral_normalize_multi) instead of three per wrapper; each wrapper's next ``forward`` then only runs its
+    layer.  What a caller can observe is what ``SpectralNorm.forward`` does one wrapper at a time (spectral.py:23-35, 63-68):
+    every wrapper's u / v advance exactly once per call, through ``.data``; the layers are independent, so doing their power
+    steps side by side instead of interleaved with the convolutions changes no number.  Wrappers with more than one power
+    iteration, CPU tensors without the test double, or a single wrapper keep the per-wrapper path (returns False)."""
+    wrappers = list(wrappers)
+    if len(wrappers) < 2 or len(wrappers) > 8 or any(w.power_iterations != 1 or getattr(w, "_prepared", False) for w in wrappers):
+        return False
+    parts = [w._parts() for w in wrappers]
+    if len({(p[0].device, p[0].dtype) for p in parts}) != 1:
+        return False
+    weights = SF.spectral_normalize_multi([p[0] for p in parts], [p[1].data for p in parts], [p[2].data for p in parts])
+    for w, t in zip(wrappers, weights):
+        setattr(w.module, w.name, t)
+        w._prepared = True
+    return True

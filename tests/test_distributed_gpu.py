@@ -28,7 +28,7 @@ def _worker(rank, world, port, fn_name, outdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", MIOPEN_LOG_LEVEL="3")
-    os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "30")      # tests: a protocol mistake must cost seconds of GPU-box time, not 600 s per exchange
+    os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "20")      # tests: a protocol mistake must cost seconds of GPU-box time, not 600 s per exchange
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -103,7 +103,7 @@ def _sync_abn_nhwc_forms(rank, world):
     from structure_knowledge_distillation_amd.utils import parallel as P
     dev = torch.device("cuda", 0)
     mb = P.SyncMailbox.get(dist.group.WORLD, dev)
-    assert mb is not None
+    assert mb is not None and mb.lib.skd_sync_set_timeout(mb.ctx, 8.0)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     cap = _lib.get().skd_abn_set_fused_max_workgroups(-1)           # query: what SyncMailbox's device-sharing detection left in place
     out = {"cap": cap, "cus": cus}
@@ -129,11 +129,13 @@ def _sync_abn_nhwc_forms(rank, world):
                     z = mod.forward_relu(cl(xs * 1.0), cl(rs * 1.0) if kind == "relu_res" else None)
                 (z * gz[sl].to(dev)).sum().backward()
                 torch.cuda.synchronize()
+                _lib.raise_on_device_errors()          # a timed-out in-kernel wait: stop here, not 50 exchanges x the time limit later
                 out[(C, form, kind)] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "dr": None if rs.grad is None else rs.grad.cpu(),
                                         "dw": mod.weight.grad.cpu(), "db": mod.bias.grad.cpu(),
                                         "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
     os.environ.pop("SKD_ABN_SYNC_FUSED", None)
     out["status"] = _lib.device_status()
+    out["forms"] = _lib.sync_form_counts()
     return out
 
 
@@ -143,6 +145,9 @@ def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
     # two ranks on one device: SyncMailbox must have split the compute units between them (grid barrier + in-kernel wait for the peer)
     assert outs[0]["cap"] <= (outs[0]["cus"] - 16) // 2 and outs[0]["cap"] == outs[1]["cap"], (outs[0]["cap"], outs[0]["cus"])
     assert not any(outs[0]["status"]) and not any(outs[1]["status"]), "an in-kernel wait timed out"
+    # 3 shapes x 3 kinds x (forward + backward) = 18 synchronised calls per form: rank 0 ran 36 as one launch (fused + mixed) and 18
+    # as three launches, rank 1 the other way round -- the forms really differed between the ranks in the mixed pass
+    assert outs[0]["forms"] == (36, 18) and outs[1]["forms"] == (18, 36), (outs[0]["forms"], outs[1]["forms"])
     for C, hw in ((64, 65), (256, 33), (128, 65)):
         g = torch.Generator().manual_seed(C)
         x = torch.randn(4, C, hw, hw, generator=g) * 2 + 1
@@ -317,6 +322,8 @@ def _netmodel_step_once(rank, world, gen):
     from structure_knowledge_distillation_amd.utils import parallel as P
     dev = torch.device("cuda", 0)
     P.SyncMailbox.reset()                  # SKD_SYNC_IPC is read when the group's mailbox context is built
+    from structure_knowledge_distillation_amd import _lib as L
+    forms0 = L.sync_form_counts()
     torch.manual_seed(10 + rank)           # different init per rank: construction must broadcast rank 0's weights
     model = NetModel(default_args(batch_size=_B * world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
     assert (model._d_stream is not None) == (os.environ.get("SKD_D_STREAM", "1") == "1")
@@ -337,7 +344,9 @@ def _netmodel_step_once(rank, world, gen):
     model.optimize_parameters()            # two-stream or serial per SKD_D_STREAM; D's all-reduces start inside its stream
     torch.cuda.synchronize()
     assert all(p.requires_grad for p in model._d_params)
+    forms1 = L.sync_form_counts()
     return {"built": built, "ipc": P.SyncMailbox.get(dist.group.WORLD, dev) is not None,     # cached by now: not collective
+            "forms": (forms1[0] - forms0[0], forms1[1] - forms0[1]),      # synchronised ABN calls: (one launch, three launches)
             "grads": {k: p.grad.detach().cpu() for k, p in model.student.named_parameters()},
             "d_grads": {k: p.grad.detach().cpu() for k, p in model.D_model.named_parameters() if p.grad is not None},
             "losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")},
@@ -498,6 +507,8 @@ def test_netmodel_ho_step_two_ranks_one_launch_syncabn_is_deterministic_and_matc
     partial sums, so bit equality between them is not defined; between runs and between replicas it is)."""
     a, b, three = _variant("det_fused"), _variant("det_fused_again"), _variant("det_ipc1")
     for r in range(2):
+        # 29 training ABN layers, forward + backward; the (B, C, 1, 1) pyramid stage is NCHW-contiguous and exchanges from Python
+        assert a[r]["forms"][0] >= 50 and three[r]["forms"][0] == 0 and three[r]["forms"][1] >= 50, (a[r]["forms"], three[r]["forms"])
         assert a[r]["ipc"] and a[r]["losses"] == b[r]["losses"], (r, a[r]["losses"], b[r]["losses"])
         for name in ("grads", "d_grads", "after", "d_after"):
             diff = [k for k in a[r][name] if not torch.equal(a[r][name][k], b[r][name][k])]
@@ -538,7 +549,8 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     assert out["roofline"]["bound"] in ("mfma", "hbm") and out["roofline"]["achieved"] > 0      # mfma: the fused bottleneck-tail GEMM (default)
     comm = out["comm"]
     assert comm["syncabn_collectives"] == 58                                      # 29 training ABN layers, forward + backward
-    assert comm["syncabn_in_abn_calls"] == 58 and comm["abn_sync_call_ms"] > 0     # all channels-last: exchanged inside the ABN calls
+    # channels-last layers exchange inside the ABN calls; the (B, C, 1, 1) pyramid stage is NCHW-contiguous: from Python
+    assert comm["syncabn_in_abn_calls"] >= 50 and comm["abn_sync_call_ms"] > 0 and comm["syncabn_one_launch_calls"] >= 50
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"
 
 

@@ -101,6 +101,32 @@ def test_spectral_norm_wrapper_state_and_quirk():
     assert rel(conv.weight_bar.grad, Pd["weight_bar"].grad) < 1e-4
 
 
+def test_discriminator_normalises_its_weights_together_with_the_same_numbers(monkeypatch):
+    """networks/spectral.py::normalize_together (3 launches for the discriminator's four weights instead of 12) against one
+    wrapper at a time: three forwards then one backward (kd_model.py:153-165) -- same outputs, same u / v, same gradients."""
+    from structure_knowledge_distillation_amd.networks import sagan_models
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SKD_SN_TOGETHER", flag)
+        torch.manual_seed(11)
+        D = sagan_models.Discriminator(1, 19, 2, 65, 64).train()
+        with torch.no_grad():
+            D.attn1.gamma.fill_(0.3)
+        g = torch.Generator().manual_seed(12)
+        a, b = torch.randn(2, 19, 65, 65, generator=g), torch.randn(2, 19, 65, 65, generator=g)
+        with torch.no_grad():
+            D(a)
+        loss = D(b)[0].mean() - D(a)[0].mean()
+        loss.backward()
+        res[flag] = (float(loss), {k: v.detach().clone() for k, v in D.state_dict().items()},
+                     {k: p.grad.clone() for k, p in D.named_parameters() if p.grad is not None})
+        assert not any(getattr(blk[0], "_prepared", False) for blk in (D.l1, D.l2, D.l3, D.l4))
+    assert res["1"][0] == res["0"][0]
+    for which in (1, 2):
+        for k, v in res["0"][which].items():
+            assert torch.equal(v, res["1"][which][k]), k
+
+
 def test_inference_fusion_equals_unfused_graph():
     """Under no_grad + eval the networks take the fused BN->ReLU / BN->(+res)->ReLU passes; with grad enabled
     they run the reference's op sequence.  Same numbers either way (teacher = Bottleneck, student = BasicBlock)."""

@@ -727,6 +727,41 @@ def test_spectral_norm(hip, ref, h, w):
     close(gg, gr, 5e-5, "grad_w_bar")
 
 
+@pytest.mark.parametrize("shapes", [[(64, 304), (128, 1024), (256, 2048), (512, 4096)], [(7, 5), (1, 1)], [(33, 1000), (64, 304), (5, 3)]])
+def test_spectral_norm_multi_is_bit_identical_to_the_single_layer_entries(hip, shapes):
+    """All spectrally normalised layers of the discriminator in 3 + 2 launches (skd_spectral_norm_*_multi): per layer the
+    same kernels' arithmetic, so u, v, sigma, w and the gradient have the SAME BITS as the single-layer entries."""
+    L = len(shapes)
+    g = torch.Generator().manual_seed(L * 100 + shapes[0][0])
+    Ws = [gpu(torch.randn(h, w, generator=g) * 0.05) for h, w in shapes]
+    u0 = [torch.randn(h, generator=g) for h, _ in shapes]
+    v0 = [torch.randn(w, generator=g) for _, w in shapes]
+    gws = [gpu(torch.randn(h, w, generator=g)) for h, w in shapes]
+    hs, ws_ = (ctypes.c_int * L)(*[h for h, _ in shapes]), (ctypes.c_int * L)(*[w for _, w in shapes])
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    # single-layer entries, two consecutive forwards (u, v persist)
+    us, vs = [gpu(u / u.norm()) for u in u0], [gpu(v / v.norm()) for v in v0]
+    sig_s, out_s, gb_s = [torch.empty(1, device=DEV) for _ in shapes], [torch.empty_like(W) for W in Ws], [torch.empty_like(W) for W in Ws]
+    for k, (h, w) in enumerate(shapes):
+        ws = torch.empty(max(1, hip.skd_spectral_workspace_floats(h, w)), device=DEV)
+        for _ in range(2):
+            assert hip.skd_spectral_norm_forward(h, w, P(Ws[k]), P(us[k]), P(vs[k]), P(sig_s[k]), P(out_s[k]), P(ws), None)
+        assert hip.skd_spectral_norm_backward(h, w, P(Ws[k]), P(us[k]), P(vs[k]), P(sig_s[k]), P(gws[k]), P(gb_s[k]), P(ws), None)
+    # the multi entries
+    um, vm = [gpu(u / u.norm()) for u in u0], [gpu(v / v.norm()) for v in v0]
+    sig_m = torch.empty(L, device=DEV)
+    sig_l = [sig_m[k:k + 1] for k in range(L)]
+    out_m, gb_m = [torch.empty_like(W) for W in Ws], [torch.empty_like(W) for W in Ws]
+    work = torch.empty(sum(max(1, hip.skd_spectral_workspace_floats(h, w)) for h, w in shapes), device=DEV)
+    for _ in range(2):
+        assert hip.skd_spectral_norm_forward_multi(L, hs, ws_, arr(Ws), arr(um), arr(vm), arr(sig_l), arr(out_m), P(work), None)
+    assert hip.skd_spectral_norm_backward_multi(L, hs, ws_, arr(Ws), arr(um), arr(vm), arr(sig_l), arr(gws), arr(gb_m), P(work), None)
+    torch.cuda.synchronize()
+    for k in range(L):
+        assert torch.equal(um[k], us[k]) and torch.equal(vm[k], vs[k]) and torch.equal(sig_l[k], sig_s[k]), k
+        assert torch.equal(out_m[k], out_s[k]) and torch.equal(gb_m[k], gb_s[k]), k
+
+
 @pytest.mark.parametrize("geom", [(2, 19, 9, 9, 65, 65), (8, 19, 65, 65, 512, 512), (2, 19, 33, 33, 256, 256), (3, 11, 46, 61, 360, 480),
                                   (1, 3, 1, 1, 4, 4), (1, 40, 5, 7, 5, 7), (2, 21, 17, 9, 100, 3)])
 def test_ce_dsn(hip, ref, geom):

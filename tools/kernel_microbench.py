@@ -8,7 +8,9 @@ dispatch of the counter CSVs back to its case through the markers (a skd_leaky_r
 the case id), so per-case HBM bytes / MFMA counters need no guessing from grid sizes.
 
 Cases = the channels-last TRAINING InPlace-ABN entries on the student's layers, the channels-last inference apply on
-the teacher's layers, and the pair-wise Gram / backward kernels at M in {9, 1089, 4225}.  Each case states its
+the teacher's layers, the pair-wise Gram / backward kernels at M in {9, 1089, 4225}, and (round 4) one isolated row per
+remaining kernel family: spectral norm (single layer and all four layers of D per launch), pixel-wise KL, fused
+upsample + CE, channels-last pyramid pooling / concat, the stem max-pool, the pair-wise pooling, the evaluation tail.  Each case states its
 ALGORITHMIC bytes or flops per call; the manifest is printed as the first JSON line.
 """
 import json
@@ -103,6 +105,83 @@ def build_cases(lib, torch, dev, st):
             lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, p(fs), p(ft), None, p(loss), p(ws), st), flops=2.0 * B * M * M * (Cs + Ct))
         add("pairwise_backward", [B, Cs, M], lambda fs=fs, G=G, nrm=nrm, gl=gl, dp=dp, bws=bws, M=M, ldm=ldm:
             lib.skd_pairwise_backward(B, Cs, M, ldm, p(fs), p(G), p(nrm), p(gl), p(dp), p(bws), st), flops=2.0 * B * M * M * Cs)
+    # ---- the other hand-written kernel families (every .hip file gets an isolated roofline row) ----
+    import ctypes
+    iarr = lambda v: (ctypes.c_int * len(v))(*v)
+    parr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    # spectral norm (csrc/spectral.hip): algorithmic bytes per layer-forward = 4 x numel(W) x 4 (two mat-vec reads, read + write of
+    # W / sigma), backward the same (read gW, W twice, write gW_bar)
+    SN = [(64, 19 * 16), (128, 64 * 16), (256, 128 * 16), (512, 256 * 16)]
+    sn_t = []
+    for h, w in SN:
+        W, out, gw, gwb = (torch.randn(h, w, device=dev) * 0.05 for _ in range(4))
+        u, v, sg = torch.randn(h, device=dev), torch.randn(w, device=dev), torch.ones(1, device=dev)
+        ws = torch.empty(max(1, lib.skd_spectral_workspace_floats(h, w)), device=dev)
+        sn_t.append((W, out, gw, gwb, u, v, sg, ws))
+        add("spectral_norm_forward", [h, w], lambda W=W, out=out, u=u, v=v, sg=sg, ws=ws, h=h, w=w:
+            lib.skd_spectral_norm_forward(h, w, p(W), p(u), p(v), p(sg), p(out), p(ws), st), 16 * h * w, keep=sn_t[-1])
+        add("spectral_norm_backward", [h, w], lambda W=W, gw=gw, gwb=gwb, u=u, v=v, sg=sg, ws=ws, h=h, w=w:
+            lib.skd_spectral_norm_backward(h, w, p(W), p(u), p(v), p(sg), p(gw), p(gwb), p(ws), st), 16 * h * w)
+    hs, ws_ = iarr([h for h, _ in SN]), iarr([w for _, w in SN])
+    work = torch.empty(sum(max(1, lib.skd_spectral_workspace_floats(h, w)) for h, w in SN), device=dev)
+    sig = torch.ones(len(SN), device=dev)
+    sigl = [sig[k:k + 1] for k in range(len(SN))]
+    tot = sum(h * w for h, w in SN)
+    add("spectral_norm_forward_multi(4 layers of D)", [len(SN), tot], lambda:
+        lib.skd_spectral_norm_forward_multi(len(SN), hs, ws_, parr([t[0] for t in sn_t]), parr([t[4] for t in sn_t]), parr([t[5] for t in sn_t]),
+                                            parr(sigl), parr([t[1] for t in sn_t]), p(work), st), 16 * tot, keep=(work, sig, sigl))
+    add("spectral_norm_backward_multi(4 layers of D)", [len(SN), tot], lambda:
+        lib.skd_spectral_norm_backward_multi(len(SN), hs, ws_, parr([t[0] for t in sn_t]), parr([t[4] for t in sn_t]), parr([t[5] for t in sn_t]),
+                                             parr(sigl), parr([t[2] for t in sn_t]), parr([t[3] for t in sn_t]), p(work), st), 16 * tot)
+    # pixel-wise KL (csrc/pixelwise.hip): read S, read T, write dS
+    N, C, HW = 8, 19, 65 * 65
+    S_, T_, dS = (torch.randn(N, C, HW, device=dev) for _ in range(3))
+    pl, pws = torch.empty(1, device=dev), torch.empty(max(1, lib.skd_pixelwise_workspace_floats(N, HW)), device=dev)
+    add("pixelwise_loss", [N, C, HW], lambda: lib.skd_pixelwise_loss(N, C, HW, p(S_), p(T_), p(pl), p(dS), p(pws), st), 12 * N * C * HW,
+        keep=(S_, T_, dS, pl, pws))
+    # fused bilinear upsample + CE of both heads (csrc/ce_dsn.hip): the int64 target + 2 x (logits read + gradient write)
+    h_, w_, H_, W_ = 65, 65, 512, 512
+    lm, ld, gm, gd = (torch.randn(N, C, h_, w_, device=dev) for _ in range(4))
+    tg = torch.randint(0, C, (N, H_, W_), device=dev)
+    cl_, cws = torch.empty(1, device=dev), torch.empty(max(8, lib.skd_ce_dsn_workspace_floats(N, C, h_, w_, H_, W_)), device=dev)
+    add("ce_dsn_forward(+grads)", [N, C, h_, w_, H_, W_], lambda:
+        lib.skd_ce_dsn_forward(N, C, h_, w_, H_, W_, p(lm), p(ld), p(tg), 255, 0.4, p(cl_), p(gm), p(gd), p(cws), st),
+        8 * N * H_ * W_ + 4 * 4 * N * C * h_ * w_, keep=(lm, ld, gm, gd, tg, cl_, cws))
+    # pyramid pooling, channels-last (csrc/ppm.hip): one read of the map (pool); one write of the concatenated tensor + reads (concat)
+    sizes = [1, 2, 3, 6]
+    sarr = iarr(sizes)
+    for B_, Cf, Cm in ((8, 2048, 512), (8, 512, 128)):
+        feats = torch.randn(B_, 65, 65, Cf, device=dev)
+        pooled = torch.empty(lib.skd_ppm_pooled_floats(B_ * Cf, 4, sarr), device=dev)
+        pws_ = torch.empty(max(1, lib.skd_ppm_nhwc_workspace_floats(B_, Cf, 0, 65, 65, 4, sarr)), device=dev)
+        add("ppm_pool_nhwc", [B_, Cf, 65, 65], lambda B_=B_, Cf=Cf, feats=feats, pooled=pooled, pws_=pws_:
+            lib.skd_ppm_pool_nhwc(B_, Cf, 65, 65, 4, sarr, p(feats), p(pooled), p(pws_), st), 4 * B_ * Cf * 65 * 65, keep=(feats, pooled, pws_))
+        priors = [torch.randn(B_, s_, s_, Cm, device=dev) for s_ in sizes]
+        cat = torch.empty(B_, 65, 65, 4 * Cm + Cf, device=dev)
+        add("ppm_concat_nhwc", [B_, Cm, Cf, 65, 65], lambda B_=B_, Cf=Cf, Cm=Cm, priors=priors, feats=feats, cat=cat:
+            lib.skd_ppm_concat_nhwc(B_, Cm, Cf, 65, 65, 4, sarr, parr(priors), p(feats), p(cat), st),
+            4 * B_ * 65 * 65 * (Cf + 4 * Cm + Cf), keep=(priors, cat))
+    # the stem's max-pool (csrc/maxpool.hip): 4 B/elem in + 5 B per output; backward 5 B per output + 4 B/elem out
+    B_, C_, Hh, Ww, OH, OW = 8, 128, 256, 256, 129, 129
+    mx, my, mdy, mdx = torch.randn(B_, Hh, Ww, C_, device=dev), torch.empty(B_, OH, OW, C_, device=dev), torch.randn(B_, OH, OW, C_, device=dev), torch.empty(B_, Hh, Ww, C_, device=dev)
+    marg = torch.empty(B_, OH, OW, C_, dtype=torch.uint8, device=dev)
+    add("maxpool3x3s2_nhwc", [B_, C_, Hh, Ww], lambda: lib.skd_maxpool3x3s2_nhwc(B_, C_, Hh, Ww, OH, OW, p(mx), p(my), p(marg), st),
+        4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW, keep=(mx, my, mdy, mdx, marg))
+    add("maxpool3x3s2_backward_nhwc", [B_, C_, Hh, Ww], lambda: lib.skd_maxpool3x3s2_backward_nhwc(B_, C_, Hh, Ww, OH, OW, p(mdy), p(marg), p(mdx), st),
+        4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW)
+    # the pair-wise criterion's max-pool with argmax (csrc/pairwise.hip, NCHW planes): read the feature maps once
+    for planes, kh in ((8 * 128, 32), (8 * 512, 32), (8 * 512, 1)):
+        fx = torch.randn(planes, 65, 65, device=dev)
+        oh = -(-65 // kh)
+        po, pi = torch.empty(planes, oh, oh, device=dev), torch.empty(planes, oh, oh, dtype=torch.int32, device=dev)
+        add("maxpool_argmax(pair-wise pooling)", [planes, 65, 65, kh], lambda planes=planes, kh=kh, fx=fx, po=po, pi=pi:
+            lib.skd_maxpool_argmax(planes, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * planes * 65 * 65 + 8 * planes * oh * oh, keep=(fx, po, pi))
+    # evaluation tail (csrc/evaluate.hip): 8 B label + 1 B prediction per pixel, the 129 x 257 logits from cache
+    el = torch.randn(1, 19, 129, 257, device=dev)
+    elab = torch.randint(0, 19, (1, 1024, 2048), device=dev)
+    econf, epred = torch.zeros(19, 19, dtype=torch.int64, device=dev), torch.empty(1, 1024, 2048, dtype=torch.uint8, device=dev)
+    add("seg_confusion(1024x2048)", [1, 19, 129, 257, 1024, 2048], lambda:
+        lib.skd_seg_confusion(1, 19, 129, 257, 1024, 2048, p(el), p(elab), 255, p(epred), p(econf), st), 9 * 1024 * 2048, keep=(el, elab, econf, epred))
     return cases
 
 
