@@ -115,8 +115,8 @@ def _sync_abn_nhwc_forms(rank, world):
         gz = torch.randn(4, C, hw, hw, generator=g)
         w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
         sl = slice(rank * 2, rank * 2 + 2)
-        for form in ("fused", "three", "mixed"):
-            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "three": "0", "mixed": "1" if rank == 0 else "0"}[form]
+        for form in ("fused", "fused_again", "three", "mixed"):
+            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "fused_again": "1", "three": "0", "mixed": "1" if rank == 0 else "0"}[form]
             for kind in ("leaky", "relu", "relu_res"):
                 mod = libs.InPlaceABNSync(C, activation="leaky_relu" if kind == "leaky" else "none").to(dev).train()
                 with torch.no_grad():
@@ -145,9 +145,9 @@ def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
     # two ranks on one device: SyncMailbox must have split the compute units between them (grid barrier + in-kernel wait for the peer)
     assert outs[0]["cap"] <= (outs[0]["cus"] - 16) // 2 and outs[0]["cap"] == outs[1]["cap"], (outs[0]["cap"], outs[0]["cus"])
     assert not any(outs[0]["status"]) and not any(outs[1]["status"]), "an in-kernel wait timed out"
-    # 3 shapes x 3 kinds x (forward + backward) = 18 synchronised calls per form: rank 0 ran 36 as one launch (fused + mixed) and 18
-    # as three launches, rank 1 the other way round -- the forms really differed between the ranks in the mixed pass
-    assert outs[0]["forms"] == (36, 18) and outs[1]["forms"] == (18, 36), (outs[0]["forms"], outs[1]["forms"])
+    # 3 shapes x 3 kinds x (forward + backward) = 18 synchronised calls per pass: rank 0 ran 54 as one launch (fused twice + mixed)
+    # and 18 as three launches, rank 1 36 / 36 -- the forms really differed between the ranks in the mixed pass
+    assert outs[0]["forms"] == (54, 18) and outs[1]["forms"] == (36, 36), (outs[0]["forms"], outs[1]["forms"])
     for C, hw in ((64, 65), (256, 33), (128, 65)):
         g = torch.Generator().manual_seed(C)
         x = torch.randn(4, C, hw, hw, generator=g) * 2 + 1
@@ -162,7 +162,7 @@ def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
             if kind != "leaky":
                 zo = torch.relu(zo + ro if kind == "relu_res" else zo)
             (zo * gz.double()).sum().backward()
-            for form in ("fused", "three", "mixed"):
+            for form in ("fused", "fused_again", "three", "mixed"):
                 o = [outs[rk][(C, form, kind)] for rk in range(2)]
                 for rk in range(2):
                     sl = slice(2 * rk, 2 * rk + 2)
@@ -174,11 +174,13 @@ def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
                 # every replica combined the same exchanged numbers in the same order: identical running statistics, bit for bit
                 assert torch.equal(o[0]["rm"], o[1]["rm"]) and torch.equal(o[0]["rv"], o[1]["rv"]), (C, form, kind)
                 assert rel(o[0]["dw"] + o[1]["dw"], wo.grad) < 1e-4 and rel(o[0]["db"] + o[1]["db"], bo.grad) < 1e-4, (C, form, kind)
-            # the one-launch form against the three-launch form: the same numbers up to the rounding of the partial sums
+            # the one-launch form against the three-launch form: the same numbers up to the rounding of the partial sums; against
+            # ITSELF (same inputs again): the same bits -- fixed-order reductions, rank-ordered combine, no atomics
             for rk in range(2):
-                a, c = outs[rk][(C, "fused", kind)], outs[rk][(C, "three", kind)]
+                a, c, a2 = outs[rk][(C, "fused", kind)], outs[rk][(C, "three", kind)], outs[rk][(C, "fused_again", kind)]
                 for k in ("z", "dx", "dw", "db", "rm", "rv"):
                     assert rel(a[k], c[k]) < 5e-6, (C, kind, k)
+                    assert torch.equal(a[k], a2[k]), "the one-launch synchronised pass is not reproducible: %s" % ((C, kind, k),)
 
 
 def _sync_timeout(rank, world):
@@ -295,14 +297,14 @@ def test_mailbox_exchange_over_hip_ipc_is_bit_identical_to_the_collectives():
 GRAD_BOUND, GRAD_FLOOR = 3.0, 5e-3        # the ONE gradient bound of tests/test_step_gpu.py (reason stated there)
 _B = 2
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-# variant -> environment of the step: D stream off / on in the default mode (SyncABN = the one-launch form with the exchange
-# inside the kernel); the deterministic mode (no atomics anywhere) with the SyncABN statistics through the IPC mailboxes in the
-# three-launch form, through torch.distributed, and in the one-launch form (twice: run-to-run bit equality)
+# variant -> environment of the step: D stream off / on in the default mode (channels-last student: SyncABN = the one-launch
+# form with the exchange inside the kernel), the same with the three-launch form; the deterministic mode (no atomics anywhere;
+# PyTorch's im2col convolutions return NCHW tensors, so the student's ABN layers take the NCHW kernels and exchange from Python)
+# with the statistics through the IPC mailboxes or through torch.distributed
 VARIANTS = {"d0": {"SKD_D_STREAM": "0"}, "d1": {"SKD_D_STREAM": "1"},
-            "det_ipc1": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "0"},
-            "det_ipc0": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "0"},
-            "det_fused": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "1"},
-            "det_fused_again": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1", "SKD_ABN_SYNC_FUSED": "1"}}
+            "d1_three": {"SKD_D_STREAM": "1", "SKD_ABN_SYNC_FUSED": "0"},
+            "det_ipc1": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "1"},
+            "det_ipc0": {"SKD_DETERMINISTIC": "1", "SKD_D_STREAM": "1", "SKD_SYNC_IPC": "0"}}
 
 
 def _generator():
@@ -494,34 +496,29 @@ def test_netmodel_ho_step_two_ranks_mailbox_equals_collectives_bit_for_bit():
     for r in range(2):
         a, b = runs["1"][r], runs["0"][r]
         assert a["ipc"] and not b["ipc"], "the two runs must differ in the transport of the SyncABN statistics"
+        assert a["forms"] == (0, 0), "deterministic mode: NCHW activations, the exchange is driven from Python (%s)" % (a["forms"],)
         assert a["losses"] == b["losses"], (r, a["losses"], b["losses"])
         for name in ("grads", "d_grads", "after", "d_after"):
             diff = [k for k in a[name] if not torch.equal(a[name][k], b[name][k])]
             assert not diff, "rank %d: %s differ between the mailbox and the collective exchange: %s" % (r, name, diff[:8])
 
 
-def test_netmodel_ho_step_two_ranks_one_launch_syncabn_is_deterministic_and_matches_three_launch():
-    """SKD_DETERMINISTIC=1, SyncABN in the ONE-launch form (exchange inside the register-resident kernels): two runs give the
-    same bits (losses, averaged gradients, parameters, running statistics), both replicas stay identical, and the step agrees
-    with the three-launch form to the rounding of the partial sums (the two forms cut a tensor into different per-thread
-    partial sums, so bit equality between them is not defined; between runs and between replicas it is)."""
-    a, b, three = _variant("det_fused"), _variant("det_fused_again"), _variant("det_ipc1")
+def test_netmodel_ho_step_two_ranks_one_launch_syncabn_matches_three_launch_form():
+    """The default-mode two-rank step with the student's SyncABN layers in the ONE-launch form (exchange inside the
+    register-resident kernels: what N > 1 runs by default) against the same step in the three-launch form: the forms really
+    differ (library counters), losses agree to 1e-5 (MIOpen's convolutions are not bit-reproducible run to run, so the
+    comparison cannot be tighter than two runs of either form), replicas stay identical."""
+    one, three = _variant("d1"), _variant("d1_three")
     for r in range(2):
         # 29 training ABN layers, forward + backward; the (B, C, 1, 1) pyramid stage is NCHW-contiguous and exchanges from Python
-        assert a[r]["forms"][0] >= 50 and three[r]["forms"][0] == 0 and three[r]["forms"][1] >= 50, (a[r]["forms"], three[r]["forms"])
-        assert a[r]["ipc"] and a[r]["losses"] == b[r]["losses"], (r, a[r]["losses"], b[r]["losses"])
-        for name in ("grads", "d_grads", "after", "d_after"):
-            diff = [k for k in a[r][name] if not torch.equal(a[r][name][k], b[r][name][k])]
-            assert not diff, "rank %d: %s differ between two deterministic runs of the one-launch SyncABN form: %s" % (r, name, diff[:8])
-        for k, v in a[r]["losses"].items():
-            assert abs(v - three[r]["losses"][k]) <= 2e-6 * abs(v), (r, k, v, three[r]["losses"][k])
-    for k in a[0]["after"]:
-        assert torch.equal(a[0]["after"][k], a[1]["after"][k]), "student replicas diverged: %s" % k
+        assert one[r]["forms"][0] >= 50 and one[r]["forms"][1] == 0, one[r]["forms"]
+        assert three[r]["forms"][0] == 0 and three[r]["forms"][1] >= 50, three[r]["forms"]
+        for k, v in one[r]["losses"].items():
+            assert abs(v - three[r]["losses"][k]) <= 1e-5 * abs(v), (r, k, v, three[r]["losses"][k])
+    for k in one[0]["after"]:
+        assert torch.equal(one[0]["after"][k], one[1]["after"][k]), "student replicas diverged: %s" % k
         if "running" in k:
-            assert rel(a[0]["after"][k], three[0]["after"][k]) < 1e-5, k
-    worst = max((rel(a[0]["grads"][k], three[0]["grads"][k]), k) for k in a[0]["grads"] if float(three[0]["grads"][k].norm()) > 1e-12)
-    print("one-launch vs three-launch SyncABN, deterministic mode: worst relative gradient difference", worst)
-    assert worst[0] < 5e-3      # (ill-conditioned pre-BN gradients amplify the 1e-7 differences of the statistics, SURVEY.md section 4)
+            assert rel(one[0]["after"][k], three[0]["after"][k]) < 1e-4, k
 
 
 def test_bench_under_torchrun_two_ranks_over_gloo():
