@@ -182,6 +182,29 @@ def build_cases(lib, torch, dev, st):
     econf, epred = torch.zeros(19, 19, dtype=torch.int64, device=dev), torch.empty(1, 1024, 2048, dtype=torch.uint8, device=dev)
     add("seg_confusion(1024x2048)", [1, 19, 129, 257, 1024, 2048], lambda:
         lib.skd_seg_confusion(1, 19, 129, 257, 1024, 2048, p(el), p(elab), 255, p(epred), p(econf), st), 9 * 1024 * 2048, keep=(el, elab, econf, epred))
+    # the frozen bottleneck's fused tail GEMM (csrc/conv1x1.hip) at the teacher's four problem shapes, in the round-4 super-tile
+    # order and in the round-3 panel-major order (SKD_GEMM_TILE_ORDER=0, read at every launch): the counter passes show what
+    # the order does to the L2 -> fabric traffic.  Algorithmic bytes: X (M x K) + W (N x K) + residual (M x N) read, Y (M x N) written.
+    for M_, K_, N_ in ((8 * 129 * 129, 64, 256), (8 * 65 * 65, 128, 512), (8 * 65 * 65, 256, 1024), (8 * 65 * 65, 512, 2048)):
+        X_, Wt_ = torch.randn(M_, K_, device=dev), torch.randn(N_, K_, device=dev) * 0.05
+        R_, Y_ = torch.randn(M_, N_, device=dev), torch.empty(M_, N_, device=dev)
+        mu, va, ga, be = torch.zeros(N_, device=dev), torch.ones(N_, device=dev), torch.ones(N_, device=dev), torch.zeros(N_, device=dev)
+        pm, pv = torch.zeros(K_, device=dev), torch.ones(K_, device=dev)
+        pack = torch.empty(4 * K_, device=dev)
+        assert lib.skd_abn_pack_eval_params(K_, p(pm), p(pv), None, None, 1e-5, p(pack), st)
+        keep = (X_, Wt_, R_, Y_, mu, va, ga, be, pm, pv, pack)
+
+        def gemm(order, M_=M_, K_=K_, N_=N_, X_=X_, Wt_=Wt_, R_=R_, Y_=Y_, mu=mu, va=va, ga=ga, be=be, pack=pack):
+            if order is None:
+                os.environ.pop("SKD_GEMM_TILE_ORDER", None)
+            else:
+                os.environ["SKD_GEMM_TILE_ORDER"] = order
+            r = lib.skd_conv1x1_abn_pro_nhwc(M_, K_, N_, p(X_), p(Wt_), p(R_), p(Y_), p(mu), p(va), p(ga), p(be), 1e-5, p(pack), 3, 0.0, st)
+            os.environ.pop("SKD_GEMM_TILE_ORDER", None)
+            return r
+        nbytes = 4 * (M_ * K_ + N_ * K_ + 2 * M_ * N_)
+        add("conv1x1_abn_pro(tail GEMM, super-tile order)", [M_, K_, N_], lambda gemm=gemm: gemm(None), nbytes, flops=2.0 * M_ * K_ * N_, keep=keep)
+        add("conv1x1_abn_pro(tail GEMM, panel-major order)", [M_, K_, N_], lambda gemm=gemm: gemm("0"), nbytes, flops=2.0 * M_ * K_ * N_)
     return cases
 
 
@@ -221,8 +244,12 @@ def main():
             row["GBs"] = round(c["algo_bytes"] / (ms * 1e-3) / 1e9, 1)
             row["frac_hbm_8TBs"] = round(row["GBs"] / 8000.0, 3)
         if c["algo_flops"]:
-            row["TFLOPs(full-matrix convention)"] = round(c["algo_flops"] / (ms * 1e-3) / 1e12, 2)
-            row["frac_fp32_mfma_157.3"] = round(row["TFLOPs(full-matrix convention)"] / 157.3, 4)
+            tf = round(c["algo_flops"] / (ms * 1e-3) / 1e12, 2)
+            if c["name"].startswith("pairwise"):      # symmetric Gram: only the upper-triangle tiles execute -- a convention, not a utilisation
+                row["TFLOPs(full-matrix convention)"] = tf
+            else:
+                row["TFLOPs"] = tf
+                row["frac_fp32_mfma_157.3"] = round(tf / 157.3, 4)
         print(json.dumps(row), flush=True)
     torch.cuda.synchronize()
 
