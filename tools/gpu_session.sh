@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session (gpurun): every section writes under gpurun_out/<tag>/ and is bounded by its own timeout.
 #   tools/gpu_session.sh <tag> <section> [<section> ...]
-# sections: tests_new | tests_all | smoke | bench | bench_prof | micro | micro_prof | pmc | conv | dist
+# sections: tests_new | tests_all | smoke | bench | bench_prof | micro | micro_prof | pmc | pmc2 | conv | dist | dist_ab | r4_ab | ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -182,6 +182,52 @@ EOF
     det)
       timeout 400 python tools/determinism_probe.py 8 > $O/determinism.jsonl 2> $O/determinism.err
       stamp "det rc=$?"; cut -c1-700 $O/determinism.jsonl | tee -a $O/session.log ;;
+    r4_ab)
+      # round 4 A/B on the default bench: teacher hipGraph, discriminator's spectral norms in 3 launches, GEMM super-tile order
+      for v in "SKD_TEACHER_GRAPH=1" "SKD_TEACHER_GRAPH=0" "SKD_SN_TOGETHER=0" "SKD_GEMM_TILE_ORDER=0"; do
+        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
+        stamp "r4_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+      done ;;
+    dist_ab)
+      # two ranks on ONE MI355X over gloo (what a 1-GPU box can show of N > 1): SyncABN exchange inside the one-launch kernels vs
+      # the three-launch form
+      for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=0"; do
+        (env $v SKD_DIST_BACKEND=gloo timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+          --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --batch 4 --no-cpu-baseline) > "$O/bench_2ranks_$(echo $v | tr ' =' '__').json" 2>> $O/bench_2ranks.err
+        stamp "dist_ab $v rc=$?"; cut -c1-300 "$O/bench_2ranks_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
+        python - "$O/bench_2ranks_$(echo $v | tr ' =' '__').json" <<'PYEOF' | tee -a $O/session.log
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
+    print("   comm:", json.dumps(d.get("comm")))
+except Exception as e:
+    print("   (no line)", e)
+PYEOF
+      done ;;
+    pmc2)
+      # counters in their own passes (no --stats / sys-trace next to --pmc): HBM bytes and the MFMA pipe, over the microbench
+      i=0
+      for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+        i=$((i+1))
+        (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o k -- \
+          python $R/tools/kernel_microbench.py pmc > $O/pmc$i.log 2>&1)
+        stamp "pmc2 pass $i ($set) rc=$?"
+        for f in $(find $O/pmc$i -name "*counter_collection.csv"); do
+          python - "$f" <<'PYEOF'
+import csv, sys
+f = sys.argv[1]
+rows = list(csv.DictReader(open(f, newline="")))
+keep = [r for r in rows if "skd::" in r["Kernel_Name"]]
+for r in keep:
+    r["Kernel_Name"] = r["Kernel_Name"][:200]
+w = csv.DictWriter(open(f, "w", newline=""), fieldnames=list(rows[0].keys()) if rows else [])
+w.writeheader(); w.writerows(keep)
+PYEOF
+        done
+        find $O/pmc$i -name "*kernel_trace.csv" -delete
+      done
+      python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 >> $O/session.log 2>&1
+      stamp "pmc2 summarised" ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err

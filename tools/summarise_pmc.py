@@ -98,6 +98,7 @@ def main():
         if c.get("algo_bytes") and have_f and have_w:
             c["hbm_bytes (2*FETCH_SIZE + WRITE_SIZE, all kernels of one call)"] = round(tot_fetch + tot_write)
             c["hbm_over_algorithmic"] = round((tot_fetch + tot_write) / c["algo_bytes"], 4)
+            c["hbm_read_MB"], c["hbm_write_MB"] = round(tot_fetch / 1e6, 2), round(tot_write / 1e6, 2)
             if have_x:
                 c["hbm_over_algorithmic (reads by request size)"] = round((tot_exact + tot_write) / c["algo_bytes"], 4)
     json.dump({"passes": [os.path.basename(os.path.normpath(d)) for d in dirs], "cases": list(cases.values())},
