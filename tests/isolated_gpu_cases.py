@@ -12,6 +12,15 @@ from structure_knowledge_distillation_amd.networks.kd_model import NetModel, def
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
+# a case that hangs says WHERE before its wrapper kills it: the Python stack of every thread goes to stderr shortly before the
+# wrapper's time limit (tests/test_step_gpu.py::_run_isolated passes the limit in SKD_ISOLATED_LIMIT_S)
+import faulthandler
+import sys
+
+_limit = float(os.environ.get("SKD_ISOLATED_LIMIT_S", "0"))
+if _limit > 30:
+    faulthandler.dump_traceback_later(_limit - 15, exit=False, file=sys.stderr)
+
 
 def rel(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
