@@ -205,6 +205,11 @@ def build_cases(lib, torch, dev, st):
         nbytes = 4 * (M_ * K_ + N_ * K_ + 2 * M_ * N_)
         add("conv1x1_abn_pro(tail GEMM, super-tile order)", [M_, K_, N_], lambda gemm=gemm: gemm(None), nbytes, flops=2.0 * M_ * K_ * N_, keep=keep)
         add("conv1x1_abn_pro(tail GEMM, panel-major order)", [M_, K_, N_], lambda gemm=gemm: gemm("0"), nbytes, flops=2.0 * M_ * K_ * N_)
+        # SKD_MICRO_TILE_ORDERS="ct,pm;ct,pm;..." : extra super-tile geometries on the wide problem (counter sweeps)
+        if N_ == 2048:
+            for order in [o for o in os.environ.get("SKD_MICRO_TILE_ORDERS", "").split(";") if o]:
+                add("conv1x1_abn_pro(tail GEMM, order %s)" % order, [M_, K_, N_], lambda gemm=gemm, order=order: gemm(order), nbytes,
+                    flops=2.0 * M_ * K_ * N_)
     return cases
 
 
