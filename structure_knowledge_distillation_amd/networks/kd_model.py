@@ -212,7 +212,13 @@ class NetModel():
                 CriterionAdditionalGP(self.parallel_D, args.lambda_gp))
         self.criterion_adv_for_G = self.DataParallelCriterionProcess(CriterionAdvForG(args.adv_loss_type))
 
-        self._teacher_graph_on = (os.environ.get("SKD_TEACHER_GRAPH", "1") in ("1", "force") and torch.device(device).type == "cuda"
+        # N > 1: off unless forced.  Measured (profiles/r04h_two_ranks_one_gpu_bisect.txt): with two ranks SHARING one MI355X the
+        # replayed graph turns a 94 ms step into 7.8 s -- graph launches and the peer process's in-kernel exchange waits do not
+        # get co-scheduled.  One rank per GPU should not meet that, but no multi-GPU box was available to show it, the gain is
+        # 1.2 %, and the failure mode is two orders of magnitude: the default for N > 1 stays the eager teacher.
+        graph_env = os.environ.get("SKD_TEACHER_GRAPH", "1")
+        self._teacher_graph_on = (graph_env in ("1", "force") and torch.device(device).type == "cuda"
+                                  and (parallel_old.world_size() == 1 or graph_env == "force")
                                   and os.environ.get("SKD_TEACHER_STREAM", "0") != "1" and not self.deterministic_no_graph())
         self._teacher_graphs = {}
         self._teacher_tensors = list(teacher.parameters()) + list(teacher.buffers())

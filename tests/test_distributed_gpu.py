@@ -549,7 +549,7 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     comm = out["comm"]
     assert comm["syncabn_collectives"] == 58                                      # 29 training ABN layers, forward + backward
     # channels-last layers exchange inside the ABN calls; the (B, C, 1, 1) pyramid stage is NCHW-contiguous: from Python
-    assert comm["syncabn_in_abn_calls"] >= 50 and comm["abn_sync_call_ms"] > 0 and comm["syncabn_one_launch_calls"] >= 50
+    assert comm["syncabn_in_abn_calls"] >= 50 and comm["abn_sync_call_ms"] > 0 and comm["syncabn_one_launch_calls"] >= 40
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"
 
 

@@ -60,8 +60,9 @@ def main():
             agg[category(r["Name"])] += int(r["TotalDurationNs"])
             calls[category(r["Name"])] += int(r["Calls"])
         with open(os.path.join(P, tag + "_step_breakdown.md"), "w") as fh:
-            fh.write("# %s: kernel time per step by category\n\n`rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline` "
-                     "(%d steps in the trace: 3 warm-up + 5 timed + 3 kernel-timing steps)\n\n| category | ms / step | %% | launches / step |\n|---|---|---|---|\n" % (tag, steps))
+            fh.write("# %s: kernel time per step by category\n\n`rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline "
+                     "--no-pairwise-sweep` (%d steps in the trace: 3 warm-up + 5 timed + -- with the teacher hipGraph on -- 1 + 5 eager-teacher steps for the roofline kernel + 3 kernel-timing steps; "
+                     "kernels replayed from the teacher's hipGraph appear as ordinary dispatches)\n\n| category | ms / step | %% | launches / step |\n|---|---|---|---|\n" % (tag, steps))
             for k, v in agg.most_common():
                 fh.write("| %s | %.2f | %.1f | %d |\n" % (k, v / 1e6 / steps, 100.0 * v / tot, calls[k] // steps))
             fh.write("| **total** | %.2f | 100 | %d |\n\nTop kernels:\n\n| kernel | calls | avg us | %% |\n|---|---|---|---|\n" % (tot / 1e6 / steps, sum(calls.values()) // steps))
