@@ -183,6 +183,59 @@ def test_sync_abn_one_launch_form_two_ranks_and_mixed_forms():
                     assert torch.equal(a[k], a2[k]), "the one-launch synchronised pass is not reproducible: %s" % ((C, kind, k),)
 
 
+def _sync_abn_world8(rank, world):
+    """Eight ranks -- BASELINE configs[3]'s world size -- on the real kernels: eight processes share the one MI355X (30 workgroups
+    of the grid-barrier launches each), the mailboxes hold eight writers' slots, every exchange waits for eight flag words per
+    channel block.  Forms: all one-launch, all three-launch, and alternating by rank."""
+    from structure_knowledge_distillation_amd import libs, _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dev = torch.device("cuda", 0)
+    mb = P.SyncMailbox.get(dist.group.WORLD, dev)
+    assert mb is not None and mb.lib.skd_sync_set_timeout(mb.ctx, 15.0)
+    out = {"cap": _lib.get().skd_abn_set_fused_max_workgroups(-1)}
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for C, hw in ((64, 17), (256, 9)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(world, C, hw, hw, generator=g) * 2 + 1
+        gz = torch.randn(world, C, hw, hw, generator=g)
+        for form in ("fused", "three", "mixed"):
+            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "three": "0", "mixed": "1" if rank % 2 == 0 else "0"}[form]
+            mod = libs.InPlaceABNSync(C, activation="leaky_relu").to(dev).train()
+            xs = x[rank:rank + 1].to(dev).requires_grad_(True)
+            z = mod(cl(xs * 1.0))
+            (z * gz[rank:rank + 1].to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            _lib.raise_on_device_errors()
+            out[(C, form)] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
+    os.environ.pop("SKD_ABN_SYNC_FUSED", None)
+    out["forms"] = _lib.sync_form_counts()
+    return out
+
+
+def test_sync_abn_eight_ranks_on_the_real_kernels():
+    from oracle import abn_torch
+    world = 8
+    outs = _run("_sync_abn_world8", world)
+    assert all(o["cap"] == outs[0]["cap"] and 4 <= o["cap"] <= 32 for o in outs), [o["cap"] for o in outs]
+    # 2 shapes x (forward + backward) = 4 calls per form: even ranks 8 one-launch + 4 three-launch, odd ranks 4 + 8
+    assert [o["forms"] for o in outs] == [(8, 4) if r % 2 == 0 else (4, 8) for r in range(world)]
+    for C, hw in ((64, 17), (256, 9)):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(world, C, hw, hw, generator=g) * 2 + 1
+        gz = torch.randn(world, C, hw, hw, generator=g)
+        xo = x.double().requires_grad_(True)
+        rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+        zo = abn_torch.abn_autograd(xo, torch.ones(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64), rm, rv, True, 0.1, 1e-5,
+                                    "leaky_relu", 0.01)
+        (zo * gz.double()).sum().backward()
+        for form in ("fused", "three", "mixed"):
+            for r in range(world):
+                o = outs[r][(C, form)]
+                assert rel(o["z"], zo[r:r + 1]) < 1e-5 and rel(o["dx"], xo.grad[r:r + 1]) < 1e-4, (C, form, r)
+                assert rel(o["rm"], rm) < 1e-5 and rel(o["rv"], rv) < 1e-5, (C, form, r)          # pooled n = 8 N S
+                assert torch.equal(o["rm"], outs[0][(C, form)]["rm"]) and torch.equal(o["rv"], outs[0][(C, form)]["rv"]), (C, form, r)
+
+
 def _sync_timeout(rank, world):
     """A peer that never arrives: the exchange gives up after the context's time limit, the statistics are NaN AND the device
     status word is raised -- _lib.raise_on_device_errors() turns it into an exception (no silent NaN)."""
