@@ -512,7 +512,8 @@ def test_netmodel_ho_step_two_ranks_vs_sharded_oracle(d_stream):
             pS, pT = outs[r]["logits"]
             loss, grads = O.discriminator_step(P, pS.to(dt), pT.to(dt), cfg, alpha[sl].to(dt))
             if name == "f64":
-                assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-5 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
+                # (north_star's 1e-4: the critic loss is a cancelling sum on real logits, tests/test_step_gpu.py has the numbers)
+                assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-4 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
             for k, g in grads.items():
                 if g is not None:
                     acc[k] = acc.get(k, 0.0) + g / 2

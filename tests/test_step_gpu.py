@@ -451,7 +451,12 @@ def test_full_step_b8_vs_golden():
         d_loss = cfg.lambda_d * O.criterion_adv(d_s, d_t) + cfg.lambda_d * O.criterion_gp(P, [pS_gpu.to(dt)], [pT_gpu.to(dt)], cfg.lambda_gp, alpha.to(dt))
         keys = O.learnable_keys(P)
         ref[name] = (float(d_loss), dict(zip(keys, torch.autograd.grad(d_loss, [P[k] for k in keys], allow_unused=True))))
-    assert abs(model.D_loss - ref["f64"][0]) <= 1e-5 * abs(ref["f64"][0]), (model.D_loss, ref["f64"][0])
+    # D LOSS tolerance = north_star's 1e-4.  On THESE logits the critic loss is a cancelling sum (-mean D(T) + mean D(S), the
+    # gradient penalty's (|grad| - 1)^2): the CPU fp32 oracle itself is 2.3e-5 off the fp64 one, the HIP path has landed anywhere in
+    # 0.4451488 ... 0.4451856 over twelve runs (1e-6 of run-to-run noise in the logits, amplified ~50 x), and two fp32 evaluations of
+    # the SAME logits (MIOpen vs im2col convolutions) have differed by 5.2e-5 (gpurun r04k).  On random logits every path agrees
+    # with fp64 to 1e-7 (tests/diagnostics/diag_d_loss_paths.py, profiles/r04l_d_loss_paths.txt): conditioning, not a kernel.
+    assert abs(model.D_loss - ref["f64"][0]) <= 1e-4 * abs(ref["f64"][0]), (model.D_loss, ref["f64"][0])
     _report("B=8 discriminator step on the GPU's own logits",
             [(k, float((gD[k].cpu().double() - g).norm()), float((ref["f32"][1][k].double() - g).norm()), float(g.norm()))
              for k, g in ref["f64"][1].items() if g is not None and float(g.norm()) > 1e-12], GRAD_BOUND, GRAD_FLOOR)
@@ -472,7 +477,7 @@ def test_full_step_b8_vs_golden():
             loss2.backward()
     finally:
         torch.use_deterministic_algorithms(False)
-    assert abs(float(loss2) - ref["f64"][0]) <= 1e-5 * abs(ref["f64"][0])
+    assert abs(float(loss2) - ref["f64"][0]) <= 1e-4 * abs(ref["f64"][0])          # see the tolerance note above
     g2 = {k: p.grad for k, p in D2.named_parameters() if p.grad is not None}
     _report("B=8 discriminator step, convolutions on the im2col + rocBLAS path",
             [(k, float((g2[k].cpu().double() - g).norm()), float((ref["f32"][1][k].double() - g).norm()), float(g.norm()))
