@@ -272,7 +272,7 @@ def _sync_timeout(rank, world):
 def test_exchange_timeout_raises_a_device_status_word_and_an_exception():
     outs = _run("_sync_timeout")
     o = outs[0]
-    assert not any(o["before"]) and o["nan"] and 0.9 < o["took"] < 2.9, o
+    assert not any(o["before"]) and o["nan"] and 0.9 < o["took"] < 6.0, o          # the 1 s limit, plus launch / sync latency of a busy host
     assert o["after"][0] != 0 and o["raised"] is not None and "timed out waiting for a peer" in o["raised"], o
     assert not any(o["cleared"]) and not any(outs[1]["before"])
 
