@@ -19,7 +19,7 @@ import sys
 
 _limit = float(os.environ.get("SKD_ISOLATED_LIMIT_S", "0"))
 if _limit > 30:
-    faulthandler.dump_traceback_later(_limit - 15, exit=False, file=sys.stderr)
+    faulthandler.dump_traceback_later(_limit - 12, exit=False, file=sys.stderr)
 
 
 def rel(a, b):
