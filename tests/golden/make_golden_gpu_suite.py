@@ -16,6 +16,7 @@ Sections (each pins what the named test used to compute live):
   networks_forward                test_networks_forward_vs_oracle          student (train) + teacher (eval), 161x129 input
   eval_full                       test_evaluate_main_full_size_student_on_gpu   1024x2048 student forward -> confusion matrix
   sharded2                        tests/test_distributed_gpu.py            two shards of B=2, Pi+Pa+Ho, sharded semantics
+  sharded8                        tests/test_distributed_gpu.py            EIGHT shards of one image, Pi+Pa+Ho (configs[3]'s world size)
 """
 import os
 import sys
@@ -37,6 +38,7 @@ SEEDS = {
     "networks_forward": {"student": 251, "teacher": 252, "x": 253},
     "eval_full": {"student": 261, "stats": 262, "data": 263},
     "sharded2": {"student": 271, "teacher": 272, "D": 273, "batch": 3, "alpha": 17},
+    "sharded8": {"student": 281, "teacher": 282, "D": 283, "batch": 13, "alpha": 27},
 }
 NUM_STEPS, POWER, LR_G, LR_D = 40000, 0.9, 1e-2, 4e-4                         # default_args() / train_options.py
 
@@ -223,7 +225,35 @@ def gen_sharded2():
             "d_uv": {k: v.clone() for k, v in PD64.items() if k.endswith(("weight_u", "weight_v"))}}
 
 
-SECTIONS = {"full_step_ho0": lambda: gen_full_step(False), "full_step_ho1": lambda: gen_full_step(True),
+def sharded8_inputs():
+    s = SEEDS["sharded8"]
+    x, y = O.synthetic_batch(8, 512, 512, seed=s["batch"])
+    alpha = torch.rand(8, 1, 1, 1, generator=torch.Generator().manual_seed(s["alpha"]))
+    return x, y, alpha, [slice(r, r + 1) for r in range(8)]
+
+
+def gen_sharded8():
+    """BASELINE configs[3]'s world size: eight shards of one image each, Pi + Pa + Ho, sharded semantics (utils/parallel.py:155,
+    libs/functions.py:185-209, sagan_models.py:148).  About 15 minutes on 8 cores."""
+    x, y, alpha, shards = sharded8_inputs()
+    cfg = O.StepConfig(weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
+    outs, after = {}, {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        PS, PT, PD = init_nets("sharded8", dt)
+        if name == "f64":
+            sums = {"student": checksum(PS), "teacher": checksum(PT), "D": checksum(PD)}
+        outs[name] = O.distillation_step_sharded(PS, PT, PD, x.to(dt), y, cfg, shards, [alpha[sl].to(dt) for sl in shards])
+        after[name] = (PS, PD)
+    o64, o32 = outs["f64"], outs["f32"]
+    PS64, PD64 = after["f64"]
+    return {"cfg": {"weight_decay": 5e-4, "lambda_pa": 0.5}, "checksums": sums, "shard_losses": o64["shards"],
+            "grads_S": {k: rec(g, o32["grads_S"][k]) for k, g in o64["grads_S"].items() if g is not None},
+            "grads_D": {k: rec(g, o32["grads_D"][k]) for k, g in o64["grads_D"].items() if g is not None},
+            "running": {k: rec(v) for k, v in PS64.items() if "running" in k},
+            "d_uv": {k: v.clone() for k, v in PD64.items() if k.endswith(("weight_u", "weight_v"))}}
+
+
+SECTIONS = {"sharded8": gen_sharded8, "full_step_ho0": lambda: gen_full_step(False), "full_step_ho1": lambda: gen_full_step(True),
             "config1_pa": lambda: gen_config1(True), "config1_pi": lambda: gen_config1(False),
             "networks_forward": gen_networks_forward, "eval_full": gen_eval_full, "sharded2": gen_sharded2}
 

@@ -577,6 +577,73 @@ def test_netmodel_ho_step_two_ranks_one_launch_syncabn_matches_three_launch_form
             assert rel(one[0]["after"][k], three[0]["after"][k]) < 1e-4, k
 
 
+def _netmodel_step_world8(rank, world):
+    """One Pi + Pa + Ho step of BASELINE configs[3]'s world size -- EIGHT ranks, one image each -- on the real kernels (the eight
+    processes share the one MI355X; SyncMailbox caps every rank's grid-barrier launches at its share of the compute units)."""
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    from structure_knowledge_distillation_amd import _lib as L
+    torch.set_num_threads(2)
+    gen = _generator()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(30 + rank)
+    model = NetModel(default_args(batch_size=world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
+    assert not model._teacher_graph_on          # N > 1: eager teacher (DESIGN.md section 9.4)
+    for m in model.student.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    PS, PT, PD = gen.init_nets("sharded8")
+    model.student.load_state_dict(PS); model.teacher.load_state_dict(PT); model.D_model.load_state_dict(PD)
+    x, y, alpha, shards = gen.sharded8_inputs()
+    sl = shards[rank]
+    forms0 = L.sync_form_counts()
+    model.gp_alpha = alpha[sl].to(dev)
+    model.set_input((x[sl], y[sl], None, None))
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    L.raise_on_device_errors()
+    forms1 = L.sync_form_counts()
+    keep = lambda d: {k: v for k, v in d.items()} if rank == 0 else {k: v for k, v in list(d.items())[:6] + list(d.items())[-6:]}
+    return {"losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")},
+            "forms": (forms1[0] - forms0[0], forms1[1] - forms0[1]),
+            "grads": keep({k: p.grad.detach().cpu() for k, p in model.student.named_parameters()}),
+            "d_grads": keep({k: p.grad.detach().cpu() for k, p in model.D_model.named_parameters() if p.grad is not None}),
+            "running": keep({k: v.detach().cpu() for k, v in model.student.state_dict().items() if "running" in k}),
+            "d_uv": {k: v.detach().cpu() for k, v in model.D_model.state_dict().items() if k.endswith(("weight_u", "weight_v"))}}
+
+
+def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
+    """configs[3]'s world size on the real kernels: per-shard losses against the recorded 8-shard fp64 oracle
+    (tests/golden/gpu_suite_oracle.pt["sharded8"]), averaged student / discriminator gradients identical on all eight ranks and
+    within the ONE bound, running statistics pooled over 8 x N x S samples, u / v identical everywhere."""
+    world = 8
+    outs = _run("_netmodel_step_world8", world)
+    fx = torch.load(os.path.join(GOLDEN_DIR, "gpu_suite_oracle.pt"), weights_only=False)["sharded8"]
+    gen = _generator()
+    PS, PT, PD = gen.init_nets("sharded8")
+    for name, P in (("student", PS), ("teacher", PT), ("D", PD)):
+        for k, v in gen.checksum(P).items():
+            assert abs(v - fx["checksums"][name][k]) <= 1e-9 * max(1.0, abs(v)), ("weight RNG drifted", name, k)
+    for r in range(world):
+        for k, ref in fx["shard_losses"][r].items():
+            got = outs[r]["losses"][k]
+            assert abs(got - ref) <= 1e-4 * abs(ref), (r, k, got, ref)
+        assert outs[r]["forms"][0] + outs[r]["forms"][1] == 56, outs[r]["forms"]      # every channels-last layer through the one-call entries
+    print("world 8: synchronised ABN calls per rank (one launch, three launches):", outs[0]["forms"])
+    for r in range(1, world):
+        for name in ("grads", "d_grads", "running", "d_uv"):
+            for k, v in outs[r][name].items():
+                assert torch.equal(v, outs[0][name][k]), "rank %d differs from rank 0 in %s[%s]" % (r, name, k)
+    rows = [(k, _rec_err(outs[0]["grads"][k], rec)[0], rec["base"], rec["norm"]) for k, rec in fx["grads_S"].items()]
+    _bound_report("world 8 student gradients (averaged over 8 ranks)", rows, GRAD_BOUND, GRAD_FLOOR)
+    rows = [(k, _rec_err(outs[0]["d_grads"][k], rec)[0], rec["base"], rec["norm"]) for k, rec in fx["grads_D"].items() if rec["norm"] > 1e-12]
+    _bound_report("world 8 discriminator gradients end to end", rows, 10.0, 2e-2)
+    for k, rec in fx["running"].items():
+        err, _ = _rec_err(outs[0]["running"][k], rec)
+        assert err <= 1e-4 * rec["norm"] + 1e-9, k
+    for k, v in fx["d_uv"].items():
+        assert rel(outs[0]["d_uv"][k], v) < 1e-4, k
+
+
 def test_bench_under_torchrun_two_ranks_over_gloo():
     """The exact command line the driver uses for its multi-GPU runs (python -m torch.distributed.run ... bench.py
     --gpus N), with two ranks sharing cuda:0 over gloo (SKD_DIST_BACKEND): rendezvous, replica broadcast, SyncABN
