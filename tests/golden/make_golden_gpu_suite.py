@@ -16,7 +16,7 @@ Sections (each pins what the named test used to compute live):
   networks_forward                test_networks_forward_vs_oracle          student (train) + teacher (eval), 161x129 input
   eval_full                       test_evaluate_main_full_size_student_on_gpu   1024x2048 student forward -> confusion matrix
   sharded2                        tests/test_distributed_gpu.py            two shards of B=2, Pi+Pa+Ho, sharded semantics
-  sharded8                        tests/test_distributed_gpu.py            EIGHT shards of one image, Pi+Pa+Ho (configs[3]'s world size)
+  sharded8                        tests/test_distributed_gpu.py            EIGHT shards of two images, Pi+Pa+Ho (configs[3]'s world size)
 """
 import os
 import sys
@@ -227,14 +227,16 @@ def gen_sharded2():
 
 def sharded8_inputs():
     s = SEEDS["sharded8"]
-    x, y = O.synthetic_batch(8, 512, 512, seed=s["batch"])
-    alpha = torch.rand(8, 1, 1, 1, generator=torch.Generator().manual_seed(s["alpha"]))
-    return x, y, alpha, [slice(r, r + 1) for r in range(8)]
+    # two images per shard: batch 2 (and 8) are the batch sizes the shipped MIOpen find-db was tuned for -- with one image per rank
+    # every rank JIT-compiles ~50 untuned convolution kernels first (measured: 105 s for the test instead of ~30)
+    x, y = O.synthetic_batch(16, 512, 512, seed=s["batch"])
+    alpha = torch.rand(16, 1, 1, 1, generator=torch.Generator().manual_seed(s["alpha"]))
+    return x, y, alpha, [slice(2 * r, 2 * r + 2) for r in range(8)]
 
 
 def gen_sharded8():
-    """BASELINE configs[3]'s world size: eight shards of one image each, Pi + Pa + Ho, sharded semantics (utils/parallel.py:155,
-    libs/functions.py:185-209, sagan_models.py:148).  About 15 minutes on 8 cores."""
+    """BASELINE configs[3]'s world size: eight shards of two images each (global batch 16), Pi + Pa + Ho, sharded semantics
+    (utils/parallel.py:155, libs/functions.py:185-209, sagan_models.py:148).  A few minutes on 8 cores, ~45 GB of host memory (fp64)."""
     x, y, alpha, shards = sharded8_inputs()
     cfg = O.StepConfig(weight_decay=5e-4, lambda_pa=0.5, dropout_p=0.0)
     outs, after = {}, {}

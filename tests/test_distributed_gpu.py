@@ -578,7 +578,7 @@ def test_netmodel_ho_step_two_ranks_one_launch_syncabn_matches_three_launch_form
 
 
 def _netmodel_step_world8(rank, world):
-    """One Pi + Pa + Ho step of BASELINE configs[3]'s world size -- EIGHT ranks, one image each -- on the real kernels (the eight
+    """One Pi + Pa + Ho step of BASELINE configs[3]'s world size -- EIGHT ranks, two images each -- on the real kernels (the eight
     processes share the one MI355X; SyncMailbox caps every rank's grid-barrier launches at its share of the compute units)."""
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     from structure_knowledge_distillation_amd import _lib as L
@@ -586,7 +586,7 @@ def _netmodel_step_world8(rank, world):
     gen = _generator()
     dev = torch.device("cuda", 0)
     torch.manual_seed(30 + rank)
-    model = NetModel(default_args(batch_size=world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
+    model = NetModel(default_args(batch_size=_B * world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
     assert not model._teacher_graph_on          # N > 1: eager teacher
     for m in model.student.modules():
         if isinstance(m, torch.nn.Dropout2d):
@@ -605,6 +605,7 @@ def _netmodel_step_world8(rank, world):
     keep = lambda d: {k: v for k, v in d.items()} if rank == 0 else {k: v for k, v in list(d.items())[:6] + list(d.items())[-6:]}
     return {"losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")},
             "forms": (forms1[0] - forms0[0], forms1[1] - forms0[1]),
+            "logits": (model.preds_S[0].detach().cpu(), model.preds_T[0].detach().cpu()),
             "grads": keep({k: p.grad.detach().cpu() for k, p in model.student.named_parameters()}),
             "d_grads": keep({k: p.grad.detach().cpu() for k, p in model.D_model.named_parameters() if p.grad is not None}),
             "running": keep({k: v.detach().cpu() for k, v in model.student.state_dict().items() if "running" in k}),
@@ -623,10 +624,18 @@ def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
     for name, P in (("student", PS), ("teacher", PT), ("D", PD)):
         for k, v in gen.checksum(P).items():
             assert abs(v - fx["checksums"][name][k]) <= 1e-9 * max(1.0, abs(v)), ("weight RNG drifted", name, k)
+    from oracle import step_torch as O
+    x, y, alpha, shards = gen.sharded8_inputs()
+    cfg = O.StepConfig(weight_decay=fx["cfg"]["weight_decay"], lambda_pa=fx["cfg"]["lambda_pa"], dropout_p=0.0)
     for r in range(world):
         for k, ref in fx["shard_losses"][r].items():
             got = outs[r]["losses"][k]
-            assert abs(got - ref) <= 1e-4 * abs(ref), (r, k, got, ref)
+            # the critic loss is a cancelling sum that amplifies the 1e-6 run-to-run noise of the logits ~50 x (tests/test_step_gpu.py has
+            # the numbers): end to end it is held to 1e-3 here and to north_star's 1e-4 against the oracle's D step on the rank's OWN logits
+            assert abs(got - ref) <= (1e-3 if k == "D_loss" else 1e-4) * abs(ref), (r, k, got, ref)
+        P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in PD.items()}
+        loss, _ = O.discriminator_step(P, outs[r]["logits"][0].double(), outs[r]["logits"][1].double(), cfg, alpha[shards[r]].double())
+        assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-4 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
         assert outs[r]["forms"][0] + outs[r]["forms"][1] == 56, outs[r]["forms"]      # every channels-last layer through the one-call entries
     print("world 8: synchronised ABN calls per rank (one launch, three launches):", outs[0]["forms"])
     for r in range(1, world):
