@@ -636,7 +636,8 @@ def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
         P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in PD.items()}
         loss, _ = O.discriminator_step(P, outs[r]["logits"][0].double(), outs[r]["logits"][1].double(), cfg, alpha[shards[r]].double())
         assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-4 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
-        assert outs[r]["forms"][0] + outs[r]["forms"][1] == 56, outs[r]["forms"]      # every channels-last layer through the one-call entries
+        if os.environ.get("SKD_SYNC_IPC", "1") == "1":
+            assert outs[r]["forms"][0] + outs[r]["forms"][1] == 56, outs[r]["forms"]      # every channels-last layer through the one-call entries
     print("world 8: synchronised ABN calls per rank (one launch, three launches):", outs[0]["forms"])
     for r in range(1, world):
         for name in ("grads", "d_grads", "running", "d_uv"):
