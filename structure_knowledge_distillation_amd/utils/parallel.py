@@ -24,7 +24,7 @@ import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
            "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
-           "clear_replica_batch", "replica_weights", "SyncMailbox"]
+           "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity"]
 
 
 def init_distributed(backend=None):
@@ -62,6 +62,21 @@ def share_device(ranks_per_device):
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     # a little under the even share: the other streams of a rank (D step) and the exchange kernels need slots too
     return _lib.get().skd_abn_set_fused_max_workgroups(max(4, (cus - 16) // ranks_per_device))
+
+
+def device_identity(props, index):
+    """A string that is equal for two ranks of one host exactly when they sit on the SAME physical GPU: the PCI address (domain :
+    bus : device) and the runtime's UUID when it reports a non-zero one; the device index only when neither is available (ranks
+    that mask devices with HIP_VISIBLE_DEVICES all call theirs 0).  A wrong "shared" verdict is not an error but costs throughput:
+    every rank's grid-barrier launches would be capped at 1 / N of the compute units (share_device)."""
+    parts = []
+    pci = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(isinstance(v, int) for v in pci) and (pci[1] or pci[2] or pci[0]):
+        parts.append("pci %04x:%02x:%02x" % tuple(pci))
+    uuid = str(getattr(props, "uuid", "") or "")
+    if uuid.strip("0-").strip():                       # an all-zero UUID (older runtimes) identifies nothing
+        parts.append("uuid " + uuid)
+    return " ".join(parts) if parts else "index %d" % (index or 0)
 
 
 def world_size(group=None):
@@ -187,8 +202,7 @@ class SyncMailbox:
             ctx = lib.skd_sync_create(w, rk, ctypes.cast(buf, ctypes.c_void_p))
         dev_id = None
         if on_gpu:
-            props = torch.cuda.get_device_properties(torch.device(device))
-            dev_id = str(getattr(props, "uuid", "")) or "index %d" % torch.device(device).index
+            dev_id = device_identity(torch.cuda.get_device_properties(torch.device(device)), torch.device(device).index)
         mine = (bytes(buf.raw) if ctx else None, socket.gethostname(), dev_id)
         everyone = [None] * w
         dist.all_gather_object(everyone, mine, group=group)

@@ -562,3 +562,23 @@ def test_teacher_dsn_head_is_optional_and_everything_else_unchanged(monkeypatch)
     model.set_input((x, y, None, None))
     model.optimize_parameters()
     assert model.preds_T[1] is not None and model.mc_T_loss > 0
+
+
+def test_device_identity_tells_physical_gpus_apart():
+    """utils.parallel.device_identity: what SyncMailbox uses to count the ranks that share ITS device (their grid-barrier launches
+    are capped at 1 / N of the compute units).  Eight ranks on eight GPUs must never look like eight ranks on one -- whether or not
+    the runtime reports a UUID, whether or not the ranks mask their devices (every masked rank calls its GPU index 0)."""
+    from structure_knowledge_distillation_amd.utils.parallel import device_identity
+
+    class Props:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    zero = "00000000-0000-0000-0000-000000000000"
+    gpus = [Props(pci_domain_id=0, pci_bus_id=0x05 + 0x10 * i, pci_device_id=0, uuid=zero) for i in range(8)]
+    assert len({device_identity(p, 0) for p in gpus}) == 8                  # masked ranks, all-zero UUIDs: the PCI address decides
+    assert device_identity(gpus[3], 0) == device_identity(gpus[3], 0)      # two ranks on ONE device agree
+    with_uuid = [Props(uuid="58f3e8c2-%04d-0000-0000-000000000000" % i) for i in range(2)]
+    assert device_identity(with_uuid[0], 0) != device_identity(with_uuid[1], 0)
+    bare = Props()
+    assert device_identity(bare, 2) == "index 2" and device_identity(bare, 2) != device_identity(bare, 3)
