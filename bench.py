@@ -245,6 +245,7 @@ def main():
     # a benchmark run must fail fast: an exchange that waits for a peer longer than this poisons its outputs and raises
     # SkdDeviceError at the next step (training keeps the library's 600 s, what torch.distributed would have waited)
     os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "120")
+    os.environ.setdefault("SKD_DIST_TIMEOUT_S", "300")       # torch.distributed collectives: same idea (utils/parallel.init_distributed)
     rank, world, local = P.init_distributed()
     if world != a.gpus:
         if world == 1 and a.gpus > 1:

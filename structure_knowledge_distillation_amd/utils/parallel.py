@@ -48,6 +48,11 @@ def init_distributed(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        if os.environ.get("SKD_DIST_TIMEOUT_S"):
+            # how long a collective waits for a peer before the job is torn down (torch's defaults: 10 min RCCL, 30 min gloo);
+            # bench.py asks for 5 min: a rank that died must fail the measurement, not park seven GPUs until somebody notices
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SKD_DIST_TIMEOUT_S"]))
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
     return rk, ws, local
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session (gpurun): every section writes under gpurun_out/<tag>/ and is bounded by its own timeout.
 #   tools/gpu_session.sh <tag> <section> [<section> ...]
-# sections: tests_new | tests_all | smoke | bench | bench_prof | micro | micro_prof | pmc | pmc2 | conv | dist | dist_ab | r4_ab | ...
+# sections: tests_new | tests_all | world8 | smoke | bench | bench_prof | micro | micro_prof | pmc | pmc2 | conv | dist | dist_ab | r4_ab | ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -19,6 +19,11 @@ for sec in "$@"; do
       timeout 1500 python -m pytest tests -m gpu -q --tb=short -s --durations=12 > $O/pytest_gpu.log 2>&1
       stamp "tests_all rc=$?"; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 | tee -a $O/session.log
       grep -E "worst|B=8 |config1 " $O/pytest_gpu.log | tee -a $O/session.log ;;
+    world8)
+      # the two eight-rank tests alone, the whole-step one WITHOUT its non-strict xfail marker (round 4 ended before its re-seeded
+      # checks (3)-(5) ran on hardware; drop the marker in tests/test_distributed_gpu.py once this section is green)
+      timeout 300 python -m pytest tests/test_distributed_gpu.py -m gpu -q --tb=short -s --runxfail --durations=3 -k "eight_ranks" > $O/world8.log 2>&1
+      stamp "world8 rc=$?"; grep -E "passed|failed|error|world 8" $O/world8.log | grep -v Gloo | tail -12 | tee -a $O/session.log ;;
     smoke)
       (timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1
       stamp "smoke rc=$?"; tail -7 $O/smoke.log | tee -a $O/session.log ;;
