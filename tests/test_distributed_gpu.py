@@ -580,7 +580,7 @@ def test_netmodel_ho_step_two_ranks_one_launch_syncabn_matches_three_launch_form
             assert rel(one[0]["after"][k], three[0]["after"][k]) < 1e-4, k
 
 
-def _netmodel_step_world8(rank, world):
+def _netmodel_step_world8(rank, world, dev=None):
     """BASELINE configs[3]'s world size -- EIGHT ranks, two images each -- on the real kernels (the eight processes share the one
     MI355X; SyncMailbox caps every rank's grid-barrier launches at its share of the compute units).  Two steps from the same
     weights and inputs: Pi + Pa + Ho (with the gradient that reaches the student's logits recorded by a tensor hook), then
@@ -591,7 +591,8 @@ def _netmodel_step_world8(rank, world):
     PC = importlib.import_module("structure_knowledge_distillation_amd.networks.pspnet_combine")
     torch.set_num_threads(2)
     gen = _generator()
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", 0) if dev is None else dev      # (tests/diagnostics/diag_world8_cpu_fixture.py runs this on the CPU double)
+    on_gpu = dev.type == "cuda"
     x, y, alpha, shards = gen.sharded8_inputs()
     sl = shards[rank]
     PS, PT, PD = gen.init_nets("sharded8")
@@ -624,8 +625,9 @@ def _netmodel_step_world8(rank, world):
             model.optimize_parameters()
         finally:
             PC.ResNet.forward = plain_forward
-        torch.cuda.synchronize()
-        L.raise_on_device_errors()
+        if on_gpu:
+            torch.cuda.synchronize()
+            L.raise_on_device_errors()
         forms1 = L.sync_form_counts()
         o = {"losses": {k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss") + (("D_loss",) if ho else ())},
              "forms": (forms1[0] - forms0[0], forms1[1] - forms0[1]),
@@ -638,7 +640,8 @@ def _netmodel_step_world8(rank, world):
             o["d_uv"] = {k: v.detach().cpu() for k, v in model.D_model.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
         out[name] = o
         del model
-        torch.cuda.empty_cache()
+        if on_gpu:
+            torch.cuda.empty_cache()
         dist.barrier()
     return out
 
@@ -664,8 +667,13 @@ def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
     against record (smooth part) + fp64 critic on the rank's own logits -- the tight statement about the Ho gradient;  (3) the D
     step on the ranks' own logits under the ONE bound;  (4) every averaged student gradient of the Pi + Pa step (smooth criteria)
     under the ONE bound;  (5) the Ho step's end-to-end gradients to a 10 % bound (a rank missing from the average is 12 %)."""
+    _check_world8(_run("_netmodel_step_world8", 8), on_gpu=True)
+
+
+def _check_world8(both, on_gpu=True):
+    """The assertions of test_netmodel_ho_step_eight_ranks_vs_sharded_oracle on the eight ranks' outputs (also driven from
+    tests/diagnostics/diag_world8_cpu_fixture.py with the C-ABI double on the CPU: same fixture, same checks, no HIP kernels)."""
     world = 8
-    both = _run("_netmodel_step_world8", world)
     outs, outs_pa = [o["ho"] for o in both], [o["pa"] for o in both]
     fx = torch.load(os.path.join(GOLDEN_DIR, "gpu_suite_oracle.pt"), weights_only=False)["sharded8"]
     gen = _generator()
@@ -676,7 +684,7 @@ def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
     from oracle import step_torch as O
     x, y, alpha, shards = gen.sharded8_inputs()
     cfg = O.StepConfig(weight_decay=fx["cfg"]["weight_decay"], lambda_pa=fx["cfg"]["lambda_pa"], dropout_p=0.0)
-    ipc = os.environ.get("SKD_SYNC_IPC", "1") == "1"
+    ipc = on_gpu and os.environ.get("SKD_SYNC_IPC", "1") == "1"
     # (1) + (2): per shard
     worst_dl = 0.0
     for r in range(world):
