@@ -824,14 +824,15 @@ def _run_nccl(fn_name, world):
         return [torch.load(os.path.join(d, "r%d.pt" % r)) for r in range(world)]
 
 
-def _multi_gpu_plumbing(rank, world):
+def _multi_gpu_plumbing(rank, world, dev=None):
     import importlib
     IA = importlib.import_module("structure_knowledge_distillation_amd.libs.inplace_abn")
     from structure_knowledge_distillation_amd import libs, _lib
     from structure_knowledge_distillation_amd.utils import parallel as P
-    dev = torch.device("cuda", rank)
+    dev = torch.device("cuda", rank) if dev is None else dev      # (tests/diagnostics/diag_multi_gpu_cpu_rehearsal.py: the CPU double)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
     lib, group = _lib.get(), dist.group.WORLD
-    st = torch.cuda.current_stream(dev).cuda_stream
+    st = _lib.stream_of(torch.empty(1, device=dev))
     out = {}
     # (1) the mailboxes across devices, against RCCL's own collectives on the same data
     res = {}
@@ -846,7 +847,7 @@ def _multi_gpu_plumbing(rank, world):
         mean, var = IA._sync_stats(stat.clone(), C, 7, group, rm, rv, 0.1, lib, st)
         gstat = torch.randn(2, C, generator=torch.Generator().manual_seed(7000 + rank)).to(dev)
         IA._sync_grad_stats(gstat, group)
-        torch.cuda.synchronize()
+        sync()
         res[mode] = [t.cpu() for t in (mean, var, rm, rv, gstat)]
     out["stats"] = res
     os.environ["SKD_SYNC_IPC"] = "1"
@@ -862,7 +863,7 @@ def _multi_gpu_plumbing(rank, world):
     xs = x[sl].to(dev).requires_grad_(True)
     z = mod(cl(xs * 1.0))
     (z * gz[sl].to(dev)).sum().backward()
-    torch.cuda.synchronize()
+    sync()
     out["abn"] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
     out["cap"] = lib.skd_abn_set_fused_max_workgroups(-1)
     # (3) bucketed gradient averaging over RCCL
@@ -871,7 +872,7 @@ def _multi_gpu_plumbing(rank, world):
     red.arm()
     sum((i + 1) * (rank + 1) * p.sum() for i, p in enumerate(params)).backward()
     red.finish()
-    torch.cuda.synchronize()
+    sync()
     out["avg"] = [float(p.grad[0]) for p in params]
     out["status"] = _lib.device_status()
     return out
@@ -879,12 +880,15 @@ def _multi_gpu_plumbing(rank, world):
 
 @pytest.mark.skipif(_ngpus() < 2, reason="needs at least two GPUs (RCCL + cross-device HIP IPC)")
 def test_multi_gpu_rccl_and_cross_device_mailboxes():
-    from oracle import abn_torch
     world = min(_ngpus(), 8)
-    outs = _run_nccl("_multi_gpu_plumbing", world)
+    _check_multi_gpu_plumbing(_run_nccl("_multi_gpu_plumbing", world), world, min(256, torch.cuda.get_device_properties(0).multi_processor_count))
+
+
+def _check_multi_gpu_plumbing(outs, world, cap):
+    from oracle import abn_torch
     for o in outs:
         assert o["mailbox_1"] and not o["mailbox_0"], "cross-device IPC mailboxes could not be set up"
-        assert not any(o["status"]) and o["cap"] == min(256, torch.cuda.get_device_properties(0).multi_processor_count)
+        assert not any(o["status"]) and o["cap"] == cap, (o["status"], o["cap"], cap)      # one rank per device: no share of the compute units
         for a, b in zip(o["stats"]["1"], o["stats"]["0"]):
             assert rel(a, b) < 1e-6                      # RCCL's ring order vs the mailboxes' rank order: rounding only
         for a, b in zip(o["stats"]["1"], outs[0]["stats"]["1"]):
@@ -907,10 +911,10 @@ def test_multi_gpu_rccl_and_cross_device_mailboxes():
         assert torch.equal(o["abn"]["rm"], outs[0]["abn"]["rm"])
 
 
-def _multi_gpu_step(rank, world):
+def _multi_gpu_step(rank, world, dev=None):
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     from oracle import step_torch as O
-    dev = torch.device("cuda", rank)
+    dev = torch.device("cuda", rank) if dev is None else dev
     torch.manual_seed(10 + rank)
     model = NetModel(default_args(batch_size=_B * world, ho=True, device=dev, weight_decay=5e-4, lambda_pa=0.5))
     for m in model.student.modules():
@@ -932,7 +936,8 @@ def _multi_gpu_step(rank, world):
         model.set_input((x[sl], y[sl], None, None))
         model.optimize_parameters()
         losses.append({k: getattr(model, k) for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss", "D_loss")})
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     from structure_knowledge_distillation_amd import _lib
     return {"losses": losses, "after": _snap(model.student), "d_after": _snap(model.D_model), "status": _lib.device_status(),
             "grads": {k: p.grad.detach().cpu() for k, p in list(model.student.named_parameters())[:8]}}
@@ -943,7 +948,10 @@ def test_multi_gpu_netmodel_steps_over_rccl():
     """Two full Pi + Pa + Ho steps, one rank per GPU over RCCL: replicas stay bit-identical (student, discriminator incl. u / v),
     no in-kernel wait times out; with exactly two GPUs the first step's per-shard losses meet the recorded sharded oracle."""
     world = min(_ngpus(), 8)
-    outs = _run_nccl("_multi_gpu_step", world)
+    _check_multi_gpu_step(_run_nccl("_multi_gpu_step", world), world)
+
+
+def _check_multi_gpu_step(outs, world):
     for o in outs:
         assert not any(o["status"])
         assert all(v == v and abs(v) < 1e6 for step in o["losses"] for v in step.values())
