@@ -24,7 +24,7 @@ import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
            "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
-           "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity"]
+           "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity", "reserve_for_collectives", "reserved_fused_cap"]
 
 
 def init_distributed(backend=None):
@@ -48,12 +48,18 @@ def init_distributed(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+            # every RCCL channel is one resident workgroup on (usually) its own compute unit for the length of a collective; the
+            # reserve that reserve_for_collectives() keeps out of the grid-barrier launches is sized for at most this many (65 MB of
+            # gradients per step do not need more; the user's own setting wins)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if os.environ.get("SKD_DIST_TIMEOUT_S"):
             # how long a collective waits for a peer before the job is torn down (torch's defaults: 10 min RCCL, 30 min gloo);
             # bench.py asks for 5 min: a rank that died must fail the measurement, not park seven GPUs until somebody notices
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SKD_DIST_TIMEOUT_S"]))
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
+        if backend == "nccl" and torch.cuda.is_available() and int(os.environ.get("LOCAL_WORLD_SIZE", ws)) <= max(1, torch.cuda.device_count()):
+            reserve_for_collectives()          # one rank per device over RCCL: its kernels must always find a compute unit
     return rk, ws, local
 
 
@@ -67,6 +73,34 @@ def share_device(ranks_per_device):
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     # a little under the even share: the other streams of a rank (D step) and the exchange kernels need slots too
     return _lib.get().skd_abn_set_fused_max_workgroups(max(4, (cus - 16) // ranks_per_device))
+
+
+def reserved_fused_cap(cus, reserve=None):
+    """Workgroups a grid-barrier launch may use when RCCL's kernels run beside the step: the device's compute units minus a reserve
+    (SKD_ABN_RCCL_RESERVE_CUS, default 64)."""
+    if reserve is None:
+        reserve = int(os.environ.get("SKD_ABN_RCCL_RESERVE_CUS", "64"))
+    return max(4, min(256, int(cus)) - max(0, reserve))
+
+
+def reserve_for_collectives(device=None):
+    """Keep compute units OUT of the one-launch InPlace-ABN passes when the process group's collectives are GPU kernels (RCCL).
+
+    The gradient buckets are all-reduced WHILE backward continues, so an RCCL kernel and a one-launch ABN pass meet on the chip.
+    The ABN pass holds a grid barrier -- every workgroup resident until the last one has arrived, one 1024-thread workgroup with
+    up to the whole register file of its compute unit (`-Rpass-analysis=kernel-resource-usage`: 128 VGPRs x 4 waves per SIMD) --
+    and, synchronised, waits INSIDE that barrier for the peer rank's pass.  With the grid at one workgroup per compute unit that
+    closes a cycle across two ranks whose hardware queues picked the two kernels in opposite order: A's ABN pass waits for B's; B's
+    cannot become resident because B's RCCL kernel holds compute units; B's RCCL kernel waits for A's RCCL kernel; A's RCCL
+    kernel finds no compute unit because A's ABN pass spins on all of them.  (Nothing on a one-GPU box shows this: gloo's
+    all-reduce runs on the host.)  With a reserve the collective can always start on every rank, finishes, and frees what the ABN
+    pass is waiting for: the cycle cannot close; the price is a quarter of the ABN passes' parallelism (2.4 -> ~3 ms per step)."""
+    if not torch.cuda.is_available():
+        return None
+    from .. import _lib
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    return _lib.get().skd_abn_set_fused_max_workgroups(reserved_fused_cap(cus))
 
 
 def device_identity(props, index):
@@ -215,7 +249,10 @@ class SyncMailbox:
         if on_gpu:
             # ranks of this group that sit on MY device: their grid-barrier launches (which, synchronised, wait for each other
             # inside the kernel) must fit the device together
-            share_device(sum(1 for _, host, d in everyone if host == mine[1] and d == dev_id))
+            here = sum(1 for _, host, d in everyone if host == mine[1] and d == dev_id)
+            share_device(here)
+            if here <= 1 and dist.get_backend(group) == "nccl":
+                reserve_for_collectives(device)         # (also for groups that were not set up by init_distributed)
         if good:
             blob = ctypes.create_string_buffer(b"".join(h for h, _, _ in everyone), nb * w)
             with on_device():

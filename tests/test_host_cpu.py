@@ -582,3 +582,16 @@ def test_device_identity_tells_physical_gpus_apart():
     assert device_identity(with_uuid[0], 0) != device_identity(with_uuid[1], 0)
     bare = Props()
     assert device_identity(bare, 2) == "index 2" and device_identity(bare, 2) != device_identity(bare, 3)
+
+
+def test_reserved_fused_cap_leaves_compute_units_for_rccl(monkeypatch):
+    """utils.parallel.reserved_fused_cap: with RCCL's kernels beside the step the grid-barrier launches must never cover the chip
+    (a cross-rank cycle ABN pass -> peer's ABN pass -> peer's RCCL kernel -> own RCCL kernel -> own ABN pass, see
+    reserve_for_collectives)."""
+    from structure_knowledge_distillation_amd.utils.parallel import reserved_fused_cap
+    monkeypatch.delenv("SKD_ABN_RCCL_RESERVE_CUS", raising=False)
+    assert reserved_fused_cap(256) == 192 and reserved_fused_cap(304) == 192 and reserved_fused_cap(32) == 4
+    monkeypatch.setenv("SKD_ABN_RCCL_RESERVE_CUS", "32")
+    assert reserved_fused_cap(256) == 224
+    monkeypatch.setenv("SKD_ABN_RCCL_RESERVE_CUS", "0")
+    assert reserved_fused_cap(256) == 256
