@@ -158,3 +158,21 @@ def test_gpu_suite_networks_forward_section_rederived():
     for name in ("student", "teacher"):
         for a, b in zip(fresh[name], suite["networks_forward"][name]):
             assert a["shape"] == b["shape"] and torch.allclose(a["sample"], b["sample"], rtol=1e-9, atol=1e-12 * (b["norm"] + 1e-30))
+
+
+def test_gpu_suite_fixtures_keep_their_distance_from_the_pyramid_kink():
+    """Round 4 (profiles/r04q_world8_discontinuities.md): the pyramid's 1 x 1 stage normalises B nearly identical pooled vectors
+    (variance ~ eps) and ONE unit at |y| = 8.9e-6 in front of its leaky ReLU made a correct GPU step sit 10 % from the record.
+    The eight-shard section records the margins it was generated with (asserted by the generator); here the recorded values are
+    checked against the generator's thresholds, re-derived for the section that is cheap to re-derive (a student forward of the
+    two-shard batch, ~3 s), and the record's new parts are checked for shape."""
+    gen, suite = _suite()
+    sh8 = suite["sharded8"]
+    assert all(m >= need for m, need in zip(sh8["pyramid_margins"], gen.PYRAMID_MARGIN)), sh8["pyramid_margins"]
+    assert len(sh8["dlogits_smooth"]) == 8 and all(r["shape"] == [2, 19, 65, 65] and r["sample"].numel() == 4096 for r in sh8["dlogits_smooth"])
+    assert set(sh8["pa"]) == {"shard_losses", "grads_S", "running"} and len(sh8["pa"]["shard_losses"]) == 8
+    assert all(sh8["pa"]["shard_losses"][r]["pi_G_loss"] == sh8["shard_losses"][r]["pi_G_loss"] for r in range(8))    # same forward
+    assert set(sh8["pa"]["grads_S"]) == set(sh8["grads_S"])
+    x, _, _, _ = gen.sharded2_inputs()
+    margins = gen.pyramid_margins(gen.init_nets("sharded2")[0], x)
+    assert margins[0] >= 1e-3, "the two-shard fixture's 1 x 1 pyramid stage sits %r from its leaky ReLU's kink" % (margins,)
