@@ -54,7 +54,7 @@ def evaluate_main(model, loader, gpu_id, input_size, num_classes, whole=False, r
         from torch.utils.data.distributed import DistributedSampler
         if isinstance(sampler, (DistributedSampler, RandomSampler)) or isinstance(getattr(loader, "batch_sampler", None), DistributedSampler):
             raise ValueError("evaluate_main shards the validation set itself (batch i on rank i %% world): hand it a plain, "
-                             "unshuffled, unsharded loader (got sampler %s)" % type(sampler).__name__)
+                             "unshuffled, unsharded loader (got sampler %s)" % sampler.__class__.__name__)   # (`type` is an argument here)
     device = torch.device("cuda", int(gpu_id) if str(gpu_id).isdigit() else 0) if torch.cuda.is_available() \
         else next(model.parameters()).device
     was_training = model.training

@@ -595,3 +595,19 @@ def test_reserved_fused_cap_leaves_compute_units_for_rccl(monkeypatch):
     assert reserved_fused_cap(256) == 224
     monkeypatch.setenv("SKD_ABN_RCCL_RESERVE_CUS", "0")
     assert reserved_fused_cap(256) == 256
+
+
+def test_sharded_evaluation_refuses_loaders_that_shard_or_shuffle():
+    """networks/evaluate.py: with world > 1 every rank walks the SAME batch sequence and scores batch i on rank i % world; a loader
+    that shuffles or already shards would be scored only in part, silently -- it must be refused with a message that
+    names the sampler (the refusal itself used to die on `type(sampler)`: `type` is an argument of evaluate_main)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+    from structure_knowledge_distillation_amd.networks.evaluate import evaluate_main
+    ds = TensorDataset(torch.zeros(4, 3, 8, 8), torch.zeros(4, 8, 8), torch.tensor([[8, 8, 3]] * 4))
+    model = torch.nn.Conv2d(3, 19, 1)
+    with pytest.raises(ValueError, match="RandomSampler"):
+        evaluate_main(model, DataLoader(ds, batch_size=1, shuffle=True), "0", "8,8", 19, whole=True, rank=0, world=2)
+    with pytest.raises(ValueError, match="DistributedSampler"):
+        evaluate_main(model, DataLoader(ds, batch_size=1, sampler=DistributedSampler(ds, num_replicas=2, rank=0)), "0", "8,8", 19,
+                      whole=True, rank=0, world=2)
