@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pairwise-sweep", action="store_true")
+    ap.add_argument("--no-dsn-ab", action="store_true", help="skip the informative re-timing without the teacher's dead DSN head")
     return ap.parse_args()
 
 
@@ -441,6 +442,32 @@ def main():
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a.cpu_baseline_seconds, a.size)
+    if world == 1 and not a.no_dsn_ab:
+        # INFORMATIVE, never `value`: the same step with the teacher's deep-supervision head not computed.  Its only consumer is the
+        # teacher's own CE, which the reference computes and discards (kd_model.py:129) and this package does not compute; the head
+        # itself IS part of the benched configuration above because the reference's forward runs it.
+        keep = getattr(model.teacher, "skip_dsn", False)
+        try:
+            model.teacher.skip_dsn = True
+            model._teacher_graphs.clear()
+            for i in range(3):
+                step(i)
+            n2 = min(a.steps, 10)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(n2):
+                step(3 + i)
+            fence()
+            el2 = time.perf_counter() - t1
+            line["informative_teacher_dsn_head_skipped"] = {
+                "ms_per_step": round(1e3 * el2 / n2, 3), "images_per_sec": round(a.batch * n2 / el2, 3), "steps": n2,
+                "note": "SKD_TEACHER_DSN=0: 0.32 TFLOP per step of dead work less (the head's output feeds only the teacher CE the reference "
+                        "discards); losses, gradients and updates are unchanged; NOT the benched configuration"}
+        except Exception as e:                       # an extra must never cost the line
+            line["informative_teacher_dsn_head_skipped"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        finally:
+            model.teacher.skip_dsn = keep
+            model._teacher_graphs.clear()
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
