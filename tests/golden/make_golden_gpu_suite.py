@@ -321,5 +321,19 @@ def main(argv):
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 
+def print_margins(seeds):
+    """--margins [batch seed ...]: min |y| of the pyramid stages for candidate batch seeds of the eight-shard section (7 s per seed):
+    how the seed in SEEDS["sharded8"] was chosen."""
+    PS = init_nets("sharded8")[0]
+    for seed in seeds or [SEEDS["sharded8"]["batch"]]:
+        x, _ = O.synthetic_batch(16, 512, 512, seed=int(seed))
+        m = pyramid_margins(PS, x)
+        print("batch seed %s: pyramid margins %s%s" % (seed, ["%.1e" % v for v in m],
+                                                      "" if all(a >= b for a, b in zip(m, PYRAMID_MARGIN)) else "   (below PYRAMID_MARGIN)"), flush=True)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if sys.argv[1:2] == ["--margins"]:
+        print_margins(sys.argv[2:])
+    else:
+        main(sys.argv[1:])
