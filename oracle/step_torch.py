@@ -251,8 +251,48 @@ def self_attn(P, name, x):
     return P[name + ".gamma"] * out + x, attn
 
 
-def discriminator_forward(P, x, training=True):
-    """[out (B,1,1,1), attn1 (B,64,64), attn2 (B,16,16)] for 65x65 inputs, preprocess mode 1 (BN)."""
+class LeakyMasks:
+    """The critic's LeakyReLU decisions of ANOTHER evaluation of the same inputs, prescribed to this one (kink-aware parity).
+
+    The critic is piecewise smooth: its LeakyReLU slopes (sagan_models.py:116-134) are step functions of the pre-activations, the
+    WGAN-GP term differentiates THROUGH them, and two evaluations of the same logits in different arithmetic (fp32 on the GPU, fp64
+    here) disagree about the sign of a pre-activation that lies within rounding of zero -- one flipped first-layer unit moves the
+    gradient by ~ 1 / sqrt(units).  No bound on a gradient holds ACROSS a flipped unit, so the comparison is made on the same linear
+    piece: ``masks`` are the (pre-activation > 0) decisions the evaluation under test actually took, in call order (4 per critic
+    forward); ``leaky`` applies them instead of this evaluation's own signs and records every disagreement with the distance of
+    that pre-activation from the kink (relative to the layer's rms) -- the test asserts that only units within rounding distance
+    of zero were overridden, and only a handful of them."""
+
+    def __init__(self, masks):
+        self.masks = [m.bool() for m in masks]
+        self.pos = 0
+        self.units = 0
+        self.flipped = 0              # units whose prescribed decision differs from this evaluation's own sign
+        self.worst = 0.0              # max over those of |pre-activation| / rms(layer pre-activations)
+
+    def leaky(self, pre, slope):
+        assert self.pos < len(self.masks), "more LeakyReLU calls than recorded masks"
+        m = self.masks[self.pos].to(pre.device)
+        self.pos += 1
+        assert m.shape == pre.shape, (tuple(m.shape), tuple(pre.shape))
+        d = pre.detach()
+        diff = m != (d > 0)
+        self.units += m.numel()
+        n = int(diff.sum())
+        if n:
+            self.flipped += n
+            self.worst = max(self.worst, float(d[diff].abs().max() / d.pow(2).mean().sqrt()))
+        return pre * torch.where(m, torch.ones((), dtype=pre.dtype), torch.full((), slope, dtype=pre.dtype))
+
+    def done(self):
+        assert self.pos == len(self.masks), "recorded %d LeakyReLU masks, %d consumed" % (len(self.masks), self.pos)
+        return self
+
+
+def discriminator_forward(P, x, training=True, masks=None):
+    """[out (B,1,1,1), attn1 (B,64,64), attn2 (B,16,16)] for 65x65 inputs, preprocess mode 1 (BN).
+    ``masks``: a LeakyMasks whose recorded decisions replace this evaluation's own LeakyReLU signs (see the class)."""
+    leaky = (lambda t: F.leaky_relu(t, 0.1)) if masks is None else (lambda t: masks.leaky(t, 0.1))
     pa = "preprocess_additional."
     if training:
         P[pa + "num_batches_tracked"] += 1
@@ -261,10 +301,10 @@ def discriminator_forward(P, x, training=True):
     out = x
     for i in (1, 2, 3):
         pre = "l%d.0.module." % i
-        out = F.leaky_relu(F.conv2d(out, spectral_weight(P, pre), P[pre + "bias"], 2, 1), 0.1)
+        out = leaky(F.conv2d(out, spectral_weight(P, pre), P[pre + "bias"], 2, 1))
     out, p1 = self_attn(P, "attn1", out)
     pre = "l4.0.module."
-    out = F.leaky_relu(F.conv2d(out, spectral_weight(P, pre), P[pre + "bias"], 2, 1), 0.1)
+    out = leaky(F.conv2d(out, spectral_weight(P, pre), P[pre + "bias"], 2, 1))
     out, p2 = self_attn(P, "attn2", out)
     out = F.conv2d(out, P["last.0.weight"], P["last.0.bias"])
     return [out, p1, p2]
@@ -329,12 +369,12 @@ def criterion_adv(d_out_S, d_out_T, adv_type="wgan-gp"):
     return F.relu(1.0 - d_out_T[0]).mean() + F.relu(1.0 + d_out_S[0]).mean()
 
 
-def criterion_gp(PD, preds_S, preds_T, lambda_gp, alpha):
+def criterion_gp(PD, preds_S, preds_T, lambda_gp, alpha, masks=None):
     """alpha: (B,1,1,1) uniform samples (the reference draws them with torch.rand, criterion.py:104)."""
     real, fake = preds_T[0].detach(), preds_S[0].detach()
     assert real.shape == fake.shape
     x = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
-    out = discriminator_forward(PD, x)
+    out = discriminator_forward(PD, x, masks=masks)
     grad = torch.autograd.grad(out[0], x, torch.ones_like(out[0]), retain_graph=True, create_graph=True)[0]
     grad = grad.reshape(grad.shape[0], -1)
     return lambda_gp * torch.mean((torch.sqrt(torch.sum(grad ** 2, dim=1)) - 1) ** 2)
@@ -520,21 +560,29 @@ def distillation_step_sharded(PS, PT, PD, images, labels, cfg, shards, alphas=No
     return out
 
 
-def discriminator_step(P, logits_S, logits_T, cfg, alpha, g_step_forward=True):
+def discriminator_step(P, logits_S, logits_T, cfg, alpha, g_step_forward=True, masks=None, terms=None):
     """The discriminator's part of one step on GIVEN logits (kd_model.py:148, 153-165): the G step's critic forward
     (advances u, v only), D(T), D(S), adversarial loss + WGAN-GP.  Mutates u, v / BN statistics in ``P``.
-    Returns (d_loss as float, {key: gradient})."""
+    Returns (d_loss as float, {key: gradient}).  ``masks``: LeakyMasks over the step's critic forwards in this order
+    (kink-aware comparison, see the class); ``terms``: a dict that receives the magnitudes of the cancelling summands."""
     require_grad(P, True)
     pS, pT = logits_S.detach(), logits_T.detach()
     if g_step_forward:
-        discriminator_forward(P, pS)
-    d_t, d_s = discriminator_forward(P, pT), discriminator_forward(P, pS)
+        discriminator_forward(P, pS, masks=masks)
+    d_t, d_s = discriminator_forward(P, pT, masks=masks), discriminator_forward(P, pS, masks=masks)
     d_loss = cfg.lambda_d * criterion_adv(d_s, d_t, cfg.adv_loss_type)
+    gp = None
     if cfg.adv_loss_type == "wgan-gp":
-        d_loss = d_loss + cfg.lambda_d * criterion_gp(P, [pS], [pT], cfg.lambda_gp, alpha)
+        gp = cfg.lambda_d * criterion_gp(P, [pS], [pT], cfg.lambda_gp, alpha, masks=masks)
+        d_loss = d_loss + gp
+    if terms is not None:
+        terms.update(d_T=float(cfg.lambda_d * d_t[0].detach().mean().abs()), d_S=float(cfg.lambda_d * d_s[0].detach().mean().abs()),
+                     gp=float(gp.detach().abs()) if gp is not None else 0.0)
     keys = learnable_keys(P)
     grads = dict(zip(keys, torch.autograd.grad(d_loss, [P[k] for k in keys], allow_unused=True)))
     require_grad(P, False)
+    if masks is not None:
+        masks.done()
     return float(d_loss.detach()), grads
 
 

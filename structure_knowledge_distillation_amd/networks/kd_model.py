@@ -219,12 +219,10 @@ class NetModel():
         graph_env = os.environ.get("SKD_TEACHER_GRAPH", "1")
         self._teacher_graph_on = (graph_env in ("1", "force") and torch.device(device).type == "cuda"
                                   and (parallel_old.world_size() == 1 or graph_env == "force")
-                                  and os.environ.get("SKD_TEACHER_STREAM", "0") != "1" and not self.deterministic_no_graph())
+                                  and not self.deterministic_no_graph())
         self._teacher_graphs = {}
         self._teacher_tensors = list(teacher.parameters()) + list(teacher.buffers())
         self._teacher_stamp = None
-        self._teacher_stream = (torch.cuda.Stream(device=device) if (os.environ.get("SKD_TEACHER_STREAM", "0") == "1"
-                                                                    and torch.device(device).type == "cuda") else None)
         # The D step (kd_model.py:153-165) only needs the two logit tensors and D's own state: it runs on a second HIP
         # stream next to the student's backbone backward (its ~700 launches are 3-8 us kernels on (8, 19..512, <=65, 65)
         # tensors that leave the chip idle when serialised).  SKD_D_STREAM=0 restores the serial order.
@@ -302,9 +300,10 @@ class NetModel():
         issued op by op from Python -- so (SKD_TEACHER_GRAPH, default on) its forward is captured ONCE per input shape into a
         hipGraph and replayed: one host call per step instead of ~330 launches plus their Python dispatch (VERDICT r03 item 4;
         DESIGN.md section 9.4 has the A/B).  The graph owns its input / activation / output buffers (2.6 GB at batch 8,
-        resident in HBM between steps -- 288 GB per GPU is what makes that free); ``preds_T`` are the graph's output tensors,
-        valid until the next replay, which the step's own stream order (main.wait_stream(D stream) at the end of a step) keeps
-        behind every reader.  The replayed kernels are the SAME kernels in the same order: results are bit-identical to the
+        resident in HBM between steps -- 288 GB per GPU is what makes that free); ``preds_T`` are the graph's output tensors:
+        STATIC buffers that the next replay overwrites.  Inside a step that is safe by stream order (main.wait_stream(D stream)
+        at the end of a step keeps the next replay behind every reader); a consumer that wants to keep teacher outputs ACROSS
+        steps must take ``model.teacher_outputs()`` (clones) instead of holding ``model.preds_T``.  The replayed kernels are the SAME kernels in the same order: results are bit-identical to the
         eager forward under SKD_DETERMINISTIC=1 (tests/test_step_gpu.py)."""
         images = self.images
         if not self._teacher_graph_on or not images.is_cuda:
@@ -333,6 +332,13 @@ class NetModel():
         graph.replay()
         return list(outs)
 
+    def teacher_outputs(self):
+        """The teacher's outputs of the last forward as tensors the caller may keep: with the hipGraph on, ``preds_T`` are the
+        graph's static output buffers (overwritten by the next step's replay) and are cloned here; eager outputs are returned as is."""
+        if not getattr(self, "_teacher_graph_on", False):
+            return list(self.preds_T)
+        return [None if t is None else t.clone() for t in self.preds_T]
+
     def _capture_teacher(self, images):
         static_in = torch.empty_like(images)
         static_in.copy_(images)
@@ -346,7 +352,11 @@ class NetModel():
         torch.cuda.current_stream(images.device).wait_stream(side)
         torch.cuda.synchronize(images.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the capture is lazy (first step), i.e. a DataLoader's pin-memory thread (dataset/datasets.py's documented
+        # loader: pin_memory=True -> hipHostMalloc / hipEventQuery from another thread) may be alive; in the default "global" mode
+        # such a call would invalidate the capture or raise hipErrorStreamCaptureUnsafe IN THAT THREAD, where the try / except
+        # around this function cannot see it.  Only this thread issues work into the capture.
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             outs = self._teacher_forward_eager(static_in)
         return static_in, graph, outs
 
@@ -360,25 +370,11 @@ class NetModel():
         return [t.contiguous() for t in preds[:3]] + list(preds[3:])
 
     def forward(self):
-        args = self.args
-        side = self._teacher_stream
-        if side is None:
-            self.preds_T = self._teacher_forward()
-            self.preds_S = self._student_forward()
-            return
-        # The frozen teacher does not depend on the student: run it on its own HIP stream so that the two
-        # forwards fill each other's launch tails (kd_model.py:121-123 runs them back to back).  Measured +0.7 %
-        # (83.8 -> 83.2 ms per step); off by default because co-running kernels blur the per-kernel HIP-event and
-        # rocprofv3 timings the roofline figures are read from (SKD_TEACHER_STREAM=1 enables it).
-        main = torch.cuda.current_stream(self.images.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.preds_T = self._teacher_forward()
+        # kd_model.py:121-123.  (Rounds 2-4 could also issue the teacher on a stream of its own -- +0.7 % -- ; with the teacher a
+        # single hipGraph replay the host-side gain is gone, and under SKD_DETERMINISTIC=1 that three-stream configuration
+        # intermittently never finished its D backward inside the vendor stack: removed in round 5)
+        self.preds_T = self._teacher_forward()
         self.preds_S = self._student_forward()
-        main.wait_stream(side)
-        for t in self.preds_T:
-            if t is not None:
-                t.record_stream(main)
 
     def student_backward(self):
         args = self.args

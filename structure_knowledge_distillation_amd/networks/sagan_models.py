@@ -6,8 +6,6 @@ double backward through them keeps working).  The unused ``Generator`` is out of
 import torch
 import torch.nn as nn
 
-import os
-
 from .spectral import SpectralNorm, normalize_together
 
 
@@ -79,12 +77,9 @@ class Discriminator(nn.Module):
 
     def forward(self, x):
         # the four spectrally normalised weights of this forward in 3 launches instead of 12 (csrc/spectral.hip, "several layers
-        # per launch"); SKD_SN_TOGETHER=0 keeps one wrapper at a time
-        # Not under torch.use_deterministic_algorithms (SKD_DETERMINISTIC=1): with the teacher on its own stream as well, that mode
-        # intermittently never finishes its D backward on this stack (engine thread in C++): 5 of 5 runs with
-        # the launches batched, 1 of 5 with one wrapper at a time -- timing, not cause, but the mode whose purpose is comparing
-        # orders of execution keeps round 3's per-wrapper order.
-        if os.environ.get("SKD_SN_TOGETHER", "1") == "1" and not torch.are_deterministic_algorithms_enabled():
+        # per launch"; bit-identical to one wrapper at a time: tests/test_kernels_gpu.py::test_spectral_norm_multi_*, step-neutral A/B
+        # in profiles/r04g_bench_ab_SN_TOGETHER_0.json)
+        if not torch.are_deterministic_algorithms_enabled():      # SKD_DETERMINISTIC=1 keeps round 3's one-wrapper-at-a-time order
             normalize_together([blk[0] for blk in (self.l1, self.l2, self.l3, getattr(self, "l4", None))
                                 if blk is not None and isinstance(blk[0], SpectralNorm)])
         x = self.preprocess_additional(x)

@@ -81,7 +81,11 @@ def normalize_together(wrappers):
     steps side by side instead of interleaved with the convolutions changes no number.  Wrappers with more than one power
     iteration, CPU tensors without the test double, or a single wrapper keep the per-wrapper path (returns False)."""
     wrappers = list(wrappers)
-    if len(wrappers) < 2 or len(wrappers) > 8 or any(w.power_iterations != 1 or getattr(w, "_prepared", False) for w in wrappers):
+    for w in wrappers:
+        # a flag left over from a forward that raised between this function and the layer (OOM, interrupt) must not make the next
+        # forward skip its power step and reuse a weight whose graph may be gone: every call starts clean and recomputes
+        w._prepared = False
+    if len(wrappers) < 2 or len(wrappers) > 8 or any(w.power_iterations != 1 for w in wrappers):
         return False
     parts = [w._parts() for w in wrappers]
     if len({(p[0].device, p[0].dtype) for p in parts}) != 1:

@@ -32,38 +32,6 @@ def cpu_sd(mod, dtype=torch.float32):
             for k, v in mod.state_dict().items()}
 
 
-def case_teacher_stream_equals_serial_bit_for_bit_in_deterministic_mode(monkeypatch):
-    """SKD_TEACHER_STREAM=1 (the frozen teacher's forward on its own HIP stream beside the student's) against the serial
-    order, under SKD_DETERMINISTIC=1: same bits in every loss and every student / discriminator tensor after two steps."""
-    monkeypatch.setenv("SKD_DETERMINISTIC", "1")
-    try:
-        def run(flag):
-            monkeypatch.setenv("SKD_TEACHER_STREAM", flag)
-            torch.manual_seed(99)
-            args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
-            model = NetModel(args)
-            assert model.deterministic and (model._teacher_stream is not None) == (flag == "1")
-            losses = []
-            for step in range(2):
-                images, labels = O.synthetic_batch(2, 512, 512, seed=step)
-                model.gp_alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step)).to(DEV)
-                torch.manual_seed(500 + step)
-                model.set_input((images, labels, None, None))
-                model.optimize_parameters()
-                losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
-            torch.cuda.synchronize()
-            return losses, cpu_sd(model.student), cpu_sd(model.D_model)
-
-        serial, stream = run("0"), run("1")
-        assert serial[0] == stream[0], (serial[0], stream[0])
-        for which, what in ((1, "student"), (2, "D")):
-            diff = [k for k, v in serial[which].items() if not torch.equal(v, stream[which][k])]
-            assert not diff, "%s state differs with the teacher on its own stream: %s" % (what, diff[:8])
-    finally:
-        torch.backends.cudnn.enabled = True
-        torch.use_deterministic_algorithms(False)
-
-
 def case_teacher_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode(monkeypatch):
     """SKD_TEACHER_GRAPH (default on): the frozen teacher's forward captured once into a hipGraph and replayed.  Same kernels,
     same order: under SKD_DETERMINISTIC=1 two steps -- the capture step and a REPLAY on a new batch -- give the same bits as

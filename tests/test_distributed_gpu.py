@@ -12,6 +12,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kinks import assert_only_rounding_flips  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -588,6 +591,7 @@ def _netmodel_step_world8(rank, world, dev=None):
     import importlib
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     from structure_knowledge_distillation_amd import _lib as L
+    from kinks import LeakyRecorder
     PC = importlib.import_module("structure_knowledge_distillation_amd.networks.pspnet_combine")
     torch.set_num_threads(2)
     gen = _generator()
@@ -622,7 +626,8 @@ def _netmodel_step_world8(rank, world, dev=None):
         model.set_input((x[sl], y[sl], None, None))
         PC.ResNet.forward = recording_forward if ho else plain_forward
         try:
-            model.optimize_parameters()
+            with LeakyRecorder(model.D_model) as rec:      # the critic's own LeakyReLU decisions: G step, D(T), D(S), gradient penalty
+                model.optimize_parameters()
         finally:
             PC.ResNet.forward = plain_forward
         if on_gpu:
@@ -636,6 +641,8 @@ def _netmodel_step_world8(rank, world, dev=None):
         if ho:
             o["logits"] = (model.preds_S[0].detach().cpu(), model.preds_T[0].detach().cpu())
             o["d_logits"] = got["d_logits"].contiguous().cpu()
+            o["masks"] = rec.masks
+            assert len(o["masks"]) == 16, len(o["masks"])
             o["d_grads"] = {k: p.grad.detach().cpu() for k, p in model.D_model.named_parameters() if p.grad is not None}
             o["d_uv"] = {k: v.detach().cpu() for k, v in model.D_model.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
         out[name] = o
@@ -646,11 +653,6 @@ def _netmodel_step_world8(rank, world, dev=None):
     return out
 
 
-@pytest.mark.xfail(strict=False, reason="re-seeded at the end of round 4 (the first batch seed sat on a leaky-ReLU kink of the pyramid's 1 x 1 stage, see "
-                   "the docstring).  With the new seed checks (1)-(2) ran on the GPU and ALL five pass in the full-size CPU rehearsal "
-                   "(tests/diagnostics/diag_world8_cpu_fixture.py, profiles/r04u_world8_cpu_rehearsal.log); the round's GPU budget ended before "
-                   "(3)-(5) ran on hardware.  Non-strict: runs and reports (XPASS when green), does not gate the suite until a hardware run "
-                   "has confirmed it -- tools/gpu_session.sh world8 runs it without the marker")
 def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
     """configs[3]'s world size on the real kernels, against the recorded 8-shard fp64 oracle (tests/golden/gpu_suite_oracle.pt
     ["sharded8"]).
@@ -666,9 +668,14 @@ def test_netmodel_ho_step_eight_ranks_vs_sharded_oracle():
         rank's OWN logits to 2e-5, while the fp64 critic itself moves by 4e-3 .. 1.3e-2 between the product's and the oracle's logits
         (which agree to 1.4e-5) on five of the eight shards.
     So:  (1) losses per shard, replicas, running statistics, u / v against the record;  (2) d G_loss / d logits per rank
-    against record (smooth part) + fp64 critic on the rank's own logits -- the tight statement about the Ho gradient;  (3) the D
-    step on the ranks' own logits under the ONE bound;  (4) every averaged student gradient of the Pi + Pa step (smooth criteria)
-    under the ONE bound;  (5) the Ho step's end-to-end gradients to a 10 % bound (a rank missing from the average is 12 %)."""
+    against record (smooth part) + fp64 critic on the rank's own logits ON THE LINEAR PIECE THE RANK TOOK (tests/kinks.py: the
+    critic's recorded LeakyReLU decisions replace the oracle's own signs, and only units within rounding of zero may differ) to
+    2e-4 -- the tight statement about the Ho gradient (round 4 had widened it to 3e-2 to leave room for flipped units);  (3) the D
+    step on the ranks' own logits, same linear piece, under the ONE bound;  (4) every averaged student gradient of the Pi + Pa step
+    (smooth criteria) under the ONE bound;  (5) the Ho step's end-to-end gradients to a 10 % bound (a rank missing from the average
+    is 12 %).  Size note: BASELINE configs[3] is 8 ranks x 8 images; the eight ranks here share ONE MI355X (and one 45 GB CPU
+    fixture), so each holds 2 images (global batch 16) -- the world size, the exchanges and the averaging are configs[3]'s, the
+    per-rank batch is not."""
     # In its OWN process group with a hard limit: nine processes (this one's child + eight ranks) that a hang anywhere -- a rank stuck in
     # a collective after a peer died in a way mp.spawn does not see -- must not turn into the suite's time limit.  It takes ~70 s.
     import signal
@@ -710,10 +717,8 @@ def _check_world8(both, on_gpu=True):
     worst_dl = 0.0
     for r in range(world):
         for k, ref in fx["shard_losses"][r].items():
-            got = outs[r]["losses"][k]
-            # the critic loss is a cancelling sum that amplifies the 1e-6 run-to-run noise of the logits ~50 x (tests/test_step_gpu.py has
-            # the numbers): end to end it is held to 1e-3 here and to north_star's 1e-4 against the oracle's D step on the rank's OWN logits
-            assert abs(got - ref) <= (1e-3 if k == "D_loss" else 1e-4) * abs(ref), (r, k, got, ref)
+            if k != "D_loss":              # the critic loss: in (3), where the magnitudes of its cancelling summands are at hand
+                assert abs(outs[r]["losses"][k] - ref) <= 1e-4 * abs(ref), (r, k, outs[r]["losses"][k], ref)
         for k, ref in fx["pa"]["shard_losses"][r].items():
             assert abs(outs_pa[r]["losses"][k] - ref) <= 1e-4 * abs(ref) + 1e-12, ("Pi + Pa step", r, k, outs_pa[r]["losses"][k], ref)
         if ipc:
@@ -721,8 +726,10 @@ def _check_world8(both, on_gpu=True):
                 assert o["forms"][0] + o["forms"][1] == 56, o["forms"]      # every channels-last layer through the one-call entries
         logits = outs[r]["logits"][0].double().requires_grad_(True)
         P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in PD.items()}
-        adv = cfg.lambda_d * O.criterion_adv_for_g(O.discriminator_forward(P, logits), cfg.adv_loss_type)     # kd_model.py:141-142
+        lm = O.LeakyMasks(outs[r]["masks"][:4])          # the decisions of the rank's own G-step critic forward
+        adv = cfg.lambda_d * O.criterion_adv_for_g(O.discriminator_forward(P, logits, masks=lm), cfg.adv_loss_type)     # kd_model.py:141-142
         want = torch.autograd.grad(adv, logits)[0].reshape(-1)
+        assert_only_rounding_flips(lm.done(), "rank %d, critic forward of the G step" % r)
         rec = fx["dlogits_smooth"][r]
         assert list(outs[r]["d_logits"].shape) == rec["shape"]
         idx = torch.arange(rec["sample"].numel()) * rec["step"]
@@ -730,11 +737,9 @@ def _check_world8(both, on_gpu=True):
         got_s = outs[r]["d_logits"].double().reshape(-1)[idx]
         err = float((got_s - want_s).norm() / want_s.norm())
         worst_dl = max(worst_dl, err)
-        # 2e-5 on all eight ranks with the first batch seed, 4e-3 on one rank with the second: the critic has ~250 k LeakyReLU units per
-        # shard and the fp32 (GPU) and fp64 (here) evaluations of the SAME logits disagree about the sign of one of them now and then --
-        # one flipped unit of the first layer is 1 / sqrt(65536) = 4e-3 of the gradient.  The bound leaves room for a handful of flips;
-        # a wrong lambda_d, a missing term or a wrong sign is an O(1) error.
-        assert err <= 3e-2, "rank %d: d G_loss / d logits differs from CE + KL (record) + critic on its own logits (fp64): %.2e" % (r, err)
+        # On the same linear piece the product's gradient equals the fp64 critic's to ~2e-5 (round 4 measured 2e-5 on the ranks without a
+        # flipped unit and 4e-3 = one first-layer unit of 65536 on the one with); a wrong lambda_d, a missing term or a sign is O(1).
+        assert err <= 2e-4, "rank %d: d G_loss / d logits differs from CE + KL (record) + critic on its own logits (fp64, same linear piece): %.2e" % (r, err)
     print("world 8: synchronised ABN calls per rank (one launch, three launches):", outs[0]["forms"], "Pi + Pa step:", outs_pa[0]["forms"])
     print("world 8: d G_loss / d logits vs record + fp64 critic on the rank's own logits, worst rank: %.2e" % worst_dl)
     # replicas: identical averaged gradients, running statistics, u / v on all eight ranks -- in both steps
@@ -744,19 +749,34 @@ def _check_world8(both, on_gpu=True):
                 for k, v in o.get(name, {}).items():
                     assert torch.equal(v, o0[name][k]), "rank %d differs from rank 0 in %s[%s]" % (r, name, k)
     # (3) the D step on the very logits each rank produced, per shard, averaged over the 8 shards: the ONE bound
-    ref = {}
+    ref, moved = {}, 0.0
     for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
         acc = {}
         for r, sl in enumerate(shards):
             P = {k: (v.to(dt, copy=True) if v.is_floating_point() else v.clone()) for k, v in PD.items()}
             pS, pT = outs[r]["logits"]
-            loss, grads = O.discriminator_step(P, pS.to(dt), pT.to(dt), cfg, alpha[sl].to(dt))
+            lm, terms = O.LeakyMasks(outs[r]["masks"]), {}
+            loss, grads = O.discriminator_step(P, pS.to(dt), pT.to(dt), cfg, alpha[sl].to(dt), masks=lm, terms=terms)
             if name == "f64":
-                assert abs(outs[r]["losses"]["D_loss"] - loss) <= 1e-4 * abs(loss), (r, outs[r]["losses"]["D_loss"], loss)
+                assert_only_rounding_flips(lm, "rank %d, the four critic forwards of the step" % r)
+                got = outs[r]["losses"]["D_loss"]
+                # north_star's 1e-4 against the oracle's D step on the rank's OWN logits ...
+                assert abs(got - loss) <= 1e-4 * abs(loss), (r, got, loss)
+                # ... and end to end against the record (the fp64 oracle on ITS OWN logits, which agree with the rank's to ~1.4e-5).  By the
+                # triangle inequality |got - record| <= |got - oracle(own logits)| + |oracle(own logits) - record|: the first term is the
+                # statement about the product (1e-4, just asserted), the second is the fp64 critic's own movement between two sets of logits
+                # 1.4e-5 apart -- the gradient penalty (|grad D| - 1)^2 makes D_loss about ten times as sensitive to its input as a linear
+                # functional (CPU double, product not involved: 1.05e-4 on one shard) -- so 1e-4 cannot hold end to end for ANY correct fp32
+                # forward; the end-to-end figure is a sanity bound on that movement (printed), not the parity statement.
+                ref_rec = fx["shard_losses"][r]["D_loss"]
+                moved = max(moved, abs(loss - ref_rec) / abs(ref_rec))
+                assert abs(got - ref_rec) <= 1e-4 * abs(loss) + abs(loss - ref_rec) + 1e-12, (r, got, loss, ref_rec)
+                assert abs(got - ref_rec) <= 1e-3 * abs(ref_rec), (r, got, ref_rec, terms)
             for k, g in grads.items():
                 if g is not None:
                     acc[k] = acc.get(k, 0.0) + g / world
         ref[name] = acc
+    print("world 8: the fp64 critic's D_loss on the ranks' own logits vs on the oracle's logits (the function's movement, product not involved), worst shard: %.2e" % moved)
     _bound_report("world 8 discriminator step on the ranks' own logits (averaged over the 8 shards)",
                   [(k, float((outs[0]["d_grads"][k].double() - g).norm()), float((ref["f32"][k].double() - g).norm()), float(g.norm()))
                    for k, g in ref["f64"].items() if float(g.norm()) > 1e-12], GRAD_BOUND, GRAD_FLOOR)

@@ -233,6 +233,35 @@ PYEOF
       done
       python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 >> $O/session.log 2>&1
       stamp "pmc2 summarised" ;;
+    timeline)
+      # ONE kernel trace of the default step (teacher = hipGraph replay, D step on its stream; no HIP-event bracketing) -> per-stream
+      # busy / idle, main-stream gaps, exposed D tail (tools/timeline.py); the slimmed per-dispatch trace travels back for re-analysis
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof_timeline -o bench -- \
+        python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing > $O/prof_timeline.log 2>&1)
+      stamp "timeline trace rc=$?"
+      T=$(find $O/prof_timeline -name "*kernel_trace.csv" | head -1)
+      python tools/timeline.py $T $O/timeline.md >> $O/session.log 2>&1
+      stamp "timeline rc=$?"
+      python - "$T" "$O/timeline_trace_slim.csv" <<'PYEOF'
+import csv, sys
+rd = csv.DictReader(open(sys.argv[1], newline=""))
+cols = [c for c in ("Queue_Id", "Stream_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size_X", "Workgroup_Size_X", "Grid_Size", "Workgroup_Size") if c in rd.fieldnames]
+w = csv.DictWriter(open(sys.argv[2], "w", newline=""), fieldnames=cols)
+w.writeheader()
+for r in rd:
+    r = {c: r[c] for c in cols}
+    r["Kernel_Name"] = r["Kernel_Name"][:140]
+    w.writerow(r)
+PYEOF
+      head -2 $T | cut -c1-600 >> $O/session.log
+      find $O/prof_timeline -name "*kernel_trace.csv" -delete ;;
+    tests_r5a)
+      # round 5, first call: the kink-aware bounds (tests/kinks.py) where round 4 had widened them, and the hipGraph cases after the
+      # capture-mode change
+      timeout 900 python -m pytest tests/test_step_gpu.py tests/test_distributed_gpu.py -m gpu -q --tb=short -s --durations=5 \
+        -k "b8_vs_golden or hipgraph or eight_ranks_vs or discriminator_step" > $O/pytest_r5a.log 2>&1
+      stamp "tests_r5a rc=$?"; grep -E "passed|failed|error" $O/pytest_r5a.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED|LeakyReLU decisions|worst rank|movement|im2col" $O/pytest_r5a.log | cut -c1-300 | head -60 | tee -a $O/session.log ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
