@@ -16,8 +16,7 @@ Extra objects on the line:
   roofline      the dominant hand-written kernel of the step, timed live with HIP events on the launch stream over the
                 timed steps: since round 3 the fused bottleneck-tail GEMM of the frozen teacher (conv1x1_abn_kernel:
                 bn2 + ReLU prologue, 1x1 convolution on fp32 MFMA, bn3 + residual + ReLU epilogue; 2*M*K*N algorithmic
-                flops per launch, bound "mfma"); with SKD_TEACHER_TAIL=0 the eval-mode ABN apply pass (8 algorithmic
-                bytes per element, bound "hbm") as in rounds 1-2
+                flops per launch, bound "mfma")
   kernels       the same measurement for the other hand-written kernels / kernel chains
   cpu_baseline  the CPU oracle (oracle/step_torch.py, a port of the reference step pinned to the
                 reference's own Python) timed on this host's cores on a bounded sample
@@ -35,7 +34,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, exact fp32
 STEP_TFLOP_PER_IMAGE = 0.959   # teacher fwd 579.3 GF + student fwd 126.7 + bwd 253.3
-# the PSP bottleneck fold (csrc/ppm.hip, SKD_PSP_FOLD=1) evaluates the priors' half of both bottleneck convolutions by
+# the PSP bottleneck fold (csrc/ppm.hip, networks/pspnet_combine.PSP_FOLD) evaluates the priors' half of both bottleneck convolutions by
 # a small GEMM + fold kernel: 2*65*65*9*(512*2048 [teacher fwd] + 3 * 128*512 [student fwd + 2 bwd]) flop per image less
 FOLD_TFLOP_PER_IMAGE = 2 * 65 * 65 * 9 * (512 * 2048 + 3 * 128 * 512) / 1e12
 
@@ -123,25 +122,61 @@ def pairwise_sweep(dev):
         ws = torch.empty(max(1, lib.skd_pairwise_workspace_floats(B, M)), device=dev)
         call = lambda: lib.skd_pairwise_gram_loss(B, Cs, Ct, M, ldm, fs.data_ptr(), ft.data_ptr(), G.data_ptr(),
                                                   loss.data_ptr(), ws.data_ptr(), st)
-        for _ in range(3):
-            call()
-        reps = 20 if M <= 1089 else 5
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        tf = 2.0 * B * M * M * (Cs + Ct) / (ms * 1e-3) / 1e12
         nt = ldm // 128                       # G is symmetric: only the nt (nt + 1) / 2 upper-triangle 128 x 128 tiles run
-        tf_exec = 2.0 * B * (nt * (nt + 1) // 2) * 128 * 128 * (Cs + Ct) / (ms * 1e-3) / 1e12
+        flop_full = 2.0 * B * M * M * (Cs + Ct)
+        flop_exec = 2.0 * B * (nt * (nt + 1) // 2) * 128 * 128 * (Cs + Ct)
+        flop_useful = 2.0 * B * (M * (M + 1) // 2) * (Cs + Ct)       # unique entries of the symmetric matrices
+
+        def timed(fn, reps=20):
+            """every launch bracketed on its own: median AND minimum of `reps` (five back-to-back launches
+            hid a 13 % spread between sessions); launches below ~60 us are timed back to back (event overhead)."""
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in ev:
+                e0.record()
+                fn()
+                e1.record()
+            torch.cuda.synchronize()
+            t = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+            return t[len(t) // 2], t[0], t[-1]
+
+        if M <= 289:
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = mn = mx = e0.elapsed_time(e1) / 20
+        else:
+            ms, mn, mx = timed(call)
         # the only FRACTION printed is of executed matrix work (incl. the zero padding to ldm); the full-matrix figure is the
         # reference-algorithm rate (what einsum would have had to sustain), a convention, not a utilisation: it may exceed the peak
-        useful = 2.0 * B * (M * (M + 1) // 2) * (Cs + Ct) / (ms * 1e-3) / 1e12      # unique entries of the symmetric matrices
-        out["M=%d" % M] = {"us": round(ms * 1e3, 1), "TFLOPs_full_matrix_convention": round(tf, 2),
-                           "executed_TFLOPs": round(tf_exec, 2), "frac_fp32_mfma_executed": round(tf_exec / MFMA_F32_PEAK_TFLOPS, 4),
-                           "unique_useful_TFLOPs": round(useful, 2), "frac_fp32_mfma_unique_useful": round(useful / MFMA_F32_PEAK_TFLOPS, 4)}
+        rate = lambda f, t: f / (t * 1e-3) / 1e12
+        out["M=%d" % M] = {"us": round(ms * 1e3, 1), "us_min": round(mn * 1e3, 1), "us_max": round(mx * 1e3, 1), "reps": 20,
+                           "TFLOPs_full_matrix_convention": round(rate(flop_full, ms), 2),
+                           "executed_TFLOPs": round(rate(flop_exec, ms), 2),
+                           "frac_fp32_mfma_executed": round(rate(flop_exec, ms) / MFMA_F32_PEAK_TFLOPS, 4),
+                           "frac_fp32_mfma_executed_best_launch": round(rate(flop_exec, mn) / MFMA_F32_PEAK_TFLOPS, 4),
+                           "unique_useful_TFLOPs": round(rate(flop_useful, ms), 2),
+                           "frac_fp32_mfma_unique_useful": round(rate(flop_useful, ms) / MFMA_F32_PEAK_TFLOPS, 4)}
+        if M >= 1089:
+            # the backward GEMM dP = Fhat_S G (2 B ldm^2 Cs executed flop on the zero-padded problem; round 5: both operands k-major)
+            nrm = torch.rand(B, M, device=dev) + 0.5
+            gl = torch.ones(1, device=dev)
+            dp = torch.empty(B, Cs, ldm, device=dev)
+            bws = torch.empty(max(1, lib.skd_pairwise_backward_workspace_floats(B, Cs, M)), device=dev)
+            bcall = lambda: lib.skd_pairwise_backward(B, Cs, M, ldm, fs.data_ptr(), G.data_ptr(), nrm.data_ptr(), gl.data_ptr(),
+                                                      dp.data_ptr(), bws.data_ptr(), st)
+            bms, bmn, bmx = timed(bcall)
+            fb = 2.0 * B * ldm * ldm * Cs
+            out["M=%d" % M]["backward"] = {"us": round(bms * 1e3, 1), "us_min": round(bmn * 1e3, 1), "us_max": round(bmx * 1e3, 1),
+                                           "executed_TFLOPs": round(rate(fb, bms), 2),
+                                           "frac_fp32_mfma_executed": round(rate(fb, bms) / MFMA_F32_PEAK_TFLOPS, 4),
+                                           "note": "whole skd_pairwise_backward call: node-major copy + GEMM (+ split combine)"}
     return out
 
 
@@ -236,6 +271,82 @@ def summarise(recs, bytes_per_elem, nhwc=False):
     return out
 
 
+# ---- N > 1: the first multi-GPU run must produce a number, whatever happens -------------------------------
+# The cross-replica InPlace-ABN exchange has three forms, fastest first; every one computes the reference's combine rule
+# (libs/functions.py:183-218, 257-294) bit for bit.  The warm-up steps run under a SHORT in-kernel wait limit; after each of them
+# the ranks agree (one all-reduce) whether anybody saw a device status word / a non-finite loss, and if so ALL of them drop the
+# model and the mailboxes and start again in the next, safer form.  The JSON line says which form ran and why.
+COMM_FORMS = (
+    ("as configured", {}),
+    ("three launches per pass over the ipc mailboxes", {"SKD_ABN_SYNC_FUSED": "0"}),
+    ("torch.distributed collectives", {"SKD_ABN_SYNC_FUSED": "0", "SKD_SYNC_IPC": "0"}),
+)
+
+
+def _effective_form():
+    return (os.environ.get("SKD_SYNC_IPC", "1") == "1", os.environ.get("SKD_ABN_SYNC_FUSED", "1") == "1")
+
+
+def warm_up_with_fallback(build, warmup, world, dev, warm_timeout_s=30.0, run_timeout_s=120.0, forms=COMM_FORMS):
+    """``build()`` -> (model, step) under the CURRENT environment; runs ``warmup`` untimed steps and returns
+    (model, step, info) with info = {"form", "attempts", "fallback_reason"}.  world == 1: a plain warm-up."""
+    import math
+    import torch
+    import torch.distributed as dist
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    if world <= 1:
+        model, step = build()
+        for i in range(warmup):
+            step(i)
+        return model, step, None
+    on_gpu = torch.device(dev).type == "cuda"
+    host_agree = dist.get_backend() != "nccl"
+    reasons, tried = [], set()
+    for name, env in forms:
+        os.environ.update(env)
+        if _effective_form() in tried:
+            continue                                   # e.g. the configured form already is the three-launch one
+        tried.add(_effective_form())
+        os.environ["SKD_SYNC_TIMEOUT_S"] = str(warm_timeout_s)      # read when the mailboxes are set up (first synchronised layer)
+        model, step = build()
+        failed = None
+        for i in range(warmup):
+            err = None
+            try:
+                losses = step(i)
+                if not all(math.isfinite(float(v)) for v in losses):
+                    err = "non-finite loss in warm-up step %d: %s" % (i, [float(v) for v in losses])
+            except _lib.SkdDeviceError as e:           # raised where a logged scalar is read: every collective of the step has been issued
+                err = str(e)[:300]
+            if on_gpu:
+                torch.cuda.synchronize()
+            words = _lib.device_status()
+            if words and any(words):
+                _lib.get().skd_status_clear()
+                err = err or "device status words %s in warm-up step %d" % (["0x%08x" % w for w in words], i)
+            flag = torch.tensor([1.0 if err else 0.0], device="cpu" if host_agree else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)             # same program point on every rank: nobody is left inside a collective
+            if float(flag) > 0:
+                failed = err or "a peer rank reported a failure in warm-up step %d" % i
+                break
+        if failed is None:
+            P.SyncMailbox.set_timeout_all(run_timeout_s)
+            os.environ["SKD_SYNC_TIMEOUT_S"] = str(run_timeout_s)
+            return model, step, {"form": P.comm_form(), "attempts": len(tried),
+                                 "fallback_reason": "; then ".join(reasons) if reasons else None}
+        reasons.append("'%s' (%s): %s" % (name, P.comm_form(), failed))
+        del model, step
+        if on_gpu:
+            torch.cuda.synchronize()
+        P.SyncMailbox.reset()
+        _lib.get().skd_status_clear()
+        if on_gpu:
+            torch.cuda.empty_cache()
+        dist.barrier()
+    raise SystemExit("bench.py: every form of the cross-replica exchange failed its warm-up: " + "; then ".join(reasons))
+
+
 def main():
     a = parse()
     import torch
@@ -245,8 +356,9 @@ def main():
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
 
     # a benchmark run must fail fast: an exchange that waits for a peer longer than this poisons its outputs and raises
-    # SkdDeviceError at the next step (training keeps the library's 600 s, what torch.distributed would have waited)
-    os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "120")
+    # SkdDeviceError at the next step (training keeps the library's 600 s, what torch.distributed would have waited); during the
+    # warm-up the limit is shorter still (warm_up_with_fallback)
+    run_timeout = float(os.environ.get("SKD_SYNC_TIMEOUT_S", "120"))
     os.environ.setdefault("SKD_DIST_TIMEOUT_S", "300")       # torch.distributed collectives: same idea (utils/parallel.init_distributed)
     rank, world, local = P.init_distributed()
     if world != a.gpus:
@@ -256,10 +368,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
-    torch.manual_seed(1234)
     # args.batch_size is the reference's GLOBAL batch (nn.DataParallel scatters it); every rank holds a.batch images
     args = default_args(batch_size=a.batch * world, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000)
-    model = NetModel(args)
     gen = torch.Generator().manual_seed(100 + rank)
     images = (torch.randn(a.batch, 3, a.size, a.size, generator=gen) * 57.0).to(dev)
     labels = torch.randint(0, 19, (a.batch, a.size, a.size), generator=gen)
@@ -267,12 +377,17 @@ def main():
     labels = labels.to(dev)
     data = (images, labels, None, None)
 
-    def step(i):
-        model.adjust_learning_rate(args.lr_g, model.G_solver, i)
-        model.adjust_learning_rate(args.lr_d, model.D_solver, i)
-        model.set_input(data)
-        model.optimize_parameters()
-        return (model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss)  # print_info's reads
+    def build():
+        torch.manual_seed(1234)
+        model = NetModel(args)
+
+        def step(i):
+            model.adjust_learning_rate(args.lr_g, model.G_solver, i)
+            model.adjust_learning_rate(args.lr_d, model.D_solver, i)
+            model.set_input(data)
+            model.optimize_parameters()
+            return (model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss)  # print_info's reads
+        return model, step
 
     def fence():
         torch.cuda.synchronize()
@@ -280,8 +395,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
+    # W untimed warm-up steps; N > 1: under a short in-kernel wait limit, with a collective verdict after every step and a
+    # re-initialisation in the next safer form of the SyncABN exchange if any rank saw a device error (the line says which form ran)
+    model, step, comm_setup = warm_up_with_fallback(build, a.warmup, world, dev, run_timeout_s=run_timeout)
     timed = ["skd_abn_apply_nhwc", "skd_abn_apply", "skd_abn_apply_residual", "skd_abn_forward_train", "skd_abn_backward",
              "skd_abn_forward_train_to", "skd_abn_relu_backward_reduce", "skd_abn_relu_backward_dx",
              "skd_abn_forward_train_nhwc", "skd_abn_backward_reduce_nhwc", "skd_abn_backward_dx_nhwc",
@@ -343,7 +459,8 @@ def main():
                 sf = spans.get("syncabn_fused", (0.0, 0))
                 nb = len(model._s_reducer.buckets) + len(model._d_reducer.buckets)
                 mb = sum(b.flat.numel() * 4 for r in (model._s_reducer, model._d_reducer) for b in r.buckets) / 1e6
-                comm = {"syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": (sa[1] + sf[1]) // 3,
+                comm = {"form": comm_setup["form"], "fallback_reason": comm_setup["fallback_reason"], "forms_tried": comm_setup["attempts"],
+                        "syncabn_ms": round(sa[0] / 3, 3), "syncabn_collectives": (sa[1] + sf[1]) // 3,
                         # exchanges performed INSIDE the library's synchronised ABN calls (one register-resident launch when
                         # the tensor fits); the span is the whole pass (statistics + exchange + normalise), not the exchange alone
                         "syncabn_in_abn_calls": sf[1] // 3, "abn_sync_call_ms": round(sf[0] / 3, 3),
@@ -376,7 +493,8 @@ def main():
                    "losses_last_step": {k: round(float(v), 6) for k, v in
                                         zip(("G", "mc", "pi", "pa", "D"), losses)}},
     }
-    executed = STEP_TFLOP_PER_IMAGE - (FOLD_TFLOP_PER_IMAGE if os.environ.get("SKD_PSP_FOLD", "1") == "1" else 0.0)
+    from structure_knowledge_distillation_amd.networks import pspnet_combine as _PC
+    executed = STEP_TFLOP_PER_IMAGE - (FOLD_TFLOP_PER_IMAGE if _PC.PSP_FOLD else 0.0)
     line["step_tflop_per_image"] = {"reference_algorithm": STEP_TFLOP_PER_IMAGE, "executed": round(executed, 4)}
     line["step_fp32_mfma_frac"] = round(value / world * executed / MFMA_F32_PEAK_TFLOPS, 4)   # executed flops only
     ap = summarise(recs.get(roofline_entry, []), 8, nhwc="apply")
@@ -437,6 +555,8 @@ def main():
             worst = min(line["kernels"].items(), key=lambda kv: kv[1]["achieved_GBs"] if kv[1]["avg_elems"] >= (1 << 20) else 1e9)
             line["roofline"]["worst_other_kernel"] = {"entry": worst[0], "achieved_GBs": worst[1]["achieved_GBs"],
                                                       "frac": round(worst[1]["achieved_GBs"] / HBM_PEAK_GBS, 4)}
+    if comm is None and comm_setup is not None:          # --no-kernel-timing: still say which form of the exchange ran
+        comm = {"form": comm_setup["form"], "fallback_reason": comm_setup["fallback_reason"], "forms_tried": comm_setup["attempts"]}
     if comm is not None:
         line["comm"] = comm
     if world == 1 and not a.no_pairwise_sweep:
@@ -462,7 +582,7 @@ def main():
             el2 = time.perf_counter() - t1
             line["informative_teacher_dsn_head_skipped"] = {
                 "ms_per_step": round(1e3 * el2 / n2, 3), "images_per_sec": round(a.batch * n2 / el2, 3), "steps": n2,
-                "note": "SKD_TEACHER_DSN=0: 0.32 TFLOP per step of dead work less (the head's output feeds only the teacher CE the reference "
+                "note": "model.teacher.skip_dsn = True: 0.32 TFLOP per step of dead work less (the head's output feeds only the teacher CE the reference "
                         "discards); losses, gradients and updates are unchanged; NOT the benched configuration"}
         except Exception as e:                       # an extra must never cost the line
             line["informative_teacher_dsn_head_skipped"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}

@@ -244,10 +244,10 @@ int64_t skd_pairwise_workspace_floats(int B, int M);
 int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *fhat_s,
                            const float *fhat_t, float *G, float *loss, float *workspace,
                            skd_stream_t stream);
-/* fhat_s (B, Cs, ldm): the normalised student panel the forward already holds (no node-major copy since round 3: the
- * kernel transposes it on the way into LDS); grad_loss [1] on the device; dpooled (B, Cs, ldm), columns >= M zero.
+/* fhat_s (B, Cs, ldm): the normalised student panel the forward already holds (the entry makes its own node-major copy in the
+ * workspace: round 5); grad_loss [1] on the device; dpooled (B, Cs, ldm), columns >= M zero.
  * The contraction over the nodes is split over workgroups for large M; the partials are combined in a fixed order
- * (deterministic).  workspace: skd_pairwise_backward_workspace_floats(B, Cs, M) floats, 16-byte aligned. */
+ * (deterministic).  workspace: skd_pairwise_backward_workspace_floats(B, Cs, M) floats, 16-byte aligned, REQUIRED. */
 int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M);
 int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s,
                           const float *G, const float *norm_s, const float *grad_loss,
@@ -262,6 +262,15 @@ int skd_pairwise_small(int B, int Cs, int Ct, int M, const float *pooled_s, cons
 int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float *dpooled,
                           int64_t ldp, const int32_t *index, float *dx /* (planes, H, W) */,
                           skd_stream_t stream);
+
+/* Channels-last forms of the pool / un-pool (round 5): x and dx are (B, H, W, C) with C % 4 == 0 and 16-byte aligned -- the
+ * layout the PSP features have inside NetModel --, pooled / index keep the planar (B, C, OH*OW) order and the flat NCHW
+ * index h*W+w of the entries above (bit-identical results), so the rest of the pair-wise chain is unchanged and no NCHW copy
+ * of the features (17 + 69 MB per step at batch 8) is made for the criterion (utils/criterion.py:241-244). */
+int skd_maxpool_argmax_nhwc(int B, int C, int H, int W, int kh, int kw, const float *x,
+                            float *pooled /* (B, C, OH*OW) */, int32_t *index /* same, or NULL */, skd_stream_t stream);
+int skd_maxunpool_scatter_nhwc(int B, int C, int H, int W, int kh, int kw, const float *dpooled, int64_t ldp,
+                               const int32_t *index, float *dx /* (B, H, W, C) */, skd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 5. Spectral normalisation, networks/spectral.py:23-35 (one power iteration on .data):

@@ -110,6 +110,46 @@ int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float 
   return 1;
 }
 
+/* channels-last forms (include/skd.h section 4): the same scan per channel on (B, H, W, C) data, planar outputs */
+int skd_maxpool_argmax_nhwc(int B, int C, int H, int W, int kh, int kw, const float *x, float *pooled, int32_t *index, stream_t st) {
+  (void)st;
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !x || !pooled) return 0;
+  const int OH = (int)cdiv64(H, kh), OW = (int)cdiv64(W, kw);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int oh = 0; oh < OH; ++oh)
+        for (int ow = 0; ow < OW; ++ow) {
+          const int r0 = oh * kh, c0 = ow * kw;
+          const int r1 = r0 + kh < H ? r0 + kh : H, c1 = c0 + kw < W ? c0 + kw : W;
+          float bv = -INFINITY;
+          int bi = r0 * W + c0;
+          for (int r = r0; r < r1; ++r)
+            for (int q = c0; q < c1; ++q) {
+              const float v = x[(((int64_t)b * H + r) * W + q) * C + c];
+              if (v > bv || v != v) { bv = v; bi = r * W + q; }
+            }
+          const int64_t o = (((int64_t)b * C + c) * OH + oh) * OW + ow;
+          pooled[o] = bv;
+          if (index) index[o] = bi;
+        }
+  return 1;
+}
+
+int skd_maxunpool_scatter_nhwc(int B, int C, int H, int W, int kh, int kw, const float *dpooled, int64_t ldp, const int32_t *index,
+                               float *dx, stream_t st) {
+  (void)st;
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !dpooled || !index || !dx) return 0;
+  const int OH = (int)cdiv64(H, kh), OW = (int)cdiv64(W, kw);
+  memset(dx, 0, sizeof(float) * (size_t)B * H * W * C);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int m = 0; m < OH * OW; ++m) {
+        const int64_t plane = (int64_t)b * C + c;
+        dx[((int64_t)b * H * W + index[plane * OH * OW + m]) * C + c] += dpooled[plane * ldp + m];
+      }
+  return 1;
+}
+
 /* ---- pair-wise similarity ------------------------------------------------------------------- */
 int skd_pairwise_ldm(int M) { return M <= 0 ? 0 : (int)(cdiv64(M, 128) * 128); }
 int64_t skd_pairwise_workspace_floats(int B, int M) { (void)B; (void)M; return 1; }

@@ -140,7 +140,9 @@ static int exchange(sync_ctx *c, unsigned seq, int n, const float *src, int nwor
       const unsigned *flag = (const unsigned *)slot_of(c->mail[c->rank], c->world, parity, r) + w;
       while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > c->timeout_s) {
+        const double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        /* csrc/sync_dev.hpp: a wait that has lasted 0.1 s gives up at once when an earlier exchange already timed out */
+        if (dt > c->timeout_s || (dt > 0.1 && __atomic_load_n(&g_status[0], __ATOMIC_ACQUIRE) != 0u)) {
           __atomic_store_n(&g_status[0], seq | 0x80000000u, __ATOMIC_RELEASE);
           return 0;
         }

@@ -140,13 +140,12 @@ def configure_miopen(force=False):
     6e-7 without; the same kernels put 1.8e-3 on the student's DSN weight gradient at 256 x 256), which the WGAN critic's
     cancelling gradients amplify to per cent, they are NCHW-only (each call is wrapped in layout transposes), and whether
     immediate mode picks them varied between otherwise identical runs.  The step is not slower without them (76.9 vs
-    77.1 ms).  SKD_MIOPEN_WINOGRAD=1 leaves MIOpen's choice alone."""
+    77.1 ms).  MIOpen's own variable wins: MIOPEN_DEBUG_CONV_WINOGRAD=1 in the environment leaves its choice alone."""
     global _configured, MIOPEN_DB_VERSION
     if _configured and not force:
         return _os.environ.get("MIOPEN_USER_DB_PATH")
     _configured = True
-    if _os.environ.get("SKD_MIOPEN_WINOGRAD", "0") != "1":
-        _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+    _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
     if _os.path.isdir(MIOPEN_DB_DIR):
         MIOPEN_DB_VERSION = _miopen_db_version()
         if "MIOPEN_USER_DB_PATH" not in _os.environ:

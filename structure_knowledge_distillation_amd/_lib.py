@@ -71,6 +71,8 @@ SIGNATURES = {
     "skd_pairwise_backward_workspace_floats": (_L, [_I, _I, _I]),
     "skd_pairwise_backward": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "skd_maxunpool_scatter": (_I, [_I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "skd_maxpool_argmax_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_maxunpool_scatter_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
     "skd_spectral_workspace_floats": (_L, [_I, _I]),
     "skd_spectral_norm_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "skd_spectral_norm_backward": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

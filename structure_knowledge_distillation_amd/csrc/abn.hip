@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 4.9-6.0 TB/s when every tensor comes from HBM (PyTorch's own copy_/relu_ reach 5.2-5.9); either alone does
 // nothing.  INSIDE the training step, however, the convolution output is still partly in the Infinity Cache
 // when the apply pass reads it, and the same policy LOWERS the pass from 4.70 to 4.22 TB/s (bench.py A/B) --
-// so the default stays "normal" and SKD_ABN_NT (bit 0 loads, bit 1 stores) is an experiment switch.
+// so the policy is "normal" (apply_nt_mode below).
 __device__ __forceinline__ float4 ldg4(const float *p, bool nt) {
   if (nt) {
     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
@@ -820,15 +820,10 @@ static bool same_phase(const void *a, const void *b) {
   return ((reinterpret_cast<uintptr_t>(a) ^ reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
-// Cache policy of the apply pass (SKD_ABN_NT: bit 0 non-temporal loads, bit 1 non-temporal stores).
-static int apply_nt_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char *e = getenv("SKD_ABN_NT");
-    mode = e != nullptr ? atoi(e) & 3 : 0;
-  }
-  return mode;
-}
+// Cache policy of the planar apply / dx passes (bit 0 non-temporal loads, bit 1 non-temporal stores): normal.  The streaming
+// policy was an experiment switch until round 5; its verdict (+11 % on HBM-cold tensors, -10 % inside the step where the
+// convolution output is still in the Infinity Cache: profiles/r02*) is recorded and the switch is gone.
+static constexpr int apply_nt_mode() { return 0; }
 
 template <bool WRITE_Y>
 static void launch_apply(int act, const Plan &pl, hipStream_t st, const float *x, const float *mean,
@@ -1795,14 +1790,12 @@ static int launch_apply_nhwc_train(int act, const float *x, const float *res, fl
   return ok();
 }
 
-// SKD_ABN_FUSED=0 keeps the two-launch passes (A/B switch); default: the register-resident one-launch passes when they fit
+// SKD_ABN_FUSED=0 keeps the two-launch passes -- the operational switch for a device that is shared with another grid-barrier
+// launch (multi-tenant GPU); default: the register-resident one-launch passes when they fit.  Read on every
+// call (a getenv is nanoseconds beside a launch): tests/test_kernels_gpu.py flips it inside one process.
 static bool fused_enabled() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char *e = getenv("SKD_ABN_FUSED");
-    mode = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
-  return mode == 1;
+  const char *e = getenv("SKD_ABN_FUSED");
+  return !(e != nullptr && e[0] == '0');
 }
 constexpr int kFuseFwdMaxNR = 17, kFuseBwdMaxNR = 9;
 // SKD_ABN_SYNC_FUSED=0: the synchronised entries keep the three-launch form (statistics, exchange kernel, normalise): A/B switch

@@ -262,17 +262,6 @@ __global__ void pack_eval_params_kernel(int K, const float *__restrict__ mean, c
   pack[3 * (int64_t)K + k] = bias != nullptr ? bias[k] : 0.f;
 }
 
-// SKD_GEMM_TILE_ORDER="ct,pm" overrides the super-tile geometry (counter experiments: tools/conv1x1_bench.py); "0" = the
-// round-3 panel-major order everywhere
-static void tile_order_override(int &ct, int &pm) {
-  const char *e = getenv("SKD_GEMM_TILE_ORDER");
-  if (e == nullptr || e[0] == 0) return;
-  int a = 0, b = 0;
-  const int n = sscanf(e, "%d,%d", &a, &b);
-  if (n == 1 && a == 0) { ct = 1 << 20; pm = 1; }
-  else if (n == 2 && a > 0 && b > 0) { ct = a; pm = b; }
-}
-
 template <int ACT, bool HAS_RES, bool PRO>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
                   const float *weight, const float *bias, const float *ppack, float eps, float slope, int64_t M, int K, int N,
@@ -290,8 +279,9 @@ static int launch(const float *X, const float *Wt, const float *R, float *Y, con
   const int64_t tiles_m = cdiv(M, kTM);
   // super-tile geometry (see the kernel): column-tile chunks of <= 1 MB of weights, panel groups of <= 2 MB of activations
   const int64_t tile_bytes = (int64_t)kTN * K * sizeof(float);
+  // (ten geometries were swept with the counters: profiles/r04g_pmc.json, profiles/r04h_two_ranks_one_gpu_bisect.txt; this is the
+  // one that minimised L2 -> fabric reads at K = 512 / N = 2048: 851 -> 617 MB per launch)
   int ct = (int)((1 << 20) / tile_bytes), pm = (int)((2 << 20) / tile_bytes);
-  tile_order_override(ct, pm);
   if (ct < 1) ct = 1;
   if (pm < 1) pm = 1;
   if (ct >= tiles_n) { ct = tiles_n; pm = 1; }              // narrow output: plain panel-major order

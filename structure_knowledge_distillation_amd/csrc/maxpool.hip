@@ -54,34 +54,72 @@ __global__ __launch_bounds__(kThreads) void maxpool3x3s2_nhwc_kernel(const float
   if (ARG) *reinterpret_cast<uchar4 *>(arg + item * 4) = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
 }
 
+// Backward, gather form over 2 x 2 INPUT blocks (round 5): the four positions (2i, 2j) .. (2i+1, 2j+1) only ever belong to the four
+// windows (i, j), (i, j+1), (i+1, j), (i+1, j+1) -- with the codes below -- so a lane loads those four (gradient quad + argmax
+// bytes) once and writes four 16-byte results, instead of one lane per position re-reading 1 / 2 / 2 / 4 windows (9 loads of
+// 20 bytes for 64 bytes written; measured 2.3 TB/s).  Same terms in the same order per position
+// (windows in (oy, ox) order): bit-identical to the one-position form.
+//   position      window (i, j)   (i, j+1)   (i+1, j)   (i+1, j+1)
+//   (2i,   2j)        4
+//   (2i,   2j+1)      5              3
+//   (2i+1, 2j)        7                         1
+//   (2i+1, 2j+1)      8              6          2           0
 __global__ __launch_bounds__(kThreads) void maxpool3x3s2_bwd_nhwc_kernel(const float *__restrict__ dy,
                                                                         const uint8_t *__restrict__ arg,
                                                                         float *__restrict__ dx, int64_t items, int H, int W,
-                                                                        int OH, int OW, int C4) {
+                                                                        int OH, int OW, int C4, int H2, int W2) {
   const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (item >= items) return;
   const int q = (int)(item % C4);
-  const int xx = (int)((item / C4) % W);
-  const int yy = (int)((item / ((int64_t)C4 * W)) % H);
-  const int b = (int)(item / ((int64_t)C4 * W * H));
-  // windows (oy, ox) with 2*o - 1 <= pos <= 2*o + 1
-  const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1, ox0 = xx >> 1, ox1 = (xx + 1) >> 1;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int oy = oy0; oy <= oy1; ++oy) {
-    if (oy >= OH) continue;
-    for (int ox = ox0; ox <= ox1; ++ox) {
-      if (ox >= OW) continue;
-      const int code = (yy - (2 * oy - 1)) * 3 + (xx - (2 * ox - 1));
+  const int j = (int)((item / C4) % W2);
+  const int i = (int)((item / ((int64_t)C4 * W2)) % H2);
+  const int b = (int)(item / ((int64_t)C4 * W2 * H2));
+  float4 g[4];
+  uchar4 a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int oy = i + (k >> 1), ox = j + (k & 1);
+    if (oy < OH && ox < OW) {
       const int64_t o = ((((int64_t)b * OH + oy) * OW + ox) * C4 + q) * 4;
-      const uchar4 a = *reinterpret_cast<const uchar4 *>(arg + o);
-      const float4 g = *reinterpret_cast<const float4 *>(dy + o);
-      if (a.x == code) acc.x += g.x;
-      if (a.y == code) acc.y += g.y;
-      if (a.z == code) acc.z += g.z;
-      if (a.w == code) acc.w += g.w;
+      a[k] = *reinterpret_cast<const uchar4 *>(arg + o);
+      g[k] = *reinterpret_cast<const float4 *>(dy + o);
+    } else {
+      a[k] = make_uchar4(255, 255, 255, 255);          // no such window: matches no code
+      g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  *reinterpret_cast<float4 *>(dx + item * 4) = acc;
+  auto pick = [](const uchar4 &aa, const float4 &gg, int code, float4 &acc) {
+    if (aa.x == code) acc.x += gg.x;
+    if (aa.y == code) acc.y += gg.y;
+    if (aa.z == code) acc.z += gg.z;
+    if (aa.w == code) acc.w += gg.w;
+  };
+  const int yy = 2 * i, xx = 2 * j;
+  float *out = dx + ((((int64_t)b * H + yy) * W + xx) * C4 + q) * 4;
+  const int64_t dxs = (int64_t)C4 * 4, dys = (int64_t)W * C4 * 4;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  pick(a[0], g[0], 4, r);
+  *reinterpret_cast<float4 *>(out) = r;
+  if (xx + 1 < W) {
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    pick(a[0], g[0], 5, r);
+    pick(a[1], g[1], 3, r);
+    *reinterpret_cast<float4 *>(out + dxs) = r;
+  }
+  if (yy + 1 < H) {
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    pick(a[0], g[0], 7, r);
+    pick(a[2], g[2], 1, r);
+    *reinterpret_cast<float4 *>(out + dys) = r;
+    if (xx + 1 < W) {
+      r = make_float4(0.f, 0.f, 0.f, 0.f);
+      pick(a[0], g[0], 8, r);
+      pick(a[1], g[1], 6, r);
+      pick(a[2], g[2], 2, r);
+      pick(a[3], g[3], 0, r);
+      *reinterpret_cast<float4 *>(out + dys + dxs) = r;
+    }
+  }
 }
 
 bool pool_geom_ok(int B, int C, int H, int W, int OH, int OW) {
@@ -112,9 +150,10 @@ int skd_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const floa
 int skd_maxpool3x3s2_backward_nhwc(int B, int C, int H, int W, int OH, int OW, const float *dy, const uint8_t *arg, float *dx,
                                    skd_stream_t stream) {
   if (!pool_geom_ok(B, C, H, W, OH, OW) || !dy || !arg || !dx) return 0;
-  const int64_t items = (int64_t)B * H * W * (C / 4);
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;          // 2 x 2 input blocks
+  const int64_t items = (int64_t)B * H2 * W2 * (C / 4);
   maxpool3x3s2_bwd_nhwc_kernel<<<dim3((unsigned)cdiv(items, kThreads)), dim3(kThreads), 0, as_stream(stream)>>>(
-      dy, arg, dx, items, H, W, OH, OW, C / 4);
+      dy, arg, dx, items, H, W, OH, OW, C / 4, H2, W2);
   return ok();
 }
 

@@ -169,6 +169,131 @@ __global__ __launch_bounds__(kThreads) void maxunpool_kernel(const float *__rest
 }
 
 // =============================================================================================
+// the same pool / un-pool for CHANNELS-LAST features (B, H, W, C), C a multiple of 4 (round 5)
+// =============================================================================================
+// The PSP features reach the criterion channels-last (both networks run NHWC inside NetModel).  Rounds 1-4 copied them to NCHW
+// first (17 + 69 MB read + written per step) only so that maxpool_band_kernel could read planes.  Here a lane owns one channel
+// QUAD: every load is an aligned 16-byte piece of a row that is contiguous over (w, c), the scan order per channel is PyTorch's
+// (row-major, first maximum wins, a NaN wins over everything and the last NaN wins), and pooled values / argmax indices come
+// out in the reference's planar (B, C, OH * OW) order with the flat NCHW index h * W + w -- bit-identical to the planar kernels.
+struct Cand4 {
+  float v[4];
+  int idx[4];
+};
+__device__ __forceinline__ void scan4(Cand4 &b, const float4 x, int flat) {
+  const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (xv[k] > b.v[k] || xv[k] != xv[k]) {
+      b.v[k] = xv[k];
+      b.idx[k] = flat;
+    }
+}
+
+// LARGE windows (the reference default pools 65 x 65 to 3 x 3): one workgroup per (image, output cell, block of QB channel
+// quads); its 256 lanes = QB quads x S column slots scan the window's rows, then the S candidates of a quad are merged in slot
+// order with the planar kernel's tie rule.  grid: B * OH * OW * ceil(C4 / QB)
+__global__ __launch_bounds__(kThreads) void maxpool_window_nhwc_kernel(const float *__restrict__ x, float *__restrict__ pooled,
+                                                                      int32_t *__restrict__ index, int C4, int H, int W,
+                                                                      int kh, int kw, int OH, int OW, int QB, int S) {
+  __shared__ Cand4 cand[kThreads];
+  const int nblk = (C4 + QB - 1) / QB;
+  const int cb = (int)(blockIdx.x % nblk);
+  const int m = (int)((blockIdx.x / nblk) % (OH * OW));
+  const int b = (int)(blockIdx.x / ((unsigned)nblk * OH * OW));
+  const int q = threadIdx.x % QB, s = threadIdx.x / QB;
+  const int quad = cb * QB + q;
+  const int oh = m / OW, ow = m - oh * OW;
+  const int r0 = oh * kh, r1 = min(H, r0 + kh), c0 = ow * kw, c1 = min(W, c0 + kw);
+  const bool on = s < S && quad < C4;
+  Cand4 best;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    best.v[k] = -INFINITY;
+    best.idx[k] = r0 * W + c0;
+  }
+  if (on) {
+    const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
+    for (int r = r0; r < r1; ++r) {
+      const float *pr = px + (int64_t)r * W * C4 * 4;
+#pragma unroll 4
+      for (int c = c0 + s; c < c1; c += S) scan4(best, *reinterpret_cast<const float4 *>(pr + (int64_t)c * C4 * 4), r * W + c);
+    }
+  }
+  cand[threadIdx.x] = best;
+  __syncthreads();
+  if (s == 0 && quad < C4) {
+    for (int t = 1; t < S; ++t) {
+      const Cand4 &o = cand[t * QB + q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const Cand a{o.v[k], o.idx[k]}, cur{best.v[k], best.idx[k]};
+        if (better(a, cur)) {
+          best.v[k] = a.v;
+          best.idx[k] = a.idx;
+        }
+      }
+    }
+    const int M = OH * OW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t o = ((int64_t)b * C4 * 4 + quad * 4 + k) * M + m;
+      pooled[o] = best.v[k];
+      if (index != nullptr) index[o] = best.idx[k];
+    }
+  }
+}
+
+// SMALL windows (many output cells): one lane per (image, output cell, channel quad)
+__global__ __launch_bounds__(kThreads) void maxpool_cell_nhwc_kernel(const float *__restrict__ x, float *__restrict__ pooled,
+                                                                    int32_t *__restrict__ index, int64_t total, int C4, int H,
+                                                                    int W, int kh, int kw, int OH, int OW) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= total) return;
+  const int quad = (int)(t % C4);
+  const int m = (int)((t / C4) % (OH * OW));
+  const int b = (int)(t / ((int64_t)C4 * OH * OW));
+  const int oh = m / OW, ow = m - oh * OW;
+  const int r0 = oh * kh, r1 = min(H, r0 + kh), c0 = ow * kw, c1 = min(W, c0 + kw);
+  Cand4 best;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    best.v[k] = -INFINITY;
+    best.idx[k] = r0 * W + c0;
+  }
+  const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
+  for (int r = r0; r < r1; ++r)
+    for (int c = c0; c < c1; ++c) scan4(best, *reinterpret_cast<const float4 *>(px + ((int64_t)r * W + c) * C4 * 4), r * W + c);
+  const int M = OH * OW;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t o = ((int64_t)b * C4 * 4 + quad * 4 + k) * M + m;
+    pooled[o] = best.v[k];
+    if (index != nullptr) index[o] = best.idx[k];
+  }
+}
+
+// dense un-pool into a channels-last gradient: every (b, h, w, c) written exactly once, 16 bytes per lane
+__global__ __launch_bounds__(kThreads) void maxunpool_nhwc_kernel(const float *__restrict__ dpooled, const int32_t *__restrict__ index,
+                                                                 float *__restrict__ dx, int64_t total, int C4, int H, int W, int kh,
+                                                                 int kw, int OH, int OW, int64_t ldp) {
+  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= total) return;
+  const int quad = (int)(t % C4);
+  const int e = (int)((t / C4) % ((int64_t)H * W));
+  const int b = (int)(t / ((int64_t)C4 * H * W));
+  const int h = e / W, w = e - h * W;
+  const int M = OH * OW, m = (h / kh) * OW + (w / kw);
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t plane = (int64_t)b * C4 * 4 + quad * 4 + k;
+    o[k] = index[plane * M + m] == e ? dpooled[plane * ldp + m] : 0.f;
+  }
+  *reinterpret_cast<float4 *>(dx + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// =============================================================================================
 // channel L2 norm + normalise into padded buffers
 // =============================================================================================
 // grid (ceil(ldm/64), B); block 256 = 64 nodes x 4 channel slices
@@ -220,28 +345,27 @@ __global__ __launch_bounds__(kThreads) void l2_normalise_kernel(const float *__r
 // Now: segments are plain scalars selected with uniform branches (no arrays, global_load with SGPR bases), the sign is
 // applied once per element when a panel is stored to LDS, the LDS operands of k-step s+1 are fetched before the MFMAs
 // of k-step s are issued (software pipelining in registers), and full K-tiles take a guard-free path.
-// The backward GEMM reads its A operand Fhat_S (B, Cs, ldm) in the layout the forward already has -- node index
-// contiguous -- and transposes it on the way into LDS (TRANS_A: 129-float panel rows, <= 2-way bank conflicts on the scalar
-// stores), so the node-major copy that channel_l2_normalise used to write (and its uncoalesced 4-byte stores, 1.9x the
-// algorithmic traffic) is gone; its K = ldm contraction is split over gridDim.z workgroups with a fixed-order combine.
+// The backward GEMM needs Fhat_S node-major.  Round 2 had channel_l2_normalise write that copy with uncoalesced 4-byte stores
+// (1.9x its algorithmic traffic); rounds 3-4 transposed the channel-major panel on the way into LDS instead (scalar ds_write_b32
+// at a 129-float stride) and the backward sat at 0.53 of the fp32 MFMA peak while the Gram kernel, same tiles, reached 0.63;
+// round 5 makes the copy with a coalesced 32 x 32 LDS transpose inside skd_pairwise_backward (18 MB beside 606 MB of G at
+// M = 4225) so that BOTH GEMMs run the same k-major main loop.  Its K = ldm contraction is split over gridDim.z workgroups with
+// a fixed-order combine.
 // =============================================================================================
 constexpr int kTile = 128;
 constexpr int kBK = 32;             // K-tile: 16 k-steps of v_mfma_f32_32x32x2_f32
-constexpr int kSAT = kTile + 1;     // A-panel row stride (floats) when A is staged through a transpose
-template <bool TRANS_A>
 struct Panels {
-  static constexpr int SA = TRANS_A ? kSAT : kTile;
-  static constexpr int offB = kBK * SA;                 // B panel follows the A panel
-  static constexpr int stage = kBK * SA + kBK * kTile;  // floats per pipeline stage
-  static constexpr size_t lds_bytes = sizeof(float) * 2 * stage;   // double buffered: 64 KiB (64.25 with TRANS_A): 2 workgroups / CU
+  static constexpr int offB = kBK * kTile;                // B panel follows the A panel
+  static constexpr int stage = 2 * kBK * kTile;           // floats per pipeline stage
+  static constexpr size_t lds_bytes = sizeof(float) * 2 * stage;   // double buffered: 64 KiB: 2 workgroups / CU
 };
 
-// One K segment.  A(k, i): k-major -- element at A[k * lda + i] -- or, TRANS_A, i-major -- element at A[i * lda + k], rows
-// i >= rowsA read as zero.  B(k, j) at B[k * ldb + j].  Rows k >= K read as zero (k-major operands only; TRANS_A needs
-// K % kBK == 0).  All tile-local: i, j in [0, 128).
+// One K segment, both operands k-major: A(k, i) at A[k * lda + i], B(k, j) at B[k * ldb + j]; rows k >= K read as zero.
+// All tile-local: i, j in [0, 128).  (Rounds 3-4 also staged an i-major A through a transposing store for the backward GEMM;
+// since round 5 the backward reads a node-major copy instead -- transpose_pad_kernel -- and that path is gone.)
 struct Seg {
   const float *A, *B;
-  int lda, ldb, K, rowsA;
+  int lda, ldb, K;
   float sign;
 };
 
@@ -251,87 +375,59 @@ struct TileRegs {
 
 // (the segment arrives as scalars BY VALUE: a `const Seg &` picked with `first ? s0 : s1` made the compiler keep both structs
 // in scratch memory and re-load the fields -- with a wait -- in front of every K-tile)
-template <bool TRANS_A>
 __device__ __forceinline__ void panel_load(const float *__restrict__ sA, const float *__restrict__ sB, int lda, int ldb, int K,
-                                           int rowsA, int k0, TileRegs &r) {
-  struct { const float *A, *B; int lda, ldb, K, rowsA; } s = {sA, sB, lda, ldb, K, rowsA};
+                                           int k0, TileRegs &r) {
   const int t = threadIdx.x;
-  const int row = t >> 5, c4 = (t & 31) * 4;            // k-major operands: 8 panel rows x 128 columns per pass
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k0 + kBK <= s.K) {                                 // uniform: full K-tile, no guards
+  const int row = t >> 5, c4 = (t & 31) * 4;            // 8 panel rows x 128 columns per pass
+  if (k0 + kBK <= K) {                                   // uniform: full K-tile, no guards
 #pragma unroll
-    for (int h = 0; h < 4; ++h) r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)(k0 + row + 8 * h) * s.ldb + c4);
-    if (!TRANS_A) {
+    for (int h = 0; h < 4; ++h) r.b[h] = *reinterpret_cast<const float4 *>(sB + (int64_t)(k0 + row + 8 * h) * ldb + c4);
 #pragma unroll
-      for (int h = 0; h < 4; ++h) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)(k0 + row + 8 * h) * s.lda + c4);
-    }
+    for (int h = 0; h < 4; ++h) r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)(k0 + row + 8 * h) * lda + c4);
   } else {                                               // last, partial K-tile of a segment: rows k >= K are zero
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int k = k0 + row + 8 * h;
       r.b[h] = zero;
-      if (!TRANS_A) r.a[h] = zero;
-      if (k < s.K) {
-        r.b[h] = *reinterpret_cast<const float4 *>(s.B + (int64_t)k * s.ldb + c4);
-        if (!TRANS_A) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)k * s.lda + c4);
-      }
-    }
-  }
-  if (TRANS_A) {                                         // i-major: 32 rows x 32 k per pass, a lane reads 4 consecutive k
-    const int i = t >> 3, k4 = (t & 7) * 4;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int ii = i + 32 * h;
       r.a[h] = zero;
-      if (ii < s.rowsA) r.a[h] = *reinterpret_cast<const float4 *>(s.A + (int64_t)ii * s.lda + k0 + k4);
+      if (k < K) {
+        r.b[h] = *reinterpret_cast<const float4 *>(sB + (int64_t)k * ldb + c4);
+        r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)k * lda + c4);
+      }
     }
   }
 }
 
-template <bool TRANS_A>
 __device__ __forceinline__ void panel_store(float *st, const TileRegs &r, float sign) {
   const int t = threadIdx.x;
   const int row = t >> 5, c4 = (t & 31) * 4;
 #pragma unroll
-  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(st + Panels<TRANS_A>::offB + (row + 8 * h) * kTile + c4) = r.b[h];
-  if (!TRANS_A) {
+  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(st + Panels::offB + (row + 8 * h) * kTile + c4) = r.b[h];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      float4 v = r.a[h];
-      v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
-      *reinterpret_cast<float4 *>(st + (row + 8 * h) * kTile + c4) = v;
-    }
-  } else {
-    const int i = t >> 3, k4 = (t & 7) * 4;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      float *q = st + k4 * kSAT + i + 32 * h;
-      q[0] = r.a[h].x * sign;
-      q[kSAT] = r.a[h].y * sign;
-      q[2 * kSAT] = r.a[h].z * sign;
-      q[3 * kSAT] = r.a[h].w * sign;
-    }
+  for (int h = 0; h < 4; ++h) {
+    float4 v = r.a[h];
+    v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
+    *reinterpret_cast<float4 *>(st + (row + 8 * h) * kTile + c4) = v;
   }
 }
 
 // 16 k-steps on one LDS stage.  Lane (l31 = lane & 31, kk = lane >> 5) feeds column / row l31 of the 32-wide operand
 // slices with k = 2 * ks + kk; the operands of step ks + 1 are read before the four MFMAs of step ks are issued.
-template <bool TRANS_A>
 __device__ __forceinline__ void tile_compute(const float *st, f32x16 (&acc)[2][2]) {
-  constexpr int SA = Panels<TRANS_A>::SA;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
   const int kk = lane >> 5, l31 = lane & 31;
-  const float *pa = st + kk * SA + wi + l31;
-  const float *pb = st + Panels<TRANS_A>::offB + kk * kTile + wj + l31;
+  const float *pa = st + kk * kTile + wi + l31;
+  const float *pb = st + Panels::offB + kk * kTile + wj + l31;
   float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
   __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two LDS reads (ds_read2_b32) of step 0
 #pragma unroll
   for (int ks = 0; ks < kBK / 2; ++ks) {
     float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
     if (ks + 1 < kBK / 2) {
-      na0 = pa[(ks + 1) * 2 * SA];
-      na1 = pa[(ks + 1) * 2 * SA + 32];
+      na0 = pa[(ks + 1) * 2 * kTile];
+      na1 = pa[(ks + 1) * 2 * kTile + 32];
       nb0 = pb[(ks + 1) * 2 * kTile];
       nb1 = pb[(ks + 1) * 2 * kTile + 32];
     }
@@ -351,7 +447,7 @@ __device__ __forceinline__ void tile_compute(const float *st, f32x16 (&acc)[2][2
 }
 
 // Runs segment s0 then (NSEG == 2) segment s1 through the double-buffered LDS ring into one accumulator set.
-template <bool TRANS_A, int NSEG>
+template <int NSEG>
 __device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds, f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -363,13 +459,12 @@ __device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds
   const int n1 = NSEG == 2 ? (s1.K + kBK - 1) / kBK : 0;
   const int total = n0 + n1;
   if (total == 0) return;
-  constexpr int kStage = Panels<TRANS_A>::stage;
+  constexpr int kStage = Panels::stage;
   TileRegs regs;
   {
     const bool f = n0 > 0;
-    panel_load<TRANS_A>(f ? s0.A : s1.A, f ? s0.B : s1.B, f ? s0.lda : s1.lda, f ? s0.ldb : s1.ldb, f ? s0.K : s1.K,
-                        f ? s0.rowsA : s1.rowsA, 0, regs);
-    panel_store<TRANS_A>(lds, regs, f ? s0.sign : s1.sign);
+    panel_load(f ? s0.A : s1.A, f ? s0.B : s1.B, f ? s0.lda : s1.lda, f ? s0.ldb : s1.ldb, f ? s0.K : s1.K, 0, regs);
+    panel_store(lds, regs, f ? s0.sign : s1.sign);
   }
   __syncthreads();
   int stage = 0;
@@ -378,10 +473,10 @@ __device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds
     const bool more = nx < total;
     const bool first = nx < n0;                         // uniform: which segment the NEXT K-tile belongs to
     if (more)                                           // scalar selects of by-value fields: everything stays in SGPRs
-      panel_load<TRANS_A>(first ? s0.A : s1.A, first ? s0.B : s1.B, first ? s0.lda : s1.lda, first ? s0.ldb : s1.ldb,
-                          first ? s0.K : s1.K, first ? s0.rowsA : s1.rowsA, first ? nx * kBK : (nx - n0) * kBK, regs);
-    tile_compute<TRANS_A>(lds + stage * kStage, acc);
-    if (more) panel_store<TRANS_A>(lds + (stage ^ 1) * kStage, regs, first ? s0.sign : s1.sign);
+      panel_load(first ? s0.A : s1.A, first ? s0.B : s1.B, first ? s0.lda : s1.lda, first ? s0.ldb : s1.ldb,
+                 first ? s0.K : s1.K, first ? nx * kBK : (nx - n0) * kBK, regs);
+    tile_compute(lds + stage * kStage, acc);
+    if (more) panel_store(lds + (stage ^ 1) * kStage, regs, first ? s0.sign : s1.sign);
     __syncthreads();
     stage ^= 1;
   }
@@ -399,7 +494,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
                                                                 float *__restrict__ G,
                                                                 float *__restrict__ part, int Cs,
                                                                 int Ct, int ldm, int nt) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<false>::lds_bytes
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels::lds_bytes
   __shared__ float red[2 * kWavesPerWG];
   const int b = blockIdx.y;
   int ti = 0, rem = blockIdx.x;
@@ -414,16 +509,14 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
   st_.B = ft + (int64_t)b * Ct * ldm + j0;
   st_.lda = st_.ldb = ldm;
   st_.K = Ct;
-  st_.rowsA = kTile;
   st_.sign = 1.f;
   ss_.A = fs + (int64_t)b * Cs * ldm + i0;
   ss_.B = fs + (int64_t)b * Cs * ldm + j0;
   ss_.lda = ss_.ldb = ldm;
   ss_.K = Cs;
-  ss_.rowsA = kTile;
   ss_.sign = -1.f;
   f32x16 acc[2][2];
-  tile_gemm<false, 2>(st_, ss_, lds, acc);
+  tile_gemm<2>(st_, ss_, lds, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
@@ -458,33 +551,53 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
   if (threadIdx.x == 0) part[(int64_t)b * gridDim.x + blockIdx.x] = sq;
 }
 
+// node-major, zero-padded copy of the student panel for the backward GEMM: ft[b][n][c] = fs[b][c][n] (c >= Cs: 0), ldc a multiple
+// of 128.  32 x 32 tiles through LDS; grid (ldm / 32, ldc / 32, B), block 256 = 32 x 8.
+__global__ __launch_bounds__(kThreads) void transpose_pad_kernel(const float *__restrict__ fs, float *__restrict__ ft, int Cs, int ldm,
+                                                                int ldc) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r;
+    tile[ty + 8 * r][tx] = c < Cs ? fs[((int64_t)b * Cs + c) * ldm + n0 + tx] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ft[((int64_t)b * ldm + n0 + ty + 8 * r) * ldc + c0 + tx] = tile[tx][ty + 8 * r];
+}
+
 // backward: D[c][m] = sum_n Fhat_S[c][n] * G[n][m];  dP[c][m] = coef * gscale * D[c][m] / norm[m]
+// Round 5: the A operand comes from a NODE-MAJOR copy of the student panel (transpose_pad_kernel, 18 MB at M = 4225 next to the
+// 606 MB of G), so both operands are k-major and the contraction runs through the very main loop of the Gram kernel.  Rounds 3-4
+// transposed A on the way into LDS (4 scalar ds_write_b32 per 16 bytes at a 129-float stride): 0.53 of the fp32 MFMA peak
+// against the Gram kernel's 0.63 with the same tiles (profiles/r04g_micro.jsonl).
 // grid = (ntm * ntc, B, KS).  KS == 1: the epilogue scales and writes dpooled.  KS > 1: split z contracts the node range
 // [z * kper, (z + 1) * kper) and stores its raw 128 x 128 partial into part[z][b][c][m]; pairwise_bwd_combine_kernel adds the
 // KS partials in index order (deterministic) and applies the scale.
-__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ fs,
+__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ ft,
                                                                    const float *__restrict__ G,
                                                                    const float *__restrict__ norm,
                                                                    const float *__restrict__ gscale,
                                                                    float *__restrict__ dpooled,
                                                                    float *__restrict__ part, int Cs,
-                                                                   int M, int ldm, int ntm, int kper,
+                                                                   int M, int ldm, int ldc, int ntm, int kper,
                                                                    float coef) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<true>::lds_bytes
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels::lds_bytes
   const int b = blockIdx.y, z = blockIdx.z;
   const int tc = blockIdx.x / ntm, tm = blockIdx.x % ntm;
   const int c0 = tc * kTile, m0 = tm * kTile;
   const int kb = z * kper, ke = min(ldm, kb + kper);
   Seg s;
-  s.A = fs + ((int64_t)b * Cs + c0) * ldm + kb;      // A(k = n, i = c) = Fhat_S[c][n]: i-major, transposed while staged
-  s.lda = ldm;
-  s.rowsA = Cs - c0;
+  s.A = ft + ((int64_t)b * ldm + kb) * ldc + c0;     // A(k = n, i = c) = Fhat_S[c][n], node-major copy: k-major
+  s.lda = ldc;
   s.B = G + ((int64_t)b * ldm + kb) * ldm + m0;      // B(k = n, j = m) = G[n][m]
   s.ldb = ldm;
   s.K = ke - kb;
   s.sign = 1.f;
   f32x16 acc[2][2];
-  tile_gemm<true, 1>(s, s, lds, acc);
+  tile_gemm<1>(s, s, lds, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
@@ -692,6 +805,43 @@ int skd_maxunpool_scatter(int planes, int H, int W, int kh, int kw, const float 
   return ok();
 }
 
+// Channels-last variants (include/skd.h section 4): x (B, H, W, C), C % 4 == 0, 16-byte aligned; pooled / index (B, C, OH * OW) in the
+// reference's planar order with the flat NCHW index; dx (B, H, W, C).
+int skd_maxpool_argmax_nhwc(int B, int C, int H, int W, int kh, int kw, const float *x, float *pooled, int32_t *index,
+                            skd_stream_t stream) {
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !x || !pooled) return 0;
+  if ((int64_t)H * W >= (int64_t)1 << 31 || (reinterpret_cast<uintptr_t>(x) & 15)) return 0;
+  hipStream_t st = as_stream(stream);
+  const int OH = (int)cdiv(H, kh), OW = (int)cdiv(W, kw), C4 = C / 4;
+  const int wh = kh < H ? kh : H, ww = kw < W ? kw : W;
+  if ((int64_t)wh * ww >= 64) {
+    const int QB = C4 < 32 ? C4 : 32;
+    int S = kThreads / QB;
+    if (S > ww) S = ww;                                   // no more column slots than window columns
+    const int64_t grid = (int64_t)B * OH * OW * cdiv(C4, QB);
+    if (grid > 2147483647) return 0;
+    maxpool_window_nhwc_kernel<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(x, pooled, index, C4, H, W, kh, kw, OH, OW, QB, S);
+  } else {
+    const int64_t total = (int64_t)B * OH * OW * C4;
+    if (cdiv(total, kThreads) > 2147483647) return 0;
+    maxpool_cell_nhwc_kernel<<<dim3((unsigned)cdiv(total, kThreads)), dim3(kThreads), 0, st>>>(x, pooled, index, total, C4, H, W, kh,
+                                                                                              kw, OH, OW);
+  }
+  return ok();
+}
+
+int skd_maxunpool_scatter_nhwc(int B, int C, int H, int W, int kh, int kw, const float *dpooled, int64_t ldp, const int32_t *index,
+                               float *dx, skd_stream_t stream) {
+  if (B <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || !dpooled || !index || !dx) return 0;
+  if (reinterpret_cast<uintptr_t>(dx) & 15) return 0;
+  const int OH = (int)cdiv(H, kh), OW = (int)cdiv(W, kw), C4 = C / 4;
+  const int64_t total = (int64_t)B * H * W * C4;
+  if (cdiv(total, kThreads) > 2147483647) return 0;
+  maxunpool_nhwc_kernel<<<dim3((unsigned)cdiv(total, kThreads)), dim3(kThreads), 0, as_stream(stream)>>>(dpooled, index, dx, total, C4,
+                                                                                                        H, W, kh, kw, OH, OW, ldp);
+  return ok();
+}
+
 int skd_pairwise_ldm(int M) { return M <= 0 ? 0 : (int)(cdiv(M, kTile) * kTile); }
 
 int skd_channel_l2_normalise(int B, int C, int M, const float *pooled, float *fhat, int ldm,
@@ -717,9 +867,9 @@ static bool gemm_lds_ready() {
   bool &done = *donep;
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<false>::lds_bytes) != hipSuccess) return false;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels::lds_bytes) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<true>::lds_bytes) != hipSuccess) return false;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels::lds_bytes) != hipSuccess) return false;
     done = true;
   }
   return true;
@@ -735,7 +885,7 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   const int nt = ldm / kTile;
   const int ntri = nt * (nt + 1) / 2;
   if (!gemm_lds_ready()) return 0;
-  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), Panels<false>::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace, Cs,
+  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), Panels::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace, Cs,
                                                                                              Ct, ldm, nt);
   if (!ok()) return 0;
   // utils.py:181: / (M*M) / B
@@ -752,11 +902,13 @@ static int bwd_splits(int B, int Cs, int ldm) {
   return ks < 1 ? 1 : (int)ks;
 }
 
+// [node-major copy of the student panel: B * ldm * ldc][KS > 1: KS * B * Cs * ldm partials]
 int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M) {
   if (B <= 0 || Cs <= 0 || M <= 0) return 1;
   const int ldm = skd_pairwise_ldm(M);
   const int ks = bwd_splits(B, Cs, ldm);
-  return ks > 1 ? (int64_t)ks * B * Cs * ldm : 1;
+  const int64_t ldc = cdiv(Cs, kTile) * kTile;
+  return (int64_t)B * ldm * ldc + (ks > 1 ? (int64_t)ks * B * Cs * ldm : 0);
 }
 
 int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, const float *G,
@@ -767,18 +919,21 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, co
   if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(dpooled)) & 15) return 0;
   const int ntm = ldm / kTile, ntc = (int)cdiv(Cs, kTile);
   const int ks = bwd_splits(B, Cs, ldm);
-  if (ks > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return 0;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return 0;
+  const int ldc = ntc * kTile;
+  float *ft = workspace, *part = workspace + (int64_t)B * ldm * ldc;
   // dL/dA_S = -2 G /(M^2 B); dFhat = Fhat (dA + dA^T) = -4/(M^2 B) Fhat G   (G symmetric)
   const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
   if (!gemm_lds_ready()) return 0;
   hipStream_t st = as_stream(stream);
   int kper = (int)(cdiv(cdiv(ldm, kBK), ks) * kBK);      // node range per split, a multiple of the K-tile
-  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B, ks), dim3(kThreads), Panels<true>::lds_bytes, st>>>(
-      fhat_s, G, norm_s, grad_loss, dpooled, ks > 1 ? workspace : nullptr, Cs, M, ldm, ntm, kper, coef);
+  transpose_pad_kernel<<<dim3((unsigned)(ldm / 32), (unsigned)(ldc / 32), B), dim3(kThreads), 0, st>>>(fhat_s, ft, Cs, ldm, ldc);
+  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B, ks), dim3(kThreads), Panels::lds_bytes, st>>>(
+      ft, G, norm_s, grad_loss, dpooled, ks > 1 ? part : nullptr, Cs, M, ldm, ldc, ntm, kper, coef);
   if (!ok()) return 0;
   if (ks > 1) {
     pairwise_bwd_combine_kernel<<<dim3((unsigned)cdiv(ldm / 4, kThreads), Cs, B), dim3(kThreads), 0, st>>>(
-        workspace, norm_s, grad_loss, dpooled, ks, B, Cs, M, ldm, coef);
+        part, norm_s, grad_loss, dpooled, ks, B, Cs, M, ldm, coef);
     return ok();
   }
   return 1;

@@ -77,10 +77,22 @@ __device__ __forceinline__ bool sync_exchange(const SyncArgs &a, int word_lo, in
   if (t < nflags) {
     const int writer = t / nwords, w = word_lo + t % nwords;
     const unsigned *flag = reinterpret_cast<const unsigned *>(slot_of(d.mail[d.rank], d.world, parity, writer)) + w;
+    // A wait gives up after a.spin_ticks -- or, once it has lasted 0.1 s, as soon as an EARLIER exchange of this process has
+    // already timed out (its status word is still raised: the host has not consumed it yet).  The step is poisoned by then
+    // anyway; without this every one of the 58 exchanges of a step would sit out the full limit for a peer that is gone, and
+    // a benchmark / trainer that wants to fall back to another transport (bench.py --gpus N) would wait an hour to learn it.
+    // The word lives in host memory: it is only looked at from waits that are already long (never on the fast path).
     const uint64_t t0 = wall_clock64();
+    uint64_t look = kSyncTicksPerSecond / 10;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > a.spin_ticks) {
+      const uint64_t dt = wall_clock64() - t0;
+      bool give_up = dt > a.spin_ticks;
+      if (!give_up && dt > look && a.status != nullptr) {
+        give_up = __hip_atomic_load(a.status + kStatusSyncTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        look += kSyncTicksPerSecond / 100;
+      }
+      if (give_up) {
         *ok_s = 0u;
         raise_status(a.status, kStatusSyncTimeout, a.seq | 0x80000000u);
         break;

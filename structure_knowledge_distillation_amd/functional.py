@@ -634,14 +634,52 @@ def sim_dis(f_s, f_t):
     return _SimDis.apply(f_s, f_t.detach())
 
 
+def _channels_last_quads(t):
+    """A (B, C, H, W) tensor that is stored channels-last with whole channel quads: the layout the PSP features have inside
+    NetModel -- the pooling kernels read it as it is (skd_maxpool_argmax_nhwc) instead of through an NCHW copy."""
+    return (t.dim() == 4 and t.shape[1] % 4 == 0 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+            and t.data_ptr() % 16 == 0)
+
+
+def _pool_feature(lib, t, kh, kw, pooled, index, st):
+    """pooled (B, C, M) / int32 argmax (flat h * W + w, or None) of MaxPool2d((kh, kw), ceil_mode=True) for either layout.
+    Returns the tensor that was read (the caller keeps its layout for the backward)."""
+    b, c, h, w = t.shape
+    if _channels_last_quads(t):
+        _lib.check(lib.skd_maxpool_argmax_nhwc(b, c, h, w, kh, kw, t.data_ptr(), pooled.data_ptr(), _lib.ptr(index), st),
+                   "skd_maxpool_argmax_nhwc")
+        return t
+    t = t if t.is_contiguous() else t.contiguous()
+    _lib.check(lib.skd_maxpool_argmax(b * c, h, w, kh, kw, t.data_ptr(), pooled.data_ptr(), _lib.ptr(index), st), "skd_maxpool_argmax")
+    return t
+
+
+def _unpool_feature(lib, nhwc, geom, dp, ldp, index, st):
+    """d loss / d feature from the pooled gradient dp (B, C, ldp) through the argmax, in the layout the feature had."""
+    b, cs, h, w, kh, kw = geom
+    if nhwc:
+        dx = torch.empty_strided((b, cs, h, w), (h * w * cs, 1, w * cs, cs), dtype=dp.dtype, device=dp.device)   # channels-last
+        _lib.check(lib.skd_maxunpool_scatter_nhwc(b, cs, h, w, kh, kw, dp.data_ptr(), ldp, index.data_ptr(), dx.data_ptr(), st),
+                   "skd_maxunpool_scatter_nhwc")
+        return dx
+    dx = dp.new_empty((b, cs, h, w))
+    _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dp.data_ptr(), ldp, index.data_ptr(), dx.data_ptr(), st),
+               "skd_maxunpool_scatter")
+    return dx
+
+
 class _PairWise(Function):
     """Whole Pa loss in one node: pool(+argmax) -> normalise -> Gram/loss; backward scatters the
-    pooled gradient straight from the padded GEMM output (no slice/copy in between)."""
+    pooled gradient straight from the padded GEMM output (no slice/copy in between).  Features may arrive NCHW-contiguous or
+    channels-last (round 5: NetModel hands the PSP features over as they are); the student's gradient comes back in the
+    layout its feature had."""
 
     @staticmethod
     def forward(ctx, feat_s, feat_t, kh, kw):
         _lib.require_device(feat_s, feat_t)
-        feat_s, feat_t = _f32c(feat_s, "pair_wise_loss"), _f32c(feat_t, "pair_wise_loss")
+        for t in (feat_s, feat_t):
+            if t.dtype != torch.float32:
+                raise TypeError("pair_wise_loss: fp32 tensors only (got %s)" % t.dtype)
         b, cs, h, w = feat_s.shape
         ct = feat_t.shape[1]
         assert feat_t.shape[0] == b and tuple(feat_t.shape[2:]) == (h, w)
@@ -649,15 +687,14 @@ class _PairWise(Function):
         m = oh * ow
         lib, st = _lib.get(), _lib.stream_of(feat_s)
         need = ctx.needs_input_grad[0]
+        ctx.nhwc = _channels_last_quads(feat_s)
         if m <= 64:
             # small graphs (the reference default pools to 3 x 3 = 9 nodes): pool, then ONE fused launch for
             # normalise + both Grams + loss + gradient w.r.t. the pooled student features
             p_s, p_t = feat_s.new_empty((b, cs, m)), feat_s.new_empty((b, ct, m))
             index = torch.empty((b, cs, m), dtype=torch.int32, device=feat_s.device) if need else None
-            _lib.check(lib.skd_maxpool_argmax(b * cs, h, w, kh, kw, feat_s.data_ptr(), p_s.data_ptr(), _lib.ptr(index), st),
-                       "skd_maxpool_argmax")
-            _lib.check(lib.skd_maxpool_argmax(b * ct, h, w, kh, kw, feat_t.data_ptr(), p_t.data_ptr(), None, st),
-                       "skd_maxpool_argmax")
+            _pool_feature(lib, feat_s, kh, kw, p_s, index, st)
+            _pool_feature(lib, feat_t, kh, kw, p_t, None, st)
             loss = feat_s.new_empty(())
             dp = feat_s.new_empty((b, cs, m)) if need else None
             ws = feat_s.new_empty((b,))
@@ -672,10 +709,8 @@ class _PairWise(Function):
         p_s = feat_s.new_empty((b, cs, m))
         p_t = feat_s.new_empty((b, ct, m))
         index = torch.empty((b, cs, m), dtype=torch.int32, device=feat_s.device) if need else None
-        _lib.check(lib.skd_maxpool_argmax(b * cs, h, w, kh, kw, feat_s.data_ptr(), p_s.data_ptr(),
-                                          _lib.ptr(index), st), "skd_maxpool_argmax")
-        _lib.check(lib.skd_maxpool_argmax(b * ct, h, w, kh, kw, feat_t.data_ptr(), p_t.data_ptr(),
-                                          None, st), "skd_maxpool_argmax")
+        _pool_feature(lib, feat_s, kh, kw, p_s, index, st)
+        _pool_feature(lib, feat_t, kh, kw, p_t, None, st)
         fh_s = feat_s.new_empty((b, cs, ldm))
         fh_t = feat_s.new_empty((b, ct, ldm))
         norm_s = feat_s.new_empty((b, m)) if need else None
@@ -704,10 +739,7 @@ class _PairWise(Function):
             b, cs, h, w, kh, kw, m, _, _ = ctx.geom
             lib, st = _lib.get(), _lib.stream_of(dp)
             dpg = dp * gl.to(torch.float32)
-            dx = dp.new_empty((b, cs, h, w))
-            _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dpg.data_ptr(), m, index.data_ptr(), dx.data_ptr(), st),
-                       "skd_maxunpool_scatter")
-            return dx, None, None, None
+            return _unpool_feature(lib, ctx.nhwc, (b, cs, h, w, kh, kw), dpg, m, index, st), None, None, None
         fh_s, g, norm_s, index = ctx.saved_tensors
         if g is None:
             return None, None, None, None
@@ -719,10 +751,7 @@ class _PairWise(Function):
         _lib.check(lib.skd_pairwise_backward(b, cs, m, ldm, fh_s.data_ptr(), g.data_ptr(),
                                              norm_s.data_ptr(), gl.data_ptr(), dp.data_ptr(), ws.data_ptr(), st),
                    "skd_pairwise_backward")
-        dx = g.new_empty((b, cs, h, w))
-        _lib.check(lib.skd_maxunpool_scatter(b * cs, h, w, kh, kw, dp.data_ptr(), ldm, index.data_ptr(),
-                                             dx.data_ptr(), st), "skd_maxunpool_scatter")
-        return dx, None, None, None
+        return _unpool_feature(lib, ctx.nhwc, (b, cs, h, w, kh, kw), dp, ldm, index, st), None, None, None
 
 
 def pair_wise_loss(feat_s, feat_t, kh, kw):

@@ -441,7 +441,7 @@ class _ABNRelu(autograd.Function):
         ctx.has_residual = residual is not None
         # without a residual the ReLU mask is a function of x alone: the channels-last backward recomputes it instead of
         # reading `out` (which stays alive anyway as the next layer's input, but is not touched again here)
-        ctx.mask_from_x = geo.nhwc and residual is None and os.environ.get("SKD_ABN_MASK_FROM_X", "1") == "1"
+        ctx.mask_from_x = geo.nhwc and residual is None        # (A/B of round 2: profiles/r02h, 67.8 -> 66.2 ms per step)
         ctx.save_for_backward(x, None if ctx.mask_from_x else out, weight, bias, mean, var)
         return out
 

@@ -14,7 +14,7 @@ What differs from the reference, none of it changing a number the step produces:
   * the four logged scalars are kept as device tensors and read back lazily (one host sync when
     ``print_info`` / the attributes are read, instead of four ``.item()`` stalls inside the step);
   * the teacher's cross-entropy, which the reference computes and discards (kd_model.py:129), is not computed
-    (``SKD_TEACHER_CE=1`` / ``model.log_teacher_ce = True`` computes it, forward only, and keeps it as ``mc_T_loss``);
+    (``model.log_teacher_ce = True`` computes it, forward only, and keeps it as ``mc_T_loss``);
   * while the student loss is back-propagated through D (kd_model.py:148-150) D's parameters do not
     require grad: the reference computes those weight gradients and then zeroes them (kd_model.py:154).
 """
@@ -159,9 +159,9 @@ class NetModel():
         self.parallel_student = self.DataParallelModelProcess(student, 2, "train", device)
         self.student = student
         parallel_old.broadcast_module(student)      # every replica starts from rank 0's weights
-        # Channels-last student (SKD_STUDENT_NHWC=1): every convolution NHWC-native in MIOpen, InPlace-ABN through the
-        # skd_abn_*_nhwc training kernels.  Needs the find-db tuned for the NHWC problems (tools/miopen_tune.py).
-        self.student_nhwc = (os.environ.get("SKD_STUDENT_NHWC", "1") == "1" and torch.device(device).type == "cuda")
+        # Channels-last student: every convolution NHWC-native in MIOpen, InPlace-ABN through the skd_abn_*_nhwc training kernels
+        # (the shipped find-db is tuned for the NHWC problems, tools/miopen_tune.py; A/B of round 1: -1.9 ms per step).
+        self.student_nhwc = torch.device(device).type == "cuda"
         if self.student_nhwc:
             os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
             student.to(memory_format=torch.channels_last)
@@ -177,7 +177,7 @@ class NetModel():
         # The frozen teacher runs channels-last: MIOpen's fastest fp32 kernels on gfx950 are NHWC igemm kernels, and
         # with NCHW tensors MIOpen wraps each of them in NCHW<->NHWC transposes (5.6 ms per step, profiles/).  Its
         # eval-mode BN (+ReLU, +residual) has an NHWC kernel (skd_abn_apply_nhwc).
-        self.teacher_nhwc = (os.environ.get("SKD_TEACHER_NHWC", "1") == "1" and torch.device(device).type == "cuda")
+        self.teacher_nhwc = torch.device(device).type == "cuda"
         if self.teacher_nhwc:
             os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
             teacher.to(memory_format=torch.channels_last)
@@ -230,10 +230,10 @@ class NetModel():
                           if (os.environ.get("SKD_D_STREAM", "1") == "1" and torch.device(device).type == "cuda") else None)
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
-        self.log_teacher_ce = os.environ.get("SKD_TEACHER_CE", "0") == "1"
-        # preds_T[1] (the teacher's deep-supervision logits) is read by nothing but the teacher CE the reference computes and
-        # discards (kd_model.py:129).  Default: computed anyway, like the reference's forward; SKD_TEACHER_DSN=0 skips it.
-        self.teacher.skip_dsn = os.environ.get("SKD_TEACHER_DSN", "1") == "0" and not self.log_teacher_ce
+        self.log_teacher_ce = False      # True: also compute the teacher's own CE (kd_model.py:129: computed and discarded) as mc_T_loss
+        # preds_T[1] (the teacher's deep-supervision logits) is read by nothing but that CE; it is computed anyway, like the
+        # reference's forward (``model.teacher.skip_dsn = True`` skips it: bench.py --dsn-ab's informative figure, never the default)
+        self.teacher.skip_dsn = False
 
         # MIOpen find mode is opt-in: this ROCm image ships no gfx950 find/kernel database, so "find"
         # JIT-compiles every candidate solver for every convolution shape on a fresh machine.
@@ -255,10 +255,40 @@ class NetModel():
     def _get_scalar(self, key):
         v = self._scalars[key]
         if torch.is_tensor(v):
-            v = v.item()
-            self._scalars[key] = v
-            _lib.raise_on_device_errors()      # the .item() above synchronised: a timed-out in-kernel wait of this step is visible
+            pend = getattr(self, "_scalar_pending", None)
+            if pend is not None and pend[0].get(key) is v:
+                # all logged scalars of the step came back in ONE device-to-host copy (_publish_scalars): wait for it once
+                tensors, host, event = pend
+                event.synchronize()
+                vals = host.tolist()
+                for i, (k, t) in enumerate(tensors.items()):
+                    if self._scalars.get(k) is t:
+                        self._scalars[k] = vals[i]
+                self._scalar_pending = None
+                v = self._scalars[key]
+            else:
+                v = v.item()
+                self._scalars[key] = v
+            _lib.raise_on_device_errors()      # the read above synchronised: a timed-out in-kernel wait of this step is visible
         return v
+
+    def _publish_scalars(self):
+        """End of a step: the logged scalars (device tensors) are packed by one small kernel and sent to a pinned host buffer with
+        ONE asynchronous copy; ``print_info`` / the attribute reads then cost one wait instead of one blocking ``.item()`` each.
+        Measured (profiles/r05a_timeline.md): the five reads of train_and_eval.py:26 were five serial D2H copies ~27 us apart with the
+        GPU idle at every step boundary (the reference stalls four times INSIDE the step, kd_model.py:127-165)."""
+        tensors = {k: v for k, v in self._scalars.items() if torch.is_tensor(v)}
+        if not tensors or not all(t.is_cuda and t.dtype == torch.float32 for t in tensors.values()):
+            self._scalar_pending = None
+            return
+        packed = torch.stack([t.reshape(()) for t in tensors.values()])
+        host = getattr(self, "_scalar_host", None)
+        if host is None or host.numel() != len(tensors):
+            host = self._scalar_host = torch.empty(len(tensors), dtype=torch.float32, pin_memory=True)
+        host.copy_(packed, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(packed.device))
+        self._scalar_pending = (tensors, host, event)
 
     mc_G_loss = property(lambda self: self._get_scalar("mc_G_loss"))
     pi_G_loss = property(lambda self: self._get_scalar("pi_G_loss"))
@@ -292,8 +322,9 @@ class NetModel():
         with torch.no_grad():
             images_T = images.contiguous(memory_format=torch.channels_last) if self.teacher_nhwc else images
             preds_T = self.parallel_teacher.eval()(images_T, parallel=args.parallel)
-            # the three entries the criteria / D read are handed on in the reference's NCHW layout
-            return [None if t is None else t.contiguous() for t in preds_T[:3]] + list(preds_T[3:])
+            # the two logit tensors the criteria / D read are handed on in the reference's NCHW layout (19 channels: no channel
+            # quads); the PSP feature (preds[2], 69 MB at batch 8) stays as it is -- the pair-wise pooling reads channels-last
+            return [None if t is None else t.contiguous() for t in preds_T[:2]] + list(preds_T[2:])
 
     def _teacher_forward(self):
         """kd_model.py:121-122.  The frozen teacher is 100 % static -- same weights, same shapes, no autograd, ~330 launches
@@ -366,8 +397,9 @@ class NetModel():
             return self.parallel_student.train()(self.images, parallel=args.parallel)
         preds = self.parallel_student.train()(self.images.contiguous(memory_format=torch.channels_last),
                                               parallel=args.parallel)
-        # logits / DSN logits / PSP feature go to the criteria and to D in the reference's NCHW layout
-        return [t.contiguous() for t in preds[:3]] + list(preds[3:])
+        # logits / DSN logits go to the criteria and to D in the reference's NCHW layout; the PSP feature (17 MB at batch 8) is
+        # pooled as it is (functional._pool_feature) and its gradient comes back channels-last: no layout copy either way
+        return [t.contiguous() for t in preds[:2]] + list(preds[2:])
 
     def forward(self):
         # kd_model.py:121-123.  (Rounds 2-4 could also issue the teacher on a stream of its own -- +0.7 % -- ; with the teacher a
@@ -425,6 +457,7 @@ class NetModel():
             _lib.raise_on_device_errors()      # a host load, no synchronisation: errors of the steps already executed
         try:
             self._optimize_parameters()
+            self._publish_scalars()
         finally:
             parallel_old.clear_replica_batch()     # the per-rank sample weights belong to THIS step (set_input)
 

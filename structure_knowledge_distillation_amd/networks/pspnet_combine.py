@@ -7,7 +7,6 @@ and ``forward`` returns the same 7-element list ``[logits, dsn, feat_after_psp, 
 the hand-written InPlace-ABN of csrc/abn.hip (``libs``), applied in place on the conv output.
 """
 import functools
-import os
 
 import torch
 import torch.nn as nn
@@ -28,27 +27,26 @@ def _fused(module, x):
     return x.dtype == torch.float32 and (module.training or not torch.is_grad_enabled())
 
 
-def _gemm_tail(x):
-    """SKD_TEACHER_GEMM=1: run the frozen network's stride-1 1x1 convolutions + BN (+ residual) + ReLU as ONE
-    fp32-MFMA GEMM (csrc/conv1x1.hip) instead of MIOpen convolution + the in-place ABN pass.  OFF by default: measured
-    on this MIOpen build (tools/conv1x1_bench.py, profiles/r02*_conv1x1_ab.jsonl) the fused GEMM wins only on the three
-    widest problems (K >= 512 and N >= 1024: 1.01-1.06x) and loses on the K = 256 block tails that dominate the teacher
-    (0.77x), for +2.8 ms per teacher forward overall; MIOpen's own conv+bias+ReLU fusion is a naive kernel here (100x+)."""
-    return (os.environ.get("SKD_TEACHER_GEMM", "0") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
+# The frozen network's fused inference forms.  Each one is algebraically the reference's op sequence (the tests compare the two
+# on the same weights: tests/test_host_cpu.py, tests/test_kernels_gpu.py) and each was kept because its A/B on the step is
+# recorded under profiles/ -- so they are constants of this module, not environment switches (round 5: the SKD_TEACHER_TAIL /
+# SKD_TEACHER_BLAS / SKD_TEACHER_GEMM / SKD_PSP_FOLD / SKD_PSP_MM / SKD_HEAD_MM / SKD_MAXPOOL variables are gone; a test that
+# wants the plain sequence patches the constant).  Inputs the fused forms do not cover (CPU tensors without the kernels'
+# preconditions, graphs in eval mode, other dtypes) take the reference's sequence regardless.
+FUSED_TAIL = True     # conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> relu] as ONE fp32-MFMA GEMM (csrc/conv1x1.hip, round 3):
+                      # bn2 + ReLU applied to the raw 3x3-convolution output on its way into LDS, bn3 + residual + ReLU in the epilogue;
+                      # profiles/r03c_bench_ab_teacher_tail{0,1}.json: -1.1 ... -2.0 ms per step
+BLAS_TAILS = True     # the 1x1 reduce convolutions and stride-1 down-sample branches as library GEMMs with the folded BN (+ ReLU)
+                      # in the epilogue (functional.conv1x1_bn_blas); profiles/r02f: 68.2 -> 66.9 ms per step
+PSP_FOLD = True       # conv3x3(cat(up(priors), feats)) = conv3x3(feats) + fold(priors x W) (csrc/ppm.hip); profiles/r02d: 77.4 -> 72.2 ms
 
 
 def _fused_tail(x):
-    """SKD_TEACHER_TAIL (default 1; 0 = convolution + two in-place ABN passes as in round 2): the frozen bottleneck's tail conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> relu] as ONE
-    fp32-MFMA GEMM (csrc/conv1x1.hip, round 3): bn2 + ReLU applied to the raw 3x3-convolution output on its way into LDS,
-    bn3 + residual + ReLU in the epilogue -- both InPlace-ABN passes of the block tail (33 + 33 per teacher forward) disappear.
-    Measured A/B: profiles/r03c_bench_ab_teacher_tail{0,1}.json (-1.08 ms per step with the first version of the kernel)."""
-    return (os.environ.get("SKD_TEACHER_TAIL", "1") == "1" and not torch.is_grad_enabled() and x.dtype == torch.float32)
+    return FUSED_TAIL and not torch.is_grad_enabled() and x.dtype == torch.float32
 
 
 def _blas_tail(module, x):
-    """Frozen network, fp32, SKD_TEACHER_BLAS != 0: the 1x1 reduce convolutions and stride-1 down-sample branches run as
-    library GEMMs with the folded BN (+ ReLU) in the epilogue (functional.conv1x1_bn_blas)."""
-    return not module.training and not torch.is_grad_enabled() and os.environ.get("SKD_TEACHER_BLAS", "1") == "1"
+    return BLAS_TAILS and not module.training and not torch.is_grad_enabled()
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -100,12 +98,8 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if _fused(self, x):
-            gemm = not self.training and _gemm_tail(x)
             blas = _blas_tail(self, x)
-            if gemm and SF.conv1x1_abn_supported(x, self.conv1):
-                out = SF.conv1x1_abn_eval(x, self.conv1.weight, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight,
-                                          self.bn1.bias, self.bn1.eps, "relu")
-            elif blas and SF.blas_1x1_bn_supported(x, self.conv1):
+            if blas and SF.blas_1x1_bn_supported(x, self.conv1):
                 out = SF.conv1x1_bn_blas(x, self.conv1, self.bn1, relu=True)
             else:
                 out = self.bn1.forward_relu(self.conv1(x))
@@ -125,9 +119,6 @@ class Bottleneck(nn.Module):
                 return SF.conv1x1_abn_eval(c2, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
                                            self.bn3.bias, self.bn3.eps, "relu", residual=residual,
                                            pro=SF.abn_pack_eval_params(self.bn2))
-            if gemm and SF.conv1x1_abn_supported(out, self.conv3):
-                return SF.conv1x1_abn_eval(out, self.conv3.weight, self.bn3.running_mean, self.bn3.running_var, self.bn3.weight,
-                                           self.bn3.bias, self.bn3.eps, "relu", residual=residual)
             return self.bn3.forward_relu(self.conv3(out), residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -177,14 +168,14 @@ class PSPModule(nn.Module):
             # concatenated tensor (no adaptive-pool / upsample / cat launches, no atomics in backward)
             # channels-last feature maps take the channels-last kernels (no layout copies); anything else the NCHW ones
             pooled = SF.ppm_pool(feats, sizes)
-            if nhwc and os.environ.get("SKD_PSP_MM", "1") == "1":
+            if nhwc:
                 # a 1x1 convolution of a (B, C, s, s) channels-last map is the GEMM (B s^2, C) x (C, Cout): one tiny
                 # rocBLAS call instead of MIOpen's ~30 us (forward) / ~100 us (backward) launch sequences per level
                 priors = [stage[2](_conv1x1_as_mm(stage[1], p)) for stage, p in zip(self.stages, pooled)]
             else:
                 priors = [stage[2](stage[1](p)) for stage, p in zip(self.stages, pooled)]
             conv = self.bottleneck[0]
-            if (nhwc and os.environ.get("SKD_PSP_FOLD", "1") == "1" and SF.ppm_fold_supported(feats, sizes) and conv.bias is None
+            if (nhwc and PSP_FOLD and SF.ppm_fold_supported(feats, sizes) and conv.bias is None
                     and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
                     and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels % 4 == 0
                     and all(p.shape[1] == priors[0].shape[1] for p in priors)):
@@ -256,24 +247,21 @@ class ResNet(nn.Module):
             x = self.relu1(self.bn1(self.conv1(x)))
             x = self.relu2(self.bn2(self.conv2(x)))
             x = self.relu3(self.bn3(self.conv3(x)))
-        x = SF.max_pool_stem(x, self.maxpool) if os.environ.get("SKD_MAXPOOL", "1") == "1" else self.maxpool(x)
+        x = SF.max_pool_stem(x, self.maxpool)       # csrc/maxpool.hip for channels-last maps, the stock op otherwise
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
-        # the deep-supervision head feeds only CriterionDSN; a frozen network whose CE nobody computes may skip it
-        # (NetModel sets skip_dsn on the teacher when SKD_TEACHER_DSN=0; default: computed, like the reference)
-        # the 19-class 1x1 classifiers as skinny GEMMs: measured SLOWER than MIOpen here (rocBLAS picks a 311 us kernel for
-        # the 19 x 128 weight gradient over 33800 rows; 67.5 vs 67.2 ms per step), so off unless asked for
-        mm_heads = os.environ.get("SKD_HEAD_MM", "0") == "1"
+        # the deep-supervision head feeds only CriterionDSN; a frozen network whose CE nobody computes may skip it (``skip_dsn``, set by
+        # bench.py --dsn-ab for an informative figure; default: computed, like the reference's forward).  (The 19-class 1x1 classifiers
+        # as skinny GEMMs were measured SLOWER than MIOpen -- rocBLAS picks a 311 us kernel for the 19 x 128 weight gradient over 33800
+        # rows, 67.5 vs 67.2 ms per step -- and that variant is gone.)
         if getattr(self, "skip_dsn", False) and not torch.is_grad_enabled():
             x_dsn = None
-        elif mm_heads:
-            x_dsn = _conv1x1_as_mm(self.dsn[3], self.dsn[2](self.dsn[1](self.dsn[0](x3))))
         else:
             x_dsn = self.dsn(x3)
         x4 = self.layer4(x3)
         x_feat_after_psp = self.pspmodule(x4)
-        x = _conv1x1_as_mm(self.head, x_feat_after_psp) if mm_heads else self.head(x_feat_after_psp)
+        x = self.head(x_feat_after_psp)
         return [x, x_dsn, x_feat_after_psp, x4, x3, x2, x1]
 
 

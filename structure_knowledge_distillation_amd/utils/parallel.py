@@ -24,7 +24,7 @@ import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
            "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
-           "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity", "reserve_for_collectives", "reserved_fused_cap"]
+           "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity", "reserve_for_collectives", "reserved_fused_cap", "sync_fused_over_rccl", "comm_form"]
 
 
 def init_distributed(backend=None):
@@ -48,19 +48,49 @@ def init_distributed(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-            # every RCCL channel is one resident workgroup on (usually) its own compute unit for the length of a collective; the
-            # reserve that reserve_for_collectives() keeps out of the grid-barrier launches is sized for at most this many (65 MB of
-            # gradients per step do not need more; the user's own setting wins)
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+            # RCCL's kernels run BESIDE the step.  The in-kernel SyncABN exchange (one grid-barrier launch per pass that waits for
+            # the peer rank inside the barrier) can close a cross-rank cycle with them (reserve_for_collectives has the argument);
+            # the reserve makes that cycle unlikely, not impossible (other kernels may take the reserved units), and no multi-GPU
+            # box has ever run it.  Same rule as for the teacher hipGraph at N > 1: until a hardware A/B exists the DEFAULT over
+            # RCCL is the three-launch form (statistics / one-workgroup exchange / normalise: no grid barrier, nothing to cycle
+            # with, + ~1 ms per step); SKD_ABN_SYNC_FUSED=1 opts into the in-kernel form, and only then are the compute-unit
+            # reserve and the RCCL channel cap applied (they cost every collective bandwidth and every ABN pass a
+            # quarter of its parallelism, so they must not be process-wide defaults).
+            os.environ.setdefault("SKD_ABN_SYNC_FUSED", "0")
+            if sync_fused_over_rccl():
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if os.environ.get("SKD_DIST_TIMEOUT_S"):
             # how long a collective waits for a peer before the job is torn down (torch's defaults: 10 min RCCL, 30 min gloo);
             # bench.py asks for 5 min: a rank that died must fail the measurement, not park seven GPUs until somebody notices
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SKD_DIST_TIMEOUT_S"]))
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
-        if backend == "nccl" and torch.cuda.is_available() and int(os.environ.get("LOCAL_WORLD_SIZE", ws)) <= max(1, torch.cuda.device_count()):
-            reserve_for_collectives()          # one rank per device over RCCL: its kernels must always find a compute unit
+        if (backend == "nccl" and torch.cuda.is_available() and sync_fused_over_rccl()
+                and int(os.environ.get("LOCAL_WORLD_SIZE", ws)) <= max(1, torch.cuda.device_count())):
+            cap = reserve_for_collectives()    # one rank per device over RCCL: its kernels must always find a compute unit
+            if rk == 0:
+                import logging
+                logging.getLogger(__name__).warning(
+                    "SKD_ABN_SYNC_FUSED=1 over RCCL: one-launch InPlace-ABN passes capped at %s workgroups (SKD_ABN_RCCL_RESERVE_CUS), "
+                    "NCCL_MAX_NCHANNELS=%s", cap, os.environ.get("NCCL_MAX_NCHANNELS"))
     return rk, ws, local
+
+
+def sync_fused_over_rccl():
+    """True when the synchronised InPlace-ABN layers may take the one-launch form (exchange inside the grid-barrier kernel) in a
+    job whose collectives are RCCL kernels: opt-in (SKD_ABN_SYNC_FUSED=1), see init_distributed."""
+    return os.environ.get("SKD_ABN_SYNC_FUSED", "1") == "1"
+
+
+def comm_form(group=None):
+    """How the cross-replica InPlace-ABN statistics travel right now -- what bench.py prints as ``comm.form``."""
+    if world_size(group) <= 1:
+        return "single rank"
+    if not SyncMailbox.active():
+        return "torch.distributed all_gather / all_reduce per exchange (SKD_SYNC_IPC=0 or the mailbox self-test failed)"
+    if os.environ.get("SKD_ABN_SYNC_FUSED", "1") == "1" and os.environ.get("SKD_ABN_FUSED", "1") != "0":
+        return "ipc mailboxes, exchange inside the one-launch ABN kernels where the tensor fits (csrc/abn.hip, sync_dev.hpp)"
+    return "ipc mailboxes, three launches per pass: statistics / one-workgroup exchange kernel / normalise (csrc/sync.hip)"
 
 
 def share_device(ranks_per_device):
@@ -216,10 +246,19 @@ class SyncMailbox:
 
     @classmethod
     def reset(cls):
+        """COLLECTIVE in effect: every rank must drop its mailboxes at the same point of the program (the next ``get`` sets them
+        up again, from sequence number zero, under the SKD_SYNC_IPC / SKD_ABN_SYNC_FUSED settings of that moment)."""
         for _, mb in cls._by_group.values():
             if mb:
                 mb.lib.skd_sync_destroy(mb.ctx)
         cls._by_group.clear()
+
+    @classmethod
+    def set_timeout_all(cls, seconds):
+        """The in-kernel wait limit of every live mailbox context (SKD_SYNC_TIMEOUT_S applies to contexts created later)."""
+        for _, mb in cls._by_group.values():
+            if mb:
+                mb.lib.skd_sync_set_timeout(mb.ctx, float(seconds))
 
     @classmethod
     def _create(cls, group, device):
@@ -251,7 +290,7 @@ class SyncMailbox:
             # inside the kernel) must fit the device together
             here = sum(1 for _, host, d in everyone if host == mine[1] and d == dev_id)
             share_device(here)
-            if here <= 1 and dist.get_backend(group) == "nccl":
+            if here <= 1 and dist.get_backend(group) == "nccl" and sync_fused_over_rccl():
                 reserve_for_collectives(device)         # (also for groups that were not set up by init_distributed)
         if good:
             blob = ctypes.create_string_buffer(b"".join(h for h, _, _ in everyone), nb * w)

@@ -523,3 +523,65 @@ def test_netmodel_step_eight_ranks_matches_reference_dp_semantics():
         for r in range(1, world):
             assert torch.equal(v, outs[r]["running"][k]), k
         assert rel(v, PS[k]) < 1e-5, k
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N: the warm-up's safety net.  Rehearsed on the CPU double: rank 1 is held back in the first
+# warm-up step of the first form for longer than the warm-up's in-kernel wait limit, so rank 0's exchanges time out, raise the
+# device status word and poison the step; the ranks must AGREE on that after the step, drop the model and the mailboxes together,
+# come back in the next form and produce finite losses there -- and the record that bench.py prints as `comm` must say so.
+def _bench_fallback(rank, world):
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import step_torch as O
+    from structure_knowledge_distillation_amd import _lib
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    dev = torch.device("cpu")
+    args = default_args(batch_size=world, ho=False, device=dev, weight_decay=5e-4, lambda_pa=0.5)
+    x, y = O.synthetic_batch(world, 256, 256, seed=5)
+    data = (x[rank:rank + 1], y[rank:rank + 1], None, None)
+    builds = []
+
+    def build():
+        torch.manual_seed(1234)
+        model = NetModel(args)
+        builds.append(dict(os.environ))
+        first_form = len(builds) == 1
+
+        student_forward = model._student_forward
+
+        def late_student_forward():
+            time.sleep(4.0)                         # the peer that never arrives in time (limit below: 1.5 s); set_input's all-gather
+            return student_forward()                # and the teacher are behind it, the first synchronised layer in front
+
+        def step(i):
+            model._student_forward = late_student_forward if (first_form and i == 1 and rank == 1) else student_forward     # (step 0 sets the mailboxes up: collective)
+            model.set_input(data)
+            model.optimize_parameters()
+            return (model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss)
+        return model, step
+
+    os.environ.pop("SKD_ABN_SYNC_FUSED", None)
+    os.environ.pop("SKD_SYNC_IPC", None)
+    model, step, info = bench.warm_up_with_fallback(build, 3, world, dev, warm_timeout_s=1.5, run_timeout_s=20.0)
+    losses = step(3)                                 # the "timed region": the surviving form works
+    return {"info": info, "builds": len(builds), "losses": [float(v) for v in losses], "status": _lib.device_status(),
+            "env": {k: os.environ.get(k) for k in ("SKD_ABN_SYNC_FUSED", "SKD_SYNC_IPC", "SKD_SYNC_TIMEOUT_S")},
+            "mailbox": P.SyncMailbox.active()}
+
+
+@pytest.mark.timeout(900)
+def test_bench_warm_up_falls_back_to_the_next_exchange_form_on_a_device_status_word():
+    outs = _run("_bench_fallback")
+    for r, o in enumerate(outs):
+        assert o["builds"] == 2 and o["info"]["attempts"] == 2, (r, o["builds"], o["info"])
+        assert "three launches per pass" in o["info"]["form"], o["info"]["form"]          # mailboxes kept, no in-kernel exchange
+        assert o["info"]["fallback_reason"] and "as configured" in o["info"]["fallback_reason"], o["info"]
+        assert o["env"] == {"SKD_ABN_SYNC_FUSED": "0", "SKD_SYNC_IPC": None, "SKD_SYNC_TIMEOUT_S": "20.0"}, o["env"]
+        assert o["mailbox"] and not any(o["status"])
+        assert all(v == v and abs(v) < 1e6 for v in o["losses"]), o["losses"]
+    # the reason is a timed-out exchange on at least one rank (the other may only have heard of it through the all-reduce)
+    assert any("timed out" in o["info"]["fallback_reason"] or "status words" in o["info"]["fallback_reason"] for o in outs)
+    assert outs[0]["losses"][0] != outs[1]["losses"][0]          # different shards

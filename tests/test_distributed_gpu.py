@@ -846,6 +846,10 @@ def _worker_nccl(rank, world, port, fn_name, outdir):
                       LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), MIOPEN_LOG_LEVEL="3")
     os.environ.setdefault("SKD_SYNC_TIMEOUT_S", "60")
     os.environ.pop("SKD_DIST_BACKEND", None)
+    if fn_name == "_multi_gpu_plumbing":
+        # the plumbing test is the one that opts into the in-kernel exchange over RCCL (default over RCCL since round 5: the
+        # three-launch form, utils/parallel.init_distributed) -- with the compute-unit reserve that opting in applies
+        os.environ["SKD_ABN_SYNC_FUSED"] = "1"
     torch.set_num_threads(4)
     from structure_knowledge_distillation_amd.utils import parallel as P
     P.init_distributed()                    # picks "nccl", one device per rank, exactly like bench.py under torchrun

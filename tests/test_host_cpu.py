@@ -7,6 +7,8 @@ import os
 import pytest
 import torch
 
+import structure_knowledge_distillation_amd.networks.pspnet_combine as PC_MOD  # noqa: E402  (its fused-form constants are patched by tests)
+
 from oracle import abn_torch, cref, step_torch as O
 from structure_knowledge_distillation_amd import _lib
 
@@ -431,7 +433,7 @@ def test_psp_fold_equals_concat_then_convolution(shape, monkeypatch):
     x = torch.randn(b, cf, h, w).contiguous(memory_format=torch.channels_last)
 
     def run(fold):
-        monkeypatch.setenv("SKD_PSP_FOLD", "1" if fold else "0")
+        monkeypatch.setattr(PC_MOD, "PSP_FOLD", bool(fold))
         for p in m.parameters():
             p.grad = None
         for mod in m.modules():                                   # same running statistics on both runs
@@ -503,25 +505,25 @@ def test_frozen_bottleneck_blas_tail_equals_conv_plus_abn(monkeypatch):
     x = torch.randn(2, 128, 9, 7).contiguous(memory_format=torch.channels_last)
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_BLAS", flag)
+        monkeypatch.setattr(PC_MOD, "BLAS_TAILS", flag == "1")
         with torch.no_grad():
             outs[flag] = blk(x.clone())
     assert rel(outs["1"], outs["0"]) < 2e-6, rel(outs["1"], outs["0"])
     # the folded operands follow the parameters: change a running statistic -> the cache is rebuilt
     blk.bn1.running_var.mul_(2.0)
     for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_BLAS", flag)
+        monkeypatch.setattr(PC_MOD, "BLAS_TAILS", flag == "1")
         with torch.no_grad():
             outs[flag] = blk(x.clone())
     assert rel(outs["1"], outs["0"]) < 2e-6
     # with a graph (eval + grad) the reference sequence is used
-    monkeypatch.setenv("SKD_TEACHER_BLAS", "1")
+    monkeypatch.setattr(PC_MOD, "BLAS_TAILS", True)
     y = blk(x.clone().requires_grad_(True))
     assert y.requires_grad
 
 
 def test_frozen_bottleneck_fused_tail_equals_conv_plus_two_abn_passes(monkeypatch):
-    """SKD_TEACHER_TAIL: conv2 -> ONE GEMM with bn2 + ReLU in its prologue and bn3 + residual + ReLU in its epilogue
+    """pspnet_combine.FUSED_TAIL: conv2 -> ONE GEMM with bn2 + ReLU in its prologue and bn3 + residual + ReLU in its epilogue
     (functional.conv1x1_abn_eval(pro=...), here on the C double) == convolution + the two in-place ABN passes
     (pspnet_combine.py:71-82); the packed bn2 constants are cached on the module and follow its tensors."""
     from structure_knowledge_distillation_amd import functional as SF
@@ -537,7 +539,7 @@ def test_frozen_bottleneck_fused_tail_equals_conv_plus_two_abn_passes(monkeypatc
     x = torch.randn(2, 128, 9, 7).contiguous(memory_format=torch.channels_last)
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_TAIL", flag)
+        monkeypatch.setattr(PC_MOD, "FUSED_TAIL", flag == "1")
         with torch.no_grad():
             outs[flag] = blk(x.clone(memory_format=torch.channels_last))
     assert rel(outs["1"], outs["0"]) < 2e-6, rel(outs["1"], outs["0"])
@@ -547,33 +549,34 @@ def test_frozen_bottleneck_fused_tail_equals_conv_plus_two_abn_passes(monkeypatc
     blk.bn2.running_var.mul_(3.0)                                         # in-place write -> version bump -> repacked
     assert SF.abn_pack_eval_params(blk.bn2) is not pack
     for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_TAIL", flag)
+        monkeypatch.setattr(PC_MOD, "FUSED_TAIL", flag == "1")
         with torch.no_grad():
             outs[flag] = blk(x.clone(memory_format=torch.channels_last))
     assert rel(outs["1"], outs["0"]) < 2e-6
-    monkeypatch.setenv("SKD_TEACHER_TAIL", "1")                           # with a graph the reference sequence is used
+    monkeypatch.setattr(PC_MOD, "FUSED_TAIL", True)                           # with a graph the reference sequence is used
     assert blk(x.clone(memory_format=torch.channels_last).requires_grad_(True)).requires_grad
 
 
-def test_teacher_dsn_head_is_optional_and_everything_else_unchanged(monkeypatch):
-    """SKD_TEACHER_DSN=0 skips the frozen teacher's deep-supervision head -- read by nothing but the teacher CE the reference
-    computes and discards (kd_model.py:129): preds_T[1] is None, every loss of the step is bit-identical to the default."""
+def test_teacher_dsn_head_is_optional_and_everything_else_unchanged():
+    """``model.teacher.skip_dsn = True`` (bench.py --dsn-ab's informative figure; never the default) skips the frozen teacher's
+    deep-supervision head -- read by nothing but the teacher CE the reference computes and discards (kd_model.py:129):
+    preds_T[1] is None, every loss of the step is bit-identical to the default.  ``model.log_teacher_ce`` computes that CE."""
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel
     vals = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_DSN", flag)
+    for skip in (False, True):
         torch.manual_seed(3)
         model = NetModel(_tiny_args(batch_size=2, ho=False))
+        assert model.teacher.skip_dsn is False and model.log_teacher_ce is False        # the defaults: the reference's forward
+        model.teacher.skip_dsn = skip
         x, y = O.synthetic_batch(2, 96, 96)
         torch.manual_seed(17)
         model.set_input((x, y, None, None))
         model.optimize_parameters()
-        assert (model.preds_T[1] is None) == (flag == "0")
-        vals[flag] = [model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss]
-    assert vals["0"] == vals["1"], vals
-    monkeypatch.setenv("SKD_TEACHER_DSN", "0")
-    monkeypatch.setenv("SKD_TEACHER_CE", "1")                 # asking for the teacher CE keeps the head
+        assert (model.preds_T[1] is None) == skip
+        vals[skip] = [model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss]
+    assert vals[False] == vals[True], vals
     model = NetModel(_tiny_args(batch_size=2, ho=False))
+    model.log_teacher_ce = True
     model.set_input((x, y, None, None))
     model.optimize_parameters()
     assert model.preds_T[1] is not None and model.mc_T_loss > 0
@@ -626,3 +629,33 @@ def test_sharded_evaluation_refuses_loaders_that_shard_or_shuffle():
     with pytest.raises(ValueError, match="DistributedSampler"):
         evaluate_main(model, DataLoader(ds, batch_size=1, sampler=DistributedSampler(ds, num_replicas=2, rank=0)), "0", "8,8", 19,
                       whole=True, rank=0, world=2)
+
+
+def test_dist_timeout_and_miopen_find_switches(monkeypatch):
+    """Two operational switches named in INTEGRATION.md: SKD_DIST_TIMEOUT_S becomes the process group's collective time-out
+    (utils.parallel.init_distributed; bench.py asks for 300 s), SKD_MIOPEN_FIND=1 re-enables MIOpen's find mode for shapes the
+    shipped find-db does not hold (NetModel sets torch.backends.cudnn.benchmark from it)."""
+    import datetime
+    import torch.distributed as dist
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel
+    seen = {}
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: seen.update(kw))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("SKD_DIST_TIMEOUT_S", "7.5")
+    assert P.init_distributed("gloo") == (1, 2, 1)
+    assert seen["backend"] == "gloo" and seen["world_size"] == 2 and seen["timeout"] == datetime.timedelta(seconds=7.5)
+    seen.clear()
+    monkeypatch.delenv("SKD_DIST_TIMEOUT_S")
+    P.init_distributed("gloo")
+    assert "timeout" not in seen                                   # torch's default
+    monkeypatch.undo()
+    keep = torch.backends.cudnn.benchmark
+    try:
+        for flag, want in (("1", True), ("0", False)):
+            monkeypatch.setenv("SKD_MIOPEN_FIND", flag)
+            NetModel(_tiny_args(batch_size=2, ho=False))
+            assert torch.backends.cudnn.benchmark is want
+    finally:
+        torch.backends.cudnn.benchmark = keep

@@ -9,10 +9,15 @@ Tolerances (fp32 kernels; the oracle accumulates in double):
   max-pool argmax / pooled value  bit-exact
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
+
+import structure_knowledge_distillation_amd.networks.pspnet_combine as PC_MOD  # noqa: E402  (its fused-form constants are patched by tests)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import cref
 from structure_knowledge_distillation_amd import _lib
@@ -428,6 +433,42 @@ def test_fused_abn_grid_cap_and_device_status_words(hip):
     assert _lib.device_status() == [0] * n
 
 
+def test_operational_switches_of_the_one_launch_abn_passes(hip, monkeypatch):
+    """SKD_ABN_FUSED=0 (a device shared with another grid-barrier launch: INTEGRATION.md) sends the same calls down the two-launch
+    passes -- same numbers; SKD_ABN_FUSED_MAXWG caps the one-launch grids of a process from its environment (read once per device,
+    hence a fresh process)."""
+    import subprocess
+    import sys
+    rows, C = 8 * 65 * 65, 128
+    g = torch.Generator().manual_seed(6)
+    x = gpu(torch.randn(rows, C, generator=g) * 3 + 1)
+    dz = gpu(torch.randn(rows, C, generator=g))
+    w, b = gpu(torch.randn(C, generator=g)), gpu(torch.randn(C, generator=g))
+    ws = torch.empty(hip.skd_abn_nhwc_workspace_floats(rows, C), device=DEV)
+
+    def run():
+        z, st = x.clone(), torch.empty(2, C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        assert hip.skd_abn_forward_train_nhwc(rows, C, P(z), None, P(z), P(w), P(b), P(rm), P(rv), P(st[0]), P(st[1]), 0.1, 1e-5, 1, 0.01, P(ws), None)
+        e, dx, dw, db = torch.empty(2, C, device=DEV), torch.empty(rows, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        assert hip.skd_abn_backward_nhwc(rows, C, P(z), P(dz), P(st[1]), P(w), P(b), P(e[0]), P(e[1]), P(dx), P(dw), P(db), 1e-5, 1, 0.01, 0, P(ws), None)
+        torch.cuda.synchronize()
+        return z, st, rm, rv, e, dx, dw, db
+
+    monkeypatch.delenv("SKD_ABN_FUSED", raising=False)
+    one = run()
+    monkeypatch.setenv("SKD_ABN_FUSED", "0")
+    two = run()
+    monkeypatch.delenv("SKD_ABN_FUSED")
+    for a, c, name in zip(one, two, ("z", "stat", "rm", "rv", "e", "dx", "dw", "db")):
+        close(c, a, 2e-5, name + " (SKD_ABN_FUSED=0 -> two-launch passes)", floor=float(a.abs().max()) * 1e-2)
+    code = ("from structure_knowledge_distillation_amd import _lib; import torch; torch.zeros(1, device='cuda'); "
+            "print('CAP', _lib.load().skd_abn_set_fused_max_workgroups(-1))")
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SKD_ABN_FUSED_MAXWG="24"), cwd=ROOT, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and "CAP 24" in res.stdout, (res.stdout[-300:], res.stderr[-600:])
+
+
 def test_abn_single_sample_running_var_is_finite(hip):
     """One sample per channel (PSP 1x1 stage at batch 1, one replica): the reference's n / (n - 1) poisons
     running_var with NaN; here the biased variance (0) is kept -- DESIGN.md section 7."""
@@ -633,6 +674,50 @@ def test_maxpool_argmax_bit_exact(hip, ref, planes, H, W, kh, kw):
     dxg = torch.full((planes, H, W), 7.0, device=DEV)
     assert hip.skd_maxunpool_scatter(planes, H, W, kh, kw, P(gpu(dp)), OH * OW + 5, P(ig), P(dxg), None)
     assert torch.equal(dxg.cpu(), dxr)
+
+
+NHWC_POOL_CASES = [(2, 128, 65, 65, 32, 32), (1, 512, 65, 65, 32, 32), (2, 8, 33, 33, 16, 16), (2, 12, 65, 65, 8, 8), (1, 16, 65, 65, 4, 4),
+                   (2, 4, 65, 65, 1, 1), (3, 20, 46, 61, 23, 30), (1, 8, 7, 130, 3, 64), (1, 136, 9, 70, 9, 70)]
+
+
+@pytest.mark.parametrize("B,C,H,W,kh,kw", NHWC_POOL_CASES)
+def test_maxpool_argmax_channels_last_bit_exact(hip, ref, B, C, H, W, kh, kw):
+    """skd_maxpool_argmax_nhwc / skd_maxunpool_scatter_nhwc (round 5: the PSP features are pooled as they are, channels-last):
+    pooled values and argmax indices bit-identical to the planar entries on the NCHW copy of the same data -- ties (first
+    maximum wins), NaN (propagates, last one wins), partial border windows, both kernels (window per workgroup / lane per cell)."""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    x[0, 0] = torch.randint(0, 3, (H, W), generator=g).float()
+    x[0, 1] = 1.0                                                   # a constant plane: the very first position of every window
+    x[-1, 2, H // 2, W // 3] = float("nan")
+    x[-1, 2, 0, 0] = float("nan")
+    x[-1, 3] = float("-inf")
+    OH, OW = -(-H // kh), -(-W // kw)
+    M = OH * OW
+    pr, ir = torch.empty(B * C, M), torch.empty(B * C, M, dtype=torch.int32)
+    assert ref.skd_maxpool_argmax(B * C, H, W, kh, kw, P(x), P(pr), P(ir), None)
+    xl = x.permute(0, 2, 3, 1).contiguous()                         # (B, H, W, C)
+    pr2, ir2 = torch.empty(B * C, M), torch.empty(B * C, M, dtype=torch.int32)
+    assert ref.skd_maxpool_argmax_nhwc(B, C, H, W, kh, kw, P(xl), P(pr2), P(ir2), None)
+    assert torch.equal(ir2, ir) and np.array_equal(pr2.numpy().view(np.uint32), pr.numpy().view(np.uint32)), "oracle: the two layouts agree"
+    pg, ig = torch.full((B * C, M), 7.0, device=DEV), torch.full((B * C, M), -1, dtype=torch.int32, device=DEV)
+    xg = gpu(xl)
+    assert hip.skd_maxpool_argmax_nhwc(B, C, H, W, kh, kw, P(xg), P(pg), P(ig), None)
+    assert torch.equal(ig.cpu(), ir), "argmax indices must be bit-exact"
+    assert np.array_equal(pg.cpu().numpy().view(np.uint32), pr.numpy().view(np.uint32)), "pooled values bit-exact"
+    pg2 = torch.empty(B * C, M, device=DEV)
+    assert hip.skd_maxpool_argmax_nhwc(B, C, H, W, kh, kw, P(xg), P(pg2), None, None)       # index optional
+    assert np.array_equal(pg2.cpu().numpy().view(np.uint32), pr.numpy().view(np.uint32))
+    dp = torch.randn(B * C, M + 5, generator=g)
+    dxr = torch.empty(B, H, W, C)
+    assert ref.skd_maxunpool_scatter_nhwc(B, C, H, W, kh, kw, P(dp), M + 5, P(ir), P(dxr), None)
+    dxn = torch.empty(B * C, H, W)
+    assert ref.skd_maxunpool_scatter(B * C, H, W, kh, kw, P(dp), M + 5, P(ir), P(dxn), None)
+    assert torch.equal(dxr, dxn.reshape(B, C, H, W).permute(0, 2, 3, 1)), "oracle: the two layouts agree"
+    dxg = torch.full((B, H, W, C), 7.0, device=DEV)
+    assert hip.skd_maxunpool_scatter_nhwc(B, C, H, W, kh, kw, P(gpu(dp)), M + 5, P(ig), P(dxg), None)
+    assert torch.equal(dxg.cpu(), dxr)
+    assert not hip.skd_maxpool_argmax_nhwc(B, 6, H, W, kh, kw, P(xg), P(pg), P(ig), None)   # C must be whole quads
 
 
 @pytest.mark.parametrize("B,Cs,Ct,M", [(2, 16, 40, 9), (8, 128, 512, 9), (2, 128, 512, 81), (1, 5, 3, 1), (2, 130, 70, 289),
@@ -1019,7 +1104,7 @@ def test_conv1x1_abn_gemm_with_bn_relu_prologue(hip, ref, M, K, N, with_res, aff
 
 
 def test_teacher_bottleneck_fused_tail_equals_unfused(monkeypatch):
-    """SKD_TEACHER_TAIL=1 (conv2 -> ONE GEMM with bn2 + ReLU in its prologue and bn3 + residual + ReLU in its epilogue) gives the
+    """pspnet_combine.FUSED_TAIL (conv2 -> ONE GEMM with bn2 + ReLU in its prologue and bn3 + residual + ReLU in its epilogue) gives the
     frozen bottleneck's output of the default path (conv + in-place ABN passes) at the layer-3 shape."""
     from structure_knowledge_distillation_amd.networks import pspnet_combine as PC
     torch.manual_seed(3)
@@ -1028,9 +1113,9 @@ def test_teacher_bottleneck_fused_tail_equals_unfused(monkeypatch):
         for bn in (blk.bn1, blk.bn2, blk.bn3):
             bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.normal_(0, 1); bn.bias.normal_(0, 0.5)
         x = torch.randn(2, 1024, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
-        monkeypatch.setenv("SKD_TEACHER_TAIL", "0")
+        monkeypatch.setattr(PC_MOD, "FUSED_TAIL", False)
         want = blk(x.clone(memory_format=torch.channels_last))
-        monkeypatch.setenv("SKD_TEACHER_TAIL", "1")
+        monkeypatch.setattr(PC_MOD, "FUSED_TAIL", True)
         got = blk(x.clone(memory_format=torch.channels_last))
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     close(got, want, 3e-5, "fused bottleneck tail")
@@ -1134,7 +1219,7 @@ def test_psp_module_fold_vs_concat(cfg, monkeypatch):
     x = (torch.randn(B, Cf, H, W) * 2).to(DEV).contiguous(memory_format=torch.channels_last)
 
     def run(fold):
-        monkeypatch.setenv("SKD_PSP_FOLD", "1" if fold else "0")
+        monkeypatch.setattr(PC_MOD, "PSP_FOLD", bool(fold))
         for p in m.parameters():
             p.grad = None
         if not train:
@@ -1238,7 +1323,7 @@ def test_frozen_bottleneck_blas_tail(cfg, monkeypatch):
     x = torch.randn(B, Cin, HW, HW, device=DEV).contiguous(memory_format=torch.channels_last)
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("SKD_TEACHER_BLAS", flag)
+        monkeypatch.setattr(PC_MOD, "BLAS_TAILS", flag == "1")
         with torch.no_grad():
             outs[flag] = blk(x.clone())
     close(outs["1"], outs["0"], 2e-5, "blas tail vs conv + abn")

@@ -123,6 +123,15 @@ def test_criteria_vs_oracle(hw, scale):
     (0.7 * want[0] + 10.0 * want[1] + 0.5 * want[2]).backward()
     for i in range(3):
         assert rel(Sg[i].grad, So[i].grad) < 5e-5, i
+    # channels-last PSP features (what NetModel hands over since round 5): the SAME bits in the loss, the same gradient values,
+    # returned in the layout the feature had (no NCHW copy on the way in or out)
+    fs = S[2].to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ft = T[2].to(DEV).contiguous(memory_format=torch.channels_last)
+    pa_cl = C.CriterionPairWiseforWholeFeatAfterPool(scale, -5)([None, None, fs] + [None] * 4, [None, None, ft] + [None] * 4)
+    assert float(pa_cl) == float(got[2]), "pair-wise loss must not depend on the layout of the features"
+    (0.5 * pa_cl).backward()
+    assert fs.grad.is_contiguous(memory_format=torch.channels_last) and not fs.grad.is_contiguous()
+    assert torch.equal(fs.grad.contiguous(), Sg[2].grad), "pair-wise gradient must not depend on the layout of the features"
     # the helper surface of utils/utils.py
     f = torch.randn(2, 16, 3, 3)
     assert rel(U.similarity(f.to(DEV)), O.similarity(f.double())) < 1e-5
@@ -415,12 +424,12 @@ def test_full_step_b8_vs_golden():
     model.set_input((images, labels, None, None))
     model.forward()
     model.G_solver.zero_grad()
-    with LeakyRecorder(model.D_model) as rec:            # the critic's 4 forwards of a step: G step, D(T), D(S), gradient penalty
+    with LeakyRecorder(model.D_model) as krec:           # the critic's 4 forwards of a step: G step, D(T), D(S), gradient penalty
         model.student_backward()
         gS = {k: p.grad.detach().clone() for k, p in model.student.named_parameters()}
         model.G_solver.step()
         model.discriminator_backward()
-    assert len(rec.masks) == 16
+    assert len(krec.masks) == 16
     gD = {k: p.grad.detach().clone() for k, p in model.D_model.named_parameters() if p.grad is not None}   # SGD leaves .grad intact
     for k, want in gold["losses64"].items():
         got = getattr(model, k)
@@ -452,7 +461,7 @@ def test_full_step_b8_vs_golden():
                 assert_only_rounding_flips(lm, what)
         return ref
 
-    ref = oracle_d_step(rec.masks, "B=8 D step (MIOpen convolutions)")
+    ref = oracle_d_step(krec.masks, "B=8 D step (MIOpen convolutions)")
     # D LOSS tolerance = north_star's 1e-4.  On THESE logits the critic loss is a cancelling sum (-mean D(T) + mean D(S), the
     # gradient penalty's (|grad| - 1)^2): the CPU fp32 oracle itself is 2.3e-5 off the fp64 one, the HIP path has landed anywhere in
     # 0.4451488 ... 0.4451856 over twelve runs (1e-6 of run-to-run noise in the logits, amplified ~50 x), and two fp32 evaluations of
@@ -470,7 +479,7 @@ def test_full_step_b8_vs_golden():
     D2.load_state_dict({k: v.clone() for k, v in PD.items()})
     torch.use_deterministic_algorithms(True, warn_only=True)       # rocBLAS without atomics (split-K / stream-K GEMMs), see IM2COL_D_FLOOR
     try:
-        with torch.backends.cudnn.flags(enabled=False), LeakyRecorder(D2) as rec2:
+        with torch.backends.cudnn.flags(enabled=False), LeakyRecorder(D2) as krec2:
             with torch.no_grad():
                 D2(pS_gpu.to(DEV))                                                 # the G step's critic forward
             d_t2, d_s2 = D2(pT_gpu.to(DEV)), D2(pS_gpu.to(DEV))
@@ -479,7 +488,7 @@ def test_full_step_b8_vs_golden():
             loss2.backward()
     finally:
         torch.use_deterministic_algorithms(False)
-    ref2 = oracle_d_step(rec2.masks, "B=8 D step (im2col + rocBLAS convolutions)")
+    ref2 = oracle_d_step(krec2.masks, "B=8 D step (im2col + rocBLAS convolutions)")
     assert abs(float(loss2) - ref2["f64"][0]) <= 1e-4 * abs(ref2["f64"][0])          # see the tolerance note above
     g2 = {k: p.grad for k, p in D2.named_parameters() if p.grad is not None}
     _report("B=8 discriminator step, convolutions on the im2col + rocBLAS path",

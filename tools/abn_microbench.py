@@ -71,7 +71,6 @@ def cold():
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
-    print(json.dumps({"SKD_ABN_NT": os.environ.get("SKD_ABN_NT", "0")}), flush=True)
     for (N, C, S) in ((8, 512, 4225), (8, 2048, 4225), (8, 64, 65536)):
         n = max(2, int(1.5e9 // (N * C * S * 4)) + 1)
         xs = [torch.randn(N, C, S, device=dev) for _ in range(n)]

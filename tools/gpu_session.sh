@@ -1,7 +1,9 @@
 #!/bin/bash
 # One GPU-box session (gpurun): every section writes under gpurun_out/<tag>/ and is bounded by its own timeout.
 #   tools/gpu_session.sh <tag> <section> [<section> ...]
-# sections: tests_new | tests_all | world8 | smoke | bench | bench_prof | micro | micro_prof | pmc | pmc2 | conv | dist | dist_ab | r4_ab | ...
+# sections: tests_all | tests_r5a | tests_r5b | tests_dist | world8 | smoke | bench | bench_quick | bench_prof | timeline | micro | micro_prof |
+#           pmc | pmc2 | conv | lab | lab_pmc | det | dstep | fused_ab | dist | dist_ab | scale8   (A/B sections of switches that
+#           no longer exist were removed in round 5; their verdicts are under profiles/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -10,11 +12,6 @@ t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $1" | tee -a $O/session.log; }
 for sec in "$@"; do
   case $sec in
-    tests_new)
-      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "nhwc or pairwise or b8 or config1 or single_sample or criteria or small_m or ppm" > $O/pytest_new.log 2>&1
-      stamp "tests_new rc=$?"; grep -E "passed|failed|error" $O/pytest_new.log | tail -3 | tee -a $O/session.log
-      grep -E "worst|B=8 |config1 " $O/pytest_new.log | tee -a $O/session.log ;;
     tests_all)
       timeout 1500 python -m pytest tests -m gpu -q --tb=short -s --durations=12 > $O/pytest_gpu.log 2>&1
       stamp "tests_all rc=$?"; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 | tee -a $O/session.log
@@ -76,73 +73,6 @@ EOF
         python $R/tools/conv_table.py 10 > $O/conv_table.jsonl 2> $O/conv_table.err)
       stamp "conv rc=$?"; tail -1 $O/conv_table.jsonl | tee -a $O/session.log
       python tools/summarise_conv_table.py $O/conv_table.jsonl $O/prof_conv $O/conv_shapes.md >> $O/session.log 2>&1 ;;
-    c11)
-      timeout 300 python tools/conv1x1_bench.py 20 > $O/conv1x1_ab.jsonl 2> $O/conv1x1_ab.err
-      stamp "c11 rc=$?"; tail -1 $O/conv1x1_ab.jsonl | tee -a $O/session.log ;;
-    tune_fold)
-      # MIOpen find for the new convolution problems, appended to a copy of the shipped db; later sections use the copy
-      rm -rf $O/miopen_db; cp -r structure_knowledge_distillation_amd/miopen_db $O/miopen_db
-      timeout 1000 python tools/miopen_tune.py $O/miopen_db psp_fold > $O/tune_fold.log 2>&1
-      stamp "tune_fold rc=$?"; tail -12 $O/tune_fold.log | tee -a $O/session.log
-      export MIOPEN_USER_DB_PATH=$O/miopen_db MIOPEN_CUSTOM_CACHE_DIR=$O/miopen_db/cache ;;
-    tests_fold)
-      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "fold or ppm or b8 or config1 or full_step" > $O/pytest_fold.log 2>&1
-      stamp "tests_fold rc=$?"; grep -E "passed|failed|error" $O/pytest_fold.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  |worst|B=8 |config1 " $O/pytest_fold.log | head -30 | tee -a $O/session.log ;;
-    bench_ab)
-      for v in "SKD_PSP_FOLD=0 SKD_D_STREAM=0" "SKD_PSP_FOLD=1 SKD_D_STREAM=0" "SKD_PSP_FOLD=1 SKD_D_STREAM=1"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
-        stamp "bench_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    tests_pool)
-      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "maxpool or psp_module or config1" > $O/pytest_pool.log 2>&1
-      stamp "tests_pool rc=$?"; grep -E "passed|failed|error" $O/pytest_pool.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  " $O/pytest_pool.log | head -30 | tee -a $O/session.log ;;
-    bench_ab2)
-      for v in "SKD_MAXPOOL=1" "SKD_MAXPOOL=0" "SKD_TEACHER_DSN=0"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab2_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab2.err
-        stamp "bench_ab2 $v rc=$?"; cut -c1-260 "$O/bench_ab2_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    c11b)
-      C11_SKIP_MIOPEN=1 timeout 300 python tools/conv1x1_bench.py 10 > $O/conv1x1_blas.jsonl 2> $O/conv1x1_blas.err
-      stamp "c11b rc=$?"; cut -c1-400 $O/conv1x1_blas.jsonl | tee -a $O/session.log
-      C11_SKIP_MIOPEN=1 TORCH_BLAS_PREFER_HIPBLASLT=1 timeout 300 python tools/conv1x1_bench.py 10 > $O/conv1x1_blaslt.jsonl 2> $O/conv1x1_blaslt.err
-      stamp "c11b hipblaslt rc=$?"; cut -c1-400 $O/conv1x1_blaslt.jsonl | tee -a $O/session.log ;;
-    tests_blas)
-      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "blas or psp_module or config1 or teacher" > $O/pytest_blas.log 2>&1
-      stamp "tests_blas rc=$?"; grep -E "passed|failed|error" $O/pytest_blas.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  " $O/pytest_blas.log | head -30 | tee -a $O/session.log ;;
-    bench_ab3)
-      for v in "SKD_TEACHER_BLAS=1" "SKD_TEACHER_BLAS=0" "SKD_PSP_MM=0" "SKD_TEACHER_BLAS=1 TORCH_BLAS_PREFER_HIPBLASLT=1"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab3_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab3.err
-        stamp "bench_ab3 $v rc=$?"; cut -c1-260 "$O/bench_ab3_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    tests_quick)
-      timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "fold or maxpool or blas or psp_module or config1 or teacher" > $O/pytest_quick.log 2>&1
-      stamp "tests_quick rc=$?"; grep -E "passed|failed|error" $O/pytest_quick.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  " $O/pytest_quick.log | head -30 | tee -a $O/session.log ;;
-    bench_ab4)
-      for v in "SKD_HEAD_MM=1" "SKD_HEAD_MM=0"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab4_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab4.err
-        stamp "bench_ab4 $v rc=$?"; cut -c1-260 "$O/bench_ab4_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    tests_mask)
-      timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s \
-        -k "nhwc_training or full_step_vs_oracle or config1 or d_stream or relu" > $O/pytest_mask.log 2>&1
-      stamp "tests_mask rc=$?"; grep -E "passed|failed|error" $O/pytest_mask.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  " $O/pytest_mask.log | head -30 | tee -a $O/session.log ;;
-    bench_ab5)
-      for v in "SKD_ABN_MASK_FROM_X=1" "SKD_ABN_MASK_FROM_X=0"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab5_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab5.err
-        stamp "bench_ab5 $v rc=$?"; cut -c1-260 "$O/bench_ab5_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    bench_tstream)
-      (SKD_TEACHER_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_tstream.json 2>> $O/bench_tstream.err
-      stamp "bench_tstream rc=$?"; cut -c1-260 $O/bench_tstream.json | tee -a $O/session.log ;;
     lab)
       timeout 240 tools/gemm_lab time 10 > $O/gemm_lab.jsonl 2> $O/gemm_lab.err
       stamp "lab rc=$?"; cut -c1-330 $O/gemm_lab.jsonl | tee -a $O/session.log ;;
@@ -158,15 +88,6 @@ EOF
       done
       python tools/summarise_lab_pmc.py $O $O/gemm_lab_pmc.json > $O/gemm_lab_pmc.log 2>&1
       stamp "lab_pmc summarised" ;;
-    tail_ab)
-      for v in "SKD_TEACHER_TAIL=1" "SKD_TEACHER_TAIL=0"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
-        stamp "tail_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
-    tests_c11)
-      timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --tb=short -s -k "conv1x1 or bottleneck or one_call" > $O/pytest_c11.log 2>&1
-      stamp "tests_c11 rc=$?"; grep -E "passed|failed|error" $O/pytest_c11.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  |^FAILED" $O/pytest_c11.log | cut -c1-300 | head -30 | tee -a $O/session.log ;;
     tests_dist)
       timeout 900 python -m pytest tests/test_distributed_gpu.py tests/test_kernels_gpu.py -m gpu -q --tb=short -s -k "distributed or one_call or mailbox or two_ranks or torchrun" > $O/pytest_dist.log 2>&1
       stamp "tests_dist rc=$?"; grep -E "passed|failed|error" $O/pytest_dist.log | tail -3 | tee -a $O/session.log
@@ -179,20 +100,9 @@ EOF
         (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
         stamp "fused_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
       done ;;
-    tests_r3)
-      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py tests/test_distributed_gpu.py -m gpu -q --tb=short -s \
-        -k "nhwc or pairwise or b8 or config1 or two_ranks or full_step or d_stream" > $O/pytest_r3.log 2>&1
-      stamp "tests_r3 rc=$?"; grep -E "passed|failed|error" $O/pytest_r3.log | tail -3 | tee -a $O/session.log
-      grep -E "^E  |^FAILED" $O/pytest_r3.log | cut -c1-300 | head -40 | tee -a $O/session.log ;;
     det)
       timeout 400 python tools/determinism_probe.py 8 > $O/determinism.jsonl 2> $O/determinism.err
       stamp "det rc=$?"; cut -c1-700 $O/determinism.jsonl | tee -a $O/session.log ;;
-    r4_ab)
-      # round 4 A/B on the default bench: teacher hipGraph, discriminator's spectral norms in 3 launches, GEMM super-tile order
-      for v in "SKD_TEACHER_GRAPH=1" "SKD_TEACHER_GRAPH=0" "SKD_SN_TOGETHER=0" "SKD_GEMM_TILE_ORDER=0"; do
-        (env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > "$O/bench_ab_$(echo $v | tr ' =' '__').json" 2>> $O/bench_ab.err
-        stamp "r4_ab $v rc=$?"; cut -c1-260 "$O/bench_ab_$(echo $v | tr ' =' '__').json" | tee -a $O/session.log
-      done ;;
     dist_ab)
       # two ranks on ONE MI355X over gloo (what a 1-GPU box can show of N > 1): SyncABN exchange inside the one-launch kernels vs
       # the three-launch form
@@ -262,10 +172,56 @@ PYEOF
         -k "b8_vs_golden or hipgraph or eight_ranks_vs or discriminator_step" > $O/pytest_r5a.log 2>&1
       stamp "tests_r5a rc=$?"; grep -E "passed|failed|error" $O/pytest_r5a.log | tail -3 | tee -a $O/session.log
       grep -E "^E  |^FAILED|LeakyReLU decisions|worst rank|movement|im2col" $O/pytest_r5a.log | cut -c1-300 | head -60 | tee -a $O/session.log ;;
+    scale8)
+      # UNATTENDED multi-GPU recipe: runs on any box with >= 2 GPUs, every leg under its own timeout, every leg
+      # produces a JSON line or a logged reason.  (i) RCCL + cross-device HIP IPC tests; (ii) the scaling curve N = 1, 2, 4, 8 in the
+      # default (safe) form -- bench.py itself falls back to a safer SyncABN form if a warm-up step raises a device status word and says
+      # so in comm.form / comm.fallback_reason; (iii) at the largest N the A/B the defaults are waiting for: in-kernel exchange
+      # (SKD_ABN_SYNC_FUSED=1, with the compute-unit reserve), collectives only (SKD_SYNC_IPC=0), teacher hipGraph at N > 1.
+      NG=$(python -c "import torch; print(torch.cuda.device_count())")
+      stamp "scale8: $NG GPUs visible"
+      if [ "$NG" -ge 2 ]; then
+        timeout 900 python -m pytest tests/test_distributed_gpu.py -m gpu -q --tb=short -s -k multi_gpu > $O/pytest_multi_gpu.log 2>&1
+        stamp "scale8 multi_gpu tests rc=$?"; grep -E "passed|failed|error|skipped" $O/pytest_multi_gpu.log | tail -3 | tee -a $O/session.log
+      fi
+      port=29600
+      for n in 1 2 4 8; do
+        [ "$n" -le "$NG" ] || continue
+        port=$((port+1))
+        if [ "$n" -eq 1 ]; then
+          (timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pairwise-sweep) > $O/scale_n$n.json 2> $O/scale_n$n.err
+        else
+          (timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
+            bench.py --gpus $n --steps 20 --warmup 5) > $O/scale_n$n.json 2> $O/scale_n$n.err
+        fi
+        stamp "scale8 N=$n rc=$?"; grep '^{' $O/scale_n$n.json | python -c "
+import json, sys
+for l in sys.stdin:
+    d = json.loads(l); print('   N=%d %.1f img/s %.2f ms/step comm=%s' % (d['n_gpus'], d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
+      done
+      if [ "$NG" -ge 2 ]; then
+        n=$NG; [ "$n" -gt 8 ] && n=8
+        for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=1 SKD_ABN_RCCL_RESERVE_CUS=0" "SKD_SYNC_IPC=0" "SKD_TEACHER_GRAPH=force"; do
+          port=$((port+1)); f="$O/scale_ab_n${n}_$(echo $v | tr ' =' '__').json"
+          (env $v timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
+            bench.py --gpus $n --steps 10 --warmup 3) > "$f" 2>> $O/scale_ab.err
+          stamp "scale8 A/B $v N=$n rc=$?"; grep '^{' "$f" | python -c "
+import json, sys
+for l in sys.stdin:
+    d = json.loads(l); print('   %.1f img/s %.2f ms/step comm=%s' % (d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
+        done
+      fi ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
       stamp "dist rc=$?"; cut -c1-600 $O/bench_dist.json | tee -a $O/session.log ;;
+    tests_r5b)
+      # round 5, kernels rewritten this round: fused CE + upsample (cell formulation), channels-last pair-wise pooling, stem max-pool
+      # backward over 2 x 2 blocks, pair-wise backward through the node-major copy, packed scalar read-back, the b8 golden step
+      timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s --durations=8 \
+        -k "ce_dsn or maxpool or pairwise or criteria or b8_vs_golden or config1 or full_step_vs_oracle or stem or networks_forward or bottleneck or psp" > $O/pytest_r5b.log 2>&1
+      stamp "tests_r5b rc=$?"; grep -E "passed|failed|error" $O/pytest_r5b.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED|LeakyReLU decisions|im2col" $O/pytest_r5b.log | cut -c1-300 | head -60 | tee -a $O/session.log ;;
   esac
 done
 # large raw traces do not travel back (64 MiB cap): keep stats, drop per-dispatch traces except the conv one (names needed)

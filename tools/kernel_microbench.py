@@ -176,15 +176,26 @@ def build_cases(lib, torch, dev, st):
         po, pi = torch.empty(planes, oh, oh, device=dev), torch.empty(planes, oh, oh, dtype=torch.int32, device=dev)
         add("maxpool_argmax(pair-wise pooling)", [planes, 65, 65, kh], lambda planes=planes, kh=kh, fx=fx, po=po, pi=pi:
             lib.skd_maxpool_argmax(planes, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * planes * 65 * 65 + 8 * planes * oh * oh, keep=(fx, po, pi))
+    # ... and its channels-last form (round 5: what the step runs -- the PSP features are pooled as they are) + the un-pool
+    for B_, C_, kh in ((8, 128, 32), (8, 512, 32), (8, 512, 1)):
+        fx = torch.randn(B_, 65, 65, C_, device=dev)
+        oh = -(-65 // kh)
+        po, pi = torch.empty(B_ * C_, oh * oh, device=dev), torch.empty(B_ * C_, oh * oh, dtype=torch.int32, device=dev)
+        add("maxpool_argmax_nhwc(pair-wise pooling)", [B_, C_, 65, 65, kh], lambda B_=B_, C_=C_, kh=kh, fx=fx, po=po, pi=pi:
+            lib.skd_maxpool_argmax_nhwc(B_, C_, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * B_ * C_ * 65 * 65 + 8 * B_ * C_ * oh * oh, keep=(fx, po, pi))
+        if C_ == 128:
+            dpo, dxx = torch.randn(B_ * C_, oh * oh, device=dev), torch.empty(B_, 65, 65, C_, device=dev)
+            add("maxunpool_scatter_nhwc", [B_, C_, 65, 65, kh], lambda B_=B_, C_=C_, kh=kh, dpo=dpo, pi=pi, dxx=dxx, oh=oh:
+                lib.skd_maxunpool_scatter_nhwc(B_, C_, 65, 65, kh, kh, p(dpo), oh * oh, p(pi), p(dxx), st), 4 * B_ * C_ * 65 * 65 + 8 * B_ * C_ * oh * oh,
+                keep=(dpo, dxx))
     # evaluation tail (csrc/evaluate.hip): 8 B label + 1 B prediction per pixel, the 129 x 257 logits from cache
     el = torch.randn(1, 19, 129, 257, device=dev)
     elab = torch.randint(0, 19, (1, 1024, 2048), device=dev)
     econf, epred = torch.zeros(19, 19, dtype=torch.int64, device=dev), torch.empty(1, 1024, 2048, dtype=torch.uint8, device=dev)
     add("seg_confusion(1024x2048)", [1, 19, 129, 257, 1024, 2048], lambda:
         lib.skd_seg_confusion(1, 19, 129, 257, 1024, 2048, p(el), p(elab), 255, p(epred), p(econf), st), 9 * 1024 * 2048, keep=(el, elab, econf, epred))
-    # the frozen bottleneck's fused tail GEMM (csrc/conv1x1.hip) at the teacher's four problem shapes, in the round-4 super-tile
-    # order and in the round-3 panel-major order (SKD_GEMM_TILE_ORDER=0, read at every launch): the counter passes show what
-    # the order does to the L2 -> fabric traffic.  Algorithmic bytes: X (M x K) + W (N x K) + residual (M x N) read, Y (M x N) written.
+    # the frozen bottleneck's fused tail GEMM (csrc/conv1x1.hip) at the teacher's four problem shapes (super-tile order; the panel-major
+    # A/B of round 4 is recorded in profiles/r04g_pmc.json).  Algorithmic bytes: X (M x K) + W (N x K) + residual (M x N) read, Y written.
     for M_, K_, N_ in ((8 * 129 * 129, 64, 256), (8 * 65 * 65, 128, 512), (8 * 65 * 65, 256, 1024), (8 * 65 * 65, 512, 2048)):
         X_, Wt_ = torch.randn(M_, K_, device=dev), torch.randn(N_, K_, device=dev) * 0.05
         R_, Y_ = torch.randn(M_, N_, device=dev), torch.empty(M_, N_, device=dev)
@@ -194,22 +205,10 @@ def build_cases(lib, torch, dev, st):
         assert lib.skd_abn_pack_eval_params(K_, p(pm), p(pv), None, None, 1e-5, p(pack), st)
         keep = (X_, Wt_, R_, Y_, mu, va, ga, be, pm, pv, pack)
 
-        def gemm(order, M_=M_, K_=K_, N_=N_, X_=X_, Wt_=Wt_, R_=R_, Y_=Y_, mu=mu, va=va, ga=ga, be=be, pack=pack):
-            if order is None:
-                os.environ.pop("SKD_GEMM_TILE_ORDER", None)
-            else:
-                os.environ["SKD_GEMM_TILE_ORDER"] = order
-            r = lib.skd_conv1x1_abn_pro_nhwc(M_, K_, N_, p(X_), p(Wt_), p(R_), p(Y_), p(mu), p(va), p(ga), p(be), 1e-5, p(pack), 3, 0.0, st)
-            os.environ.pop("SKD_GEMM_TILE_ORDER", None)
-            return r
+        def gemm(M_=M_, K_=K_, N_=N_, X_=X_, Wt_=Wt_, R_=R_, Y_=Y_, mu=mu, va=va, ga=ga, be=be, pack=pack):
+            return lib.skd_conv1x1_abn_pro_nhwc(M_, K_, N_, p(X_), p(Wt_), p(R_), p(Y_), p(mu), p(va), p(ga), p(be), 1e-5, p(pack), 3, 0.0, st)
         nbytes = 4 * (M_ * K_ + N_ * K_ + 2 * M_ * N_)
-        add("conv1x1_abn_pro(tail GEMM, super-tile order)", [M_, K_, N_], lambda gemm=gemm: gemm(None), nbytes, flops=2.0 * M_ * K_ * N_, keep=keep)
-        add("conv1x1_abn_pro(tail GEMM, panel-major order)", [M_, K_, N_], lambda gemm=gemm: gemm("0"), nbytes, flops=2.0 * M_ * K_ * N_)
-        # SKD_MICRO_TILE_ORDERS="ct,pm;ct,pm;..." : extra super-tile geometries on the wide problem (counter sweeps)
-        if N_ == 2048:
-            for order in [o for o in os.environ.get("SKD_MICRO_TILE_ORDERS", "").split(";") if o]:
-                add("conv1x1_abn_pro(tail GEMM, order %s)" % order, [M_, K_, N_], lambda gemm=gemm, order=order: gemm(order), nbytes,
-                    flops=2.0 * M_ * K_ * N_)
+        add("conv1x1_abn_pro(tail GEMM, super-tile order)", [M_, K_, N_], gemm, nbytes, flops=2.0 * M_ * K_ * N_, keep=keep)
     return cases
 
 

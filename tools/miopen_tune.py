@@ -31,8 +31,8 @@ def child(phase):
     sys.path.insert(0, ROOT)
     batch, find, what, _ = PHASES[phase]
     os.environ["SKD_MIOPEN_FIND"] = "1" if find else "0"
-    os.environ["SKD_TEACHER_NHWC"] = "1" if what in ("teacher_nhwc", "full_nhwc") else os.environ.get("SKD_TEACHER_NHWC", "0")
-    os.environ["SKD_STUDENT_NHWC"] = "1" if what == "full_nhwc" else "0"
+    # (rounds 1-2 also tuned the NCHW forms of the problems -- phases without "_nhwc"; both networks are channels-last only since
+    # round 5, so every phase now records the channels-last problems)
     import torch
     from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
     dev = torch.device("cuda", 0)
