@@ -1861,6 +1861,44 @@ static bool fuse_kernel_fits(K kernel, PerDeviceFlag &checked, PerDeviceFlag &fi
     KERNEL<<<grid, block, 0, st>>>(__VA_ARGS__);                                            \
   } while (0)
 
+// ---- can THIS device launch every synchronised one-launch instantiation?   -------------------------------------
+// SKD_FUSE_LAUNCH checks its instantiation when it is about to launch -- for the synchronised entries that is AFTER sync_next()
+// has drawn the exchange's sequence number, when "take the other form" is no longer possible: the rank would have to fail while
+// its peers spin for it.  So the synchronised entries ask this BEFORE they draw: one occupancy query per instantiation, once per
+// device; if any of them cannot hold a 1024-thread workgroup on a compute unit (fewer registers / LDS than gfx950), the device
+// takes the three-launch form for every synchronised call (the two forms interoperate rank by rank).
+template <class K>
+static bool one_block_fits(K kernel) {
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void *>(kernel), kRedThreads, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return blocks >= 1;
+}
+template <int ACT, bool RES>
+static bool fwd_sync_fit() {
+  return one_block_fits(abn_fwd_fused_nhwc_kernel<ACT, RES, 5, true>) && one_block_fits(abn_fwd_fused_nhwc_kernel<ACT, RES, 9, true>) &&
+         one_block_fits(abn_fwd_fused_nhwc_kernel<ACT, RES, 17, true>);
+}
+template <int ACT, int MODE, bool WRITE_RES>
+static bool bwd_sync_fit() {
+  return one_block_fits(abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 5, true>) &&
+         one_block_fits(abn_bwd_fused_nhwc_kernel<ACT, MODE, WRITE_RES, 9, true>);
+}
+static bool sync_fused_fits_device() {
+  static PerDeviceFlag checked, fits;
+  bool *c = checked.get(), *f = fits.get();
+  if (c == nullptr || f == nullptr) return false;
+  if (!*c) {
+    *f = fwd_sync_fit<SKD_ACT_RELU, true>() && fwd_sync_fit<SKD_ACT_RELU, false>() && fwd_sync_fit<SKD_ACT_LEAKY_RELU, false>() &&
+         fwd_sync_fit<SKD_ACT_NONE, false>() && bwd_sync_fit<SKD_ACT_LEAKY_RELU, 0, false>() && bwd_sync_fit<SKD_ACT_NONE, 0, false>() &&
+         bwd_sync_fit<SKD_ACT_NONE, 2, false>() && bwd_sync_fit<SKD_ACT_NONE, 1, true>() && bwd_sync_fit<SKD_ACT_NONE, 1, false>();
+    *c = true;
+  }
+  return *f;
+}
+
 // how often the synchronised entries took each form (tests and bench.py report it: "did the exchange really run inside the kernel?")
 static int64_t g_sync_form_calls[2] = {0, 0};     // [one launch with the exchange inside, statistics + exchange kernel + normalise]
 
@@ -2248,7 +2286,8 @@ int skd_abn_forward_train_nhwc_sync(void *sync_ctx, int64_t rows, int C, const f
   if (!aligned16(x) || !aligned16(out) || (residual && !aligned16(residual)) || 2 * C > kSyncMaxFloats) return 0;
   hipStream_t st = as_stream(stream);
   FuseGeom f;
-  if (sync_fused_enabled() && aligned16(mean) && aligned16(var) && fwd_fused_geom(activation, residual != nullptr, rows, C, f)) {
+  if (sync_fused_enabled() && sync_fused_fits_device() && aligned16(mean) && aligned16(var) &&
+      fwd_fused_geom(activation, residual != nullptr, rows, C, f)) {
     SyncArgs sy;
     if (!sync_next(sync_ctx, sy)) return 0;
     ++g_sync_form_calls[0];
@@ -2395,7 +2434,8 @@ static int abn_backward_nhwc_any(void *sync_ctx, const float *rweights, int64_t 
   if (sync_ctx && (eydz != edz + C || 2 * C > kSyncMaxFloats)) return 0;
   hipStream_t st = as_stream(stream);
   FuseGeom f;
-  if (aligned16(edz) && aligned16(eydz) && activation != SKD_ACT_ELU && (!sync_ctx || sync_fused_enabled()) && bwd_fused_geom(rows, C, f)) {
+  if (aligned16(edz) && aligned16(eydz) && activation != SKD_ACT_ELU && (!sync_ctx || (sync_fused_enabled() && sync_fused_fits_device())) &&
+      bwd_fused_geom(rows, C, f)) {
     int r;
     if (sync_ctx) {
       SyncArgs sy;
@@ -2451,7 +2491,7 @@ static int abn_relu_backward_nhwc_any(void *sync_ctx, const float *rweights, int
   if (sync_ctx && (eydz != edz + C || 2 * C > kSyncMaxFloats)) return 0;
   hipStream_t st = as_stream(stream);
   FuseGeom f;
-  if (aligned16(edz) && aligned16(eydz) && (!sync_ctx || sync_fused_enabled()) && bwd_fused_geom(rows, C, f)) {
+  if (aligned16(edz) && aligned16(eydz) && (!sync_ctx || (sync_fused_enabled() && sync_fused_fits_device())) && bwd_fused_geom(rows, C, f)) {
     int r;
     if (sync_ctx) {
       SyncArgs sy;

@@ -73,31 +73,44 @@ __device__ __forceinline__ void cell_range(int s, float scale, int in, int out, 
     }
 }
 
-constexpr int kCeTgtMax = 16384;      // bytes of LDS for a tile's target rectangle (8 x 16 cells at 65 -> 512: ~66 x 130)
-constexpr unsigned char kCeIgnore = 255, kCeBad = 254;
+// Sum over the 8 lanes 8g .. 8g+7 of a wave, result in all of them, as three DPP adds (no LDS round trip, unlike ds_bpermute):
+// lane ^ 1 and lane ^ 2 inside each quad, then the mirrored lane of the other quad (every lane of a quad holds the quad's sum by
+// then).  A fixed order of additions: bit-reproducible.
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
 
-// Tile geometry per class-count bucket: cells per tile (TJ x TI) x heads = threads per workgroup.
-//   C <= 24: 8 x 16 cells -> 256 threads with two heads; lane-private corner accumulators 4 x CMAX x 256 floats of LDS
-//   C <= 64: 8 x  8 cells -> 128 threads
-template <int CMAX>
-struct CeTile {
-  static constexpr int TJ = 8, TI = CMAX <= 24 ? 16 : 8;
-};
+constexpr int kCeTJ = 8, kCeTI = 8;   // source cells per tile
+constexpr int kCeRows = 8;            // lanes per cell: lane r of a cell takes the cell's output rows Ylo + r, Ylo + r + 8, ...
+constexpr int kCeCells = kCeTJ * kCeTI, kCeThreads = kCeCells * kCeRows;   // 512 threads = 8 waves
+constexpr int kCeTgtMax = 8192;       // bytes of LDS for a tile's target rectangle (8 x 8 cells at 65 -> 512: ~66 x 66)
+constexpr unsigned char kCeIgnore = 255, kCeBad = 254;
 
 // part[(wg*3 + 0..2)] = sum of -log p (main), sum of -log p (dsn), number of valid pixels (NaN when a label is out of range)
 // pnodes: (B, heads, C, NTy, TJ + 1, NTx, TI + 1) per-tile node sums of the UNSCALED gradient, or NULL (loss only)
+//
+// Thread layout (round 5, second version).  The first cell formulation gave one lane a whole cell (64 pixels x ~420 instructions,
+// 256 registers): 1056 waves for 1024 SIMDs -- one wave per SIMD, nothing to hide a dependent-issue stall behind: 254 us
+// (gpurun r05b), still VALU-latency-bound.  Now EIGHT lanes share a cell, one output row each (8448 waves, 2-3 per SIMD): a lane
+// interpolates its row's two column logits, walks the row's ~8 pixels (softmax once per pixel, row sums rL / rR of
+// (softmax - onehot) x horizontal weight in registers), and the eight lanes' rows are folded onto the cell's four corners with a
+// 3-step butterfly inside the lane group (fixed order: bit-reproducible); lane 0 of the group adds the result into the
+// workgroup's corner table in LDS.  The two heads run one after the other over the same staged target rectangle.
 template <int CMAX, bool TWO>
-__global__ __launch_bounds__(CeTile<CMAX>::TJ * CeTile<CMAX>::TI * (TWO ? 2 : 1)) void ce_cells_kernel(
+__global__ __launch_bounds__(kCeThreads) void ce_cells_kernel(
     const float *__restrict__ lm, const float *__restrict__ ld, const int64_t *__restrict__ target,
     float *__restrict__ pnodes, float *__restrict__ part, int B, int C, int h, int w, int H, int W, int ignore_index,
     float sy, float sx, int NTy, int NTx) {
-  constexpr int TJ = CeTile<CMAX>::TJ, TI = CeTile<CMAX>::TI, CELLS = TJ * TI, NT = CELLS * (TWO ? 2 : 1), NW = NT / kWave;
-  extern __shared__ float acc[];                         // [4 corners][CMAX][NT]: column `tid` is private to the lane
+  constexpr int TJ = kCeTJ, TI = kCeTI, CELLS = kCeCells, NT = kCeThreads, NW = NT / kWave;
+  extern __shared__ float csum[];                        // [4 corners][CMAX][CELLS]: the tile's corner sums of the current head
   __shared__ unsigned char tgt[kCeTgtMax];
   __shared__ int rect[4];
-  __shared__ float red[4][NW > 0 ? NW : 1];
+  __shared__ float red[4][NW];
   const int tid = threadIdx.x;
-  const int head = tid / CELLS, cell = tid % CELLS, lj = cell / TI, li = cell % TI;
+  const int rslot = tid & (kCeRows - 1), cell = tid >> 3, lj = cell / TI, li = cell % TI;
   const int tx = (int)(blockIdx.x % NTx), ty = (int)((blockIdx.x / NTx) % NTy), b = (int)(blockIdx.x / ((unsigned)NTx * NTy));
   const int j = ty * TJ + lj, i = tx * TI + li;
   const bool valid = j < h && i < w;
@@ -108,16 +121,14 @@ __global__ __launch_bounds__(CeTile<CMAX>::TJ * CeTile<CMAX>::TI * (TWO ? 2 : 1)
     rect[2] = 0x7fffffff;
     rect[3] = -1;
   }
-  if (grad)
-    for (int k = tid; k < 4 * CMAX * NT; k += NT) acc[k] = 0.f;
   int Ylo = 1, Yhi = 0, Xlo = 1, Xhi = 0;
   if (valid) {
     cell_range(j, sy, h, H, Ylo, Yhi);
     cell_range(i, sx, w, W, Xlo, Xhi);
   }
-  const bool work = valid && Ylo <= Yhi && Xlo <= Xhi;
+  const bool work = valid && Ylo <= Yhi && Xlo <= Xhi;     // the same for the 8 lanes of a cell
   __syncthreads();
-  if (work && head == 0) {                               // integer min / max: order-independent
+  if (work && rslot == 0) {                              // integer min / max: order-independent
     atomicMin(&rect[0], Ylo);
     atomicMax(&rect[1], Yhi);
     atomicMin(&rect[2], Xlo);
@@ -134,112 +145,150 @@ __global__ __launch_bounds__(CeTile<CMAX>::TJ * CeTile<CMAX>::TI * (TWO ? 2 : 1)
       tgt[k] = t == (int64_t)ignore_index ? kCeIgnore : ((t < 0 || t >= C) ? kCeBad : (unsigned char)t);
     }
   }
-  __syncthreads();
-  float loss = 0.f, cnt = 0.f, bad = 0.f;
-  if (work) {
-    const int hw = h * w;
-    // the head is uniform per wave (CELLS is a multiple of 64): say so, so that the channel planes are addressed as a SCALAR base
-    // + a 32-bit lane offset (otherwise the compiler keeps 4 x CMAX loop-invariant 64-bit lane addresses alive: 150+ registers)
-    const int head_u = __builtin_amdgcn_readfirstlane(head);
-    const float *p = (head_u == 0 ? lm : ld) + (int64_t)b * C * hw;
-    const int j1 = j + (j < h - 1 ? 1 : 0), i1 = i + (i < w - 1 ? 1 : 0);
-    const unsigned o00 = j * w + i, o01 = j * w + i1, o10 = j1 * w + i, o11 = j1 * w + i1;     // the cell's four corner logits
-    for (int Y = Ylo; Y <= Yhi; ++Y) {
-      const Tap tY = tap_of(Y, sy, h);
-      float t0[CMAX], t1[CMAX], rL[CMAX], rR[CMAX];
-      // vertical interpolation of the cell's two columns, once per row (the 4 x C corner values come from L1 / L2 again for
-      // every row: keeping them in 4 x CMAX more registers spills).  Channels C <= c < CMAX are padding: a large negative
-      // logit whose softmax term is exactly 0 -- no `if (c < C)` in the loops below (with a run-time C the compiler turned each
-      // of them into a branch: 158 branches and 250 registers for 12 channels)
-#pragma unroll
-      for (int c = 0; c < CMAX; ++c) {
-        const float *q = p + (int64_t)(c < C ? c : 0) * hw;
-        const float q00 = q[o00], q01 = q[o01], q10 = q[o10], q11 = q[o11];
-        t0[c] = c < C ? tY.l0 * q00 + tY.l1 * q10 : -1e30f;
-        t1[c] = c < C ? tY.l0 * q01 + tY.l1 * q11 : -1e30f;
-        rL[c] = 0.f;
-        rR[c] = 0.f;
-      }
-      const int64_t *trow = target + ((int64_t)b * H + Y) * W;
-      const unsigned char *srow = tgt + (Y - RY0) * RW - RX0;
-      for (int X = Xlo; X <= Xhi; ++X) {
-        int t;
-        if (staged) {
-          t = srow[X];
-        } else {
-          const int64_t tt = trow[X];
-          t = tt == (int64_t)ignore_index ? kCeIgnore : ((tt < 0 || tt >= C) ? kCeBad : (int)tt);
-        }
-        if (t == kCeIgnore) continue;
-        if (t == kCeBad) {                   // F.cross_entropy asserts on such a label; here it poisons the loss (NaN)
-          bad += 1.f;
-          continue;
-        }
-        cnt += 1.f;
-        const Tap tX = tap_of(X, sx, w);
-        float v[CMAX];
-        float mx = -INFINITY;
+  const int hw = h * w;
+  const int j1 = j + (j < h - 1 ? 1 : 0), i1 = i + (i < w - 1 ? 1 : 0);
+  const unsigned o00 = j * w + i, o01 = j * w + i1, o10 = j1 * w + i, o11 = j1 * w + i1;     // the cell's four corner logits
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr int heads = TWO ? 2 : 1;
+  const int rowlen = NTx * (TI + 1);
+  float loss_m = 0.f, loss_d = 0.f, cnt = 0.f, bad = 0.f;
+  for (int head = 0; head < heads; ++head) {
+    if (grad)
+      for (int k = tid; k < 4 * CMAX * CELLS; k += NT) csum[k] = 0.f;
+    __syncthreads();                                     // (also: the staged targets are visible)
+    const float *p = (head == 0 ? lm : ld) + (int64_t)b * C * hw;
+    float loss = 0.f;
+    if (work) {
+      for (int Y0 = Ylo; Y0 <= Yhi; Y0 += kCeRows) {    // one pass for cells of <= 8 rows (every up-sampling factor <= 8)
+        const int Y = Y0 + rslot;
+        const bool on = Y <= Yhi;
+        const Tap tY = tap_of(on ? Y : Ylo, sy, h);
+        float t0[CMAX], t1[CMAX], rL[CMAX], rR[CMAX];
+        // vertical interpolation of the cell's two columns for THIS lane's row.  Channels C <= c < CMAX are padding: a large negative
+        // logit whose softmax term is exactly 0 -- no `if (c < C)` in the pixel loop (with a run-time C the compiler turned each
+        // of them into a branch: 158 branches and 250 registers for 12 channels)
+        // (the offsets are laundered through an empty asm so that the 4 x C corner loads are NOT hoisted out of this loop: the loop
+        // runs once for every up-sampling factor <= 8, but hoisted the corners would stay live across the pixel loop: +76 registers)
+        unsigned p00 = o00, p01 = o01, p10 = o10, p11 = o11;
+        asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
-          v[c] = tX.l0 * t0[c] + tX.l1 * t1[c];
-          mx = fmaxf(mx, v[c]);
+          const float *q = p + (int64_t)(c < C ? c : 0) * hw;
+          const float q00 = q[p00], q01 = q[p01], q10 = q[p10], q11 = q[p11];
+          t0[c] = c < C ? tY.l0 * q00 + tY.l1 * q10 : -1e30f;
+          t1[c] = c < C ? tY.l0 * q01 + tY.l1 * q11 : -1e30f;
+          rL[c] = 0.f;
+          rR[c] = 0.f;
         }
-        float z = 0.f, vt = 0.f;
+        if (on) {
+          const int64_t *trow = target + ((int64_t)b * H + Y) * W;
+          const unsigned char *srow = tgt + (Y - RY0) * RW - RX0;
+          for (int X = Xlo; X <= Xhi; ++X) {
+            int t;
+            if (staged) {
+              t = srow[X];
+            } else {
+              const int64_t tt = trow[X];
+              t = tt == (int64_t)ignore_index ? kCeIgnore : ((tt < 0 || tt >= C) ? kCeBad : (int)tt);
+            }
+            // branch-free: an ignored / out-of-range pixel runs the same arithmetic with zero weights (divergent `continue`s made
+            // the compiler copy the rL / rR arrays around the branch: ~40 moves per pixel)
+            const bool okp = t < kCeBad;
+            const float first = head == 0 ? 1.f : 0.f;
+            bad += t == kCeBad ? first : 0.f;   // F.cross_entropy asserts on such a label; here it poisons the loss (NaN)
+            cnt += okp ? first : 0.f;
+            const Tap tX = tap_of(X, sx, w);
+            float v[CMAX];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-          vt = c == t ? v[c] - mx : vt;
-          v[c] = __expf(v[c] - mx);
-          z += v[c];
+            for (int c = 0; c < CMAX; ++c) {
+              v[c] = tX.l0 * t0[c] + tX.l1 * t1[c];
+              mx = fmaxf(mx, v[c]);
+            }
+            const float mxs = mx * kLog2e;
+            float z = 0.f, vt = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+              vt = c == t ? v[c] : vt;
+              v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], kLog2e, -mxs));     // exp(v - max)
+              z += v[c];
+            }
+            loss += okp ? logf(z) - (vt - mx) : 0.f;
+            if (grad) {
+              const float iz = 1.f / z;
+              const float wl = okp ? tX.l0 : 0.f, wr = okp ? tX.l1 : 0.f;
+#pragma unroll
+              for (int c = 0; c < CMAX; ++c) {
+                const float d = fmaf(v[c], iz, c == t ? -1.f : 0.f);       // softmax - onehot
+                rL[c] = fmaf(d, wl, rL[c]);
+                rR[c] = fmaf(d, wr, rR[c]);
+              }
+            }
+          }
         }
-        loss += logf(z) - vt;
         if (grad) {
-          const float wl = tX.l0 / z, wr = tX.l1 / z;
+          // fold the 8 rows of the cell onto its four corners: corner(k) += sum_rows wy(k) * r{L,R}; butterfly over the lane group
+          // (lanes 8g .. 8g+7), the same order for every launch
+          const float w0 = on ? tY.l0 : 0.f, w1 = on ? tY.l1 : 0.f;
 #pragma unroll
           for (int c = 0; c < CMAX; ++c) {
-            rL[c] += v[c] * wl - (c == t ? tX.l0 : 0.f);
-            rR[c] += v[c] * wr - (c == t ? tX.l1 : 0.f);
+            float a0 = w0 * rL[c], a1 = w0 * rR[c], a2 = w1 * rL[c], a3 = w1 * rR[c];
+            a0 = group8_sum(a0);
+            a1 = group8_sum(a1);
+            a2 = group8_sum(a2);
+            a3 = group8_sum(a3);
+            if (rslot == 0) {
+              csum[(0 * CMAX + c) * CELLS + cell] += a0;
+              csum[(1 * CMAX + c) * CELLS + cell] += a1;
+              csum[(2 * CMAX + c) * CELLS + cell] += a2;
+              csum[(3 * CMAX + c) * CELLS + cell] += a3;
+            }
           }
         }
       }
-      if (grad) {
+      if (grad && rslot == 0) {
+        // border cells: both taps of an axis are the same source pixel (i1 == i0) -> that axis' second corner IS the first
+        if (j1 == j) {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-          acc[(0 * CMAX + c) * NT + tid] += tY.l0 * rL[c];
-          acc[(1 * CMAX + c) * NT + tid] += tY.l0 * rR[c];
-          acc[(2 * CMAX + c) * NT + tid] += tY.l1 * rL[c];
-          acc[(3 * CMAX + c) * NT + tid] += tY.l1 * rR[c];
+          for (int c = 0; c < CMAX; ++c) {
+            csum[(0 * CMAX + c) * CELLS + cell] += csum[(2 * CMAX + c) * CELLS + cell];
+            csum[(1 * CMAX + c) * CELLS + cell] += csum[(3 * CMAX + c) * CELLS + cell];
+            csum[(2 * CMAX + c) * CELLS + cell] = 0.f;
+            csum[(3 * CMAX + c) * CELLS + cell] = 0.f;
+          }
+        }
+        if (i1 == i) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c) {
+            csum[(0 * CMAX + c) * CELLS + cell] += csum[(1 * CMAX + c) * CELLS + cell];
+            csum[(2 * CMAX + c) * CELLS + cell] += csum[(3 * CMAX + c) * CELLS + cell];
+            csum[(1 * CMAX + c) * CELLS + cell] = 0.f;
+            csum[(3 * CMAX + c) * CELLS + cell] = 0.f;
+          }
         }
       }
     }
+    if (head == 0) loss_m = loss; else loss_d = loss;
     if (grad) {
-      // border cells: both taps of an axis are the same source pixel (i1 == i0) -> that axis' second corner IS the first
-      if (j1 == j) {
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-          acc[(0 * CMAX + c) * NT + tid] += acc[(2 * CMAX + c) * NT + tid];
-          acc[(1 * CMAX + c) * NT + tid] += acc[(3 * CMAX + c) * NT + tid];
-          acc[(2 * CMAX + c) * NT + tid] = 0.f;
-          acc[(3 * CMAX + c) * NT + tid] = 0.f;
-        }
+      __syncthreads();
+      // the tile's nodes: node (ly, lx) = cell (ly, lx) corner 00 + cell (ly, lx - 1) corner 01 + cell (ly - 1, lx) corner 10 +
+      // cell (ly - 1, lx - 1) corner 11, in this order (cells outside the tile / the map hold zeros or are skipped)
+      for (int k = tid; k < C * (TJ + 1) * (TI + 1); k += NT) {
+        const int lx = k % (TI + 1), ly = (k / (TI + 1)) % (TJ + 1), c = k / ((TI + 1) * (TJ + 1));
+        const int y = ty * TJ + ly, x = tx * TI + lx;
+        if (y >= h || x >= w) continue;
+        float s = 0.f;
+        if (ly < TJ && lx < TI) s += csum[(0 * CMAX + c) * CELLS + ly * TI + lx];
+        if (ly < TJ && lx > 0) s += csum[(1 * CMAX + c) * CELLS + ly * TI + lx - 1];
+        if (ly > 0 && lx < TI) s += csum[(2 * CMAX + c) * CELLS + (ly - 1) * TI + lx];
+        if (ly > 0 && lx > 0) s += csum[(3 * CMAX + c) * CELLS + (ly - 1) * TI + lx - 1];
+        pnodes[(((((int64_t)b * heads + head) * C + c) * NTy + ty) * (TJ + 1) + ly) * rowlen + tx * (TI + 1) + lx] = s;
       }
-      if (i1 == i) {
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-          acc[(0 * CMAX + c) * NT + tid] += acc[(1 * CMAX + c) * NT + tid];
-          acc[(2 * CMAX + c) * NT + tid] += acc[(3 * CMAX + c) * NT + tid];
-          acc[(1 * CMAX + c) * NT + tid] = 0.f;
-          acc[(3 * CMAX + c) * NT + tid] = 0.f;
-        }
-      }
+      __syncthreads();                                   // before the next head clears the table
     }
   }
-  // loss partials of the workgroup: head 0 lanes carry the main loss and the counts, head 1 lanes the deep-supervision loss
-  float lm_ = head == 0 ? loss : 0.f, ld_ = head == 0 ? 0.f : loss;
-  float cn_ = head == 0 ? cnt : 0.f, bd_ = head == 0 ? bad : 0.f;
-  lm_ = wave_sum(lm_);
-  ld_ = wave_sum(ld_);
-  cn_ = wave_sum(cn_);
-  bd_ = wave_sum(bd_);
+  // loss partials of the workgroup
+  float lm_ = wave_sum(loss_m), ld_ = wave_sum(loss_d), cn_ = wave_sum(cnt), bd_ = wave_sum(bad);
   if ((tid & (kWave - 1)) == 0) {
     red[0][tid / kWave] = lm_;
     red[1][tid / kWave] = ld_;
@@ -260,23 +309,6 @@ __global__ __launch_bounds__(CeTile<CMAX>::TJ * CeTile<CMAX>::TI * (TWO ? 2 : 1)
     // a label outside [0, C) that is not ignore_index (raw Cityscapes ids, a mis-mapped label file) must not shrink the
     // valid set silently: the valid count becomes NaN, and with it the loss and every gradient of this call
     part[(int64_t)blockIdx.x * 3 + 2] = s3 > 0.f ? __builtin_nanf("") : s2;
-  }
-  if (!grad) return;
-  // the tile's nodes: node (ly, lx) = cell (ly, lx) corner 00 + cell (ly, lx - 1) corner 01 + cell (ly - 1, lx) corner 10 +
-  // cell (ly - 1, lx - 1) corner 11, in this order (cells outside the tile / the map hold zeros or are skipped)
-  constexpr int heads = TWO ? 2 : 1;
-  const int rowlen = NTx * (TI + 1);
-  for (int k = tid; k < heads * C * (TJ + 1) * (TI + 1); k += NT) {
-    const int lx = k % (TI + 1), ly = (k / (TI + 1)) % (TJ + 1), c = (k / ((TI + 1) * (TJ + 1))) % C, hd = k / ((TI + 1) * (TJ + 1) * C);
-    const int y = ty * TJ + ly, x = tx * TI + lx;
-    if (y >= h || x >= w) continue;
-    float s = 0.f;
-    const int base = hd * CELLS;
-    if (ly < TJ && lx < TI) s += acc[(0 * CMAX + c) * NT + base + ly * TI + lx];
-    if (ly < TJ && lx > 0) s += acc[(1 * CMAX + c) * NT + base + ly * TI + lx - 1];
-    if (ly > 0 && lx < TI) s += acc[(2 * CMAX + c) * NT + base + (ly - 1) * TI + lx];
-    if (ly > 0 && lx > 0) s += acc[(3 * CMAX + c) * NT + base + (ly - 1) * TI + lx - 1];
-    pnodes[(((((int64_t)b * heads + hd) * C + c) * NTy + ty) * (TJ + 1) + ly) * rowlen + tx * (TI + 1) + lx] = s;
   }
 }
 
@@ -353,21 +385,19 @@ using namespace skd;
 extern "C" {
 
 static int ce_cmax(int C) { return C <= 12 ? 12 : (C <= 19 ? 19 : (C <= 24 ? 24 : 64)); }
-static void ce_tiles(int C, int h, int w, int &TJ, int &TI, int &NTy, int &NTx) {
-  TJ = 8;
-  TI = ce_cmax(C) <= 24 ? 16 : 8;
-  NTy = (int)cdiv(h, TJ);
-  NTx = (int)cdiv(w, TI);
+static void ce_tiles(int h, int w, int &NTy, int &NTx) {
+  NTy = (int)cdiv(h, kCeTJ);
+  NTx = (int)cdiv(w, kCeTI);
 }
 
 int64_t skd_ce_dsn_workspace_floats(int B, int C, int h, int w, int H, int W) {
   (void)H;
   (void)W;
   if (B <= 0 || C <= 0 || h <= 0 || w <= 0) return 8;
-  int TJ, TI, NTy, NTx;
-  ce_tiles(C, h, w, TJ, TI, NTy, NTx);
+  int NTy, NTx;
+  ce_tiles(h, w, NTy, NTx);
   const int64_t wgs = (int64_t)B * NTy * NTx;
-  return 8 + wgs * 3 + (int64_t)B * 2 * C * NTy * (TJ + 1) * NTx * (TI + 1);
+  return 8 + wgs * 3 + (int64_t)B * 2 * C * NTy * (kCeTJ + 1) * NTx * (kCeTI + 1);
 }
 
 int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *logits_main,
@@ -380,8 +410,8 @@ int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lo
   hipStream_t st = as_stream(stream);
   const bool two = logits_dsn != nullptr;
   const int heads = two ? 2 : 1;
-  int TJ, TI, NTy, NTx;
-  ce_tiles(C, h, w, TJ, TI, NTy, NTx);
+  int NTy, NTx;
+  ce_tiles(h, w, NTy, NTx);
   const int64_t wgs = (int64_t)B * NTy * NTx;
   if (wgs > 2147483647) return 0;
   float *stat = workspace;
@@ -390,18 +420,18 @@ int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lo
   const float sy = scale_of(h, H), sx = scale_of(w, W);
 #define SKD_CE_LAUNCH(CM, TWO_)                                                                                              \
   do {                                                                                                                       \
-    constexpr int NT_ = CeTile<CM>::TJ * CeTile<CM>::TI * (TWO_ ? 2 : 1);                                                    \
-    const size_t lds_ = pnodes ? sizeof(float) * 4 * CM * NT_ : 0;                                                           \
+    const size_t lds_ = sizeof(float) * 4 * CM * kCeCells;                                                                   \
     static PerDeviceFlag attr_;                                                                                              \
     bool *done_ = attr_.get();                                                                                               \
     if (done_ && !*done_) {                                                                                                  \
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(ce_cells_kernel<CM, TWO_>),                                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * CM * NT_)) != hipSuccess) \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)                          \
         return 0;                                                                                                            \
       *done_ = true;                                                                                                         \
     }                                                                                                                        \
-    ce_cells_kernel<CM, TWO_><<<dim3((unsigned)wgs), dim3(NT_), lds_, st>>>(logits_main, logits_dsn, target, pnodes, part, B, \
-                                                                           C, h, w, H, W, ignore_index, sy, sx, NTy, NTx);   \
+    ce_cells_kernel<CM, TWO_><<<dim3((unsigned)wgs), dim3(kCeThreads), lds_, st>>>(logits_main, logits_dsn, target, pnodes,  \
+                                                                                 part, B, C, h, w, H, W, ignore_index, sy, \
+                                                                                 sx, NTy, NTx);                              \
   } while (0)
 #define SKD_CE(CM)              \
   do {                          \
@@ -420,10 +450,7 @@ int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lo
   if (pnodes != nullptr) {
     const int64_t n = (int64_t)B * heads * C * h * w;
     const dim3 grid((unsigned)cdiv(n, kThreads)), block(kThreads);
-    if (TI == 16)
-      ce_nodes_kernel<8, 16><<<grid, block, 0, st>>>(pnodes, stat, grad_main, grad_dsn, B, C, h, w, heads, aux_weight, NTy, NTx);
-    else
-      ce_nodes_kernel<8, 8><<<grid, block, 0, st>>>(pnodes, stat, grad_main, grad_dsn, B, C, h, w, heads, aux_weight, NTy, NTx);
+    ce_nodes_kernel<kCeTJ, kCeTI><<<grid, block, 0, st>>>(pnodes, stat, grad_main, grad_dsn, B, C, h, w, heads, aux_weight, NTy, NTx);
   }
   return ok();
 }

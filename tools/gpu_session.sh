@@ -219,7 +219,7 @@ for l in sys.stdin:
       # round 5, kernels rewritten this round: fused CE + upsample (cell formulation), channels-last pair-wise pooling, stem max-pool
       # backward over 2 x 2 blocks, pair-wise backward through the node-major copy, packed scalar read-back, the b8 golden step
       timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_step_gpu.py -m gpu -q --tb=short -s --durations=8 \
-        -k "ce_dsn or maxpool or pairwise or criteria or b8_vs_golden or config1 or full_step_vs_oracle or stem or networks_forward or bottleneck or psp" > $O/pytest_r5b.log 2>&1
+        -k "ce_dsn or maxpool or pairwise or criteria or operational_switches or b8_vs_golden or config1 or full_step_vs_oracle or stem or networks_forward or bottleneck or psp" > $O/pytest_r5b.log 2>&1
       stamp "tests_r5b rc=$?"; grep -E "passed|failed|error" $O/pytest_r5b.log | tail -3 | tee -a $O/session.log
       grep -E "^E  |^FAILED|LeakyReLU decisions|im2col" $O/pytest_r5b.log | cut -c1-300 | head -60 | tee -a $O/session.log ;;
   esac

@@ -177,16 +177,16 @@ def build_cases(lib, torch, dev, st):
         add("maxpool_argmax(pair-wise pooling)", [planes, 65, 65, kh], lambda planes=planes, kh=kh, fx=fx, po=po, pi=pi:
             lib.skd_maxpool_argmax(planes, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * planes * 65 * 65 + 8 * planes * oh * oh, keep=(fx, po, pi))
     # ... and its channels-last form (round 5: what the step runs -- the PSP features are pooled as they are) + the un-pool
-    for B_, C_, kh in ((8, 128, 32), (8, 512, 32), (8, 512, 1)):
-        fx = torch.randn(B_, 65, 65, C_, device=dev)
+    for Bp, Cp, kh in ((8, 128, 32), (8, 512, 32), (8, 512, 1)):
+        fx = torch.randn(Bp, 65, 65, Cp, device=dev)
         oh = -(-65 // kh)
-        po, pi = torch.empty(B_ * C_, oh * oh, device=dev), torch.empty(B_ * C_, oh * oh, dtype=torch.int32, device=dev)
-        add("maxpool_argmax_nhwc(pair-wise pooling)", [B_, C_, 65, 65, kh], lambda B_=B_, C_=C_, kh=kh, fx=fx, po=po, pi=pi:
-            lib.skd_maxpool_argmax_nhwc(B_, C_, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * B_ * C_ * 65 * 65 + 8 * B_ * C_ * oh * oh, keep=(fx, po, pi))
-        if C_ == 128:
-            dpo, dxx = torch.randn(B_ * C_, oh * oh, device=dev), torch.empty(B_, 65, 65, C_, device=dev)
-            add("maxunpool_scatter_nhwc", [B_, C_, 65, 65, kh], lambda B_=B_, C_=C_, kh=kh, dpo=dpo, pi=pi, dxx=dxx, oh=oh:
-                lib.skd_maxunpool_scatter_nhwc(B_, C_, 65, 65, kh, kh, p(dpo), oh * oh, p(pi), p(dxx), st), 4 * B_ * C_ * 65 * 65 + 8 * B_ * C_ * oh * oh,
+        po, pi = torch.empty(Bp * Cp, oh * oh, device=dev), torch.empty(Bp * Cp, oh * oh, dtype=torch.int32, device=dev)
+        add("maxpool_argmax_nhwc(pair-wise pooling)", [Bp, Cp, 65, 65, kh], lambda Bp=Bp, Cp=Cp, kh=kh, fx=fx, po=po, pi=pi:
+            lib.skd_maxpool_argmax_nhwc(Bp, Cp, 65, 65, kh, kh, p(fx), p(po), p(pi), st), 4 * Bp * Cp * 65 * 65 + 8 * Bp * Cp * oh * oh, keep=(fx, po, pi))
+        if Cp == 128:
+            dpo, dxx = torch.randn(Bp * Cp, oh * oh, device=dev), torch.empty(Bp, 65, 65, Cp, device=dev)
+            add("maxunpool_scatter_nhwc", [Bp, Cp, 65, 65, kh], lambda Bp=Bp, Cp=Cp, kh=kh, dpo=dpo, pi=pi, dxx=dxx, oh=oh:
+                lib.skd_maxunpool_scatter_nhwc(Bp, Cp, 65, 65, kh, kh, p(dpo), oh * oh, p(pi), p(dxx), st), 4 * Bp * Cp * 65 * 65 + 8 * Bp * Cp * oh * oh,
                 keep=(dpo, dxx))
     # evaluation tail (csrc/evaluate.hip): 8 B label + 1 B prediction per pixel, the 129 x 257 logits from cache
     el = torch.randn(1, 19, 129, 257, device=dev)
