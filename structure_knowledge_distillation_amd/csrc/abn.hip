@@ -1806,7 +1806,7 @@ static bool sync_fused_enabled() {          // read on every call: tests switch 
 
 // The grid barrier of the one-launch passes needs every workgroup of the launch co-resident: the grid is
 // capped by what THIS device can hold at one 1024-thread workgroup per compute unit -- 256 on a whole MI355X, 32 on a
-// CPX partition, fewer under HSA_CU_MASK -- queried once per device, never assumed.  skd_abn_set_fused_max_workgroups()
+// CPX partition -- queried once per device, never assumed (a CU MASK is not visible in that attribute: see below).  skd_abn_set_fused_max_workgroups()
 // lowers it further (ranks that share one device must share its compute units: utils/parallel.py does that).  A cap too
 // small for a tensor (rows per thread > NR) simply sends that call to the two-launch path.
 struct FuseCap {
@@ -1830,6 +1830,12 @@ static int fuse_wg_cap() {
     if (e != nullptr && e[0] != 0) env_cap = atoi(e);
     int cap = cus < kRedMaxWG ? cus : kRedMaxWG;
     if (env_cap < cap) cap = env_cap;
+    // A CU mask is NOT reflected in hipDeviceAttributeMultiprocessorCount: a masked process that trusted the
+    // attribute would launch a grid barrier that cannot be co-resident and sit in it until the time limit.  Parsing the mask
+    // formats is not this library's business: with a mask in the environment the one-launch passes are OFF (two-launch path)
+    // unless the user states the usable compute units with SKD_ABN_FUSED_MAXWG.
+    const char *m1 = getenv("HSA_CU_MASK"), *m2 = getenv("ROC_GLOBAL_CU_MASK");
+    if (((m1 != nullptr && m1[0] != 0) || (m2 != nullptr && m2[0] != 0)) && !(e != nullptr && e[0] != 0)) cap = 0;
     g_fuse_cap.cap[dev] = cap > 0 ? cap : 0;
     g_fuse_cap.known[dev] = true;
   }

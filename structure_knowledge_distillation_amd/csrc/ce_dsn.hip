@@ -90,7 +90,7 @@ constexpr int kCeTgtMax = 8192;       // bytes of LDS for a tile's target rectan
 constexpr unsigned char kCeIgnore = 255, kCeBad = 254;
 
 // part[(wg*3 + 0..2)] = sum of -log p (main), sum of -log p (dsn), number of valid pixels (NaN when a label is out of range)
-// pnodes: (B, heads, C, NTy, TJ + 1, NTx, TI + 1) per-tile node sums of the UNSCALED gradient, or NULL (loss only)
+// pnodes: (B, NTy, NTx, heads, C, TJ + 1, TI + 1) per-tile node sums of the UNSCALED gradient (tile-major), or NULL (loss only)
 //
 // Thread layout (round 5, second version).  The first cell formulation gave one lane a whole cell (64 pixels x ~420 instructions,
 // 256 registers): 1056 waves for 1024 SIMDs -- one wave per SIMD, nothing to hide a dependent-issue stall behind: 254 us
@@ -99,8 +99,11 @@ constexpr unsigned char kCeIgnore = 255, kCeBad = 254;
 // (softmax - onehot) x horizontal weight in registers), and the eight lanes' rows are folded onto the cell's four corners with a
 // 3-step butterfly inside the lane group (fixed order: bit-reproducible); lane 0 of the group adds the result into the
 // workgroup's corner table in LDS.  The two heads run one after the other over the same staged target rectangle.
+#ifndef SKD_CE_WAVES_PER_SIMD
+#define SKD_CE_WAVES_PER_SIMD 2       // tools/ce_lab.py measures 2 / 3 / 4 (register budget 256 / 168 / 128 per lane)
+#endif
 template <int CMAX, bool TWO>
-__global__ __launch_bounds__(kCeThreads) void ce_cells_kernel(
+__global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_kernel(
     const float *__restrict__ lm, const float *__restrict__ ld, const int64_t *__restrict__ target,
     float *__restrict__ pnodes, float *__restrict__ part, int B, int C, int h, int w, int H, int W, int ignore_index,
     float sy, float sx, int NTy, int NTx) {
@@ -150,7 +153,6 @@ __global__ __launch_bounds__(kCeThreads) void ce_cells_kernel(
   const unsigned o00 = j * w + i, o01 = j * w + i1, o10 = j1 * w + i, o11 = j1 * w + i1;     // the cell's four corner logits
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr int heads = TWO ? 2 : 1;
-  const int rowlen = NTx * (TI + 1);
   float loss_m = 0.f, loss_d = 0.f, cnt = 0.f, bad = 0.f;
   for (int head = 0; head < heads; ++head) {
     if (grad)
@@ -282,7 +284,9 @@ __global__ __launch_bounds__(kCeThreads) void ce_cells_kernel(
         if (ly < TJ && lx > 0) s += csum[(1 * CMAX + c) * CELLS + ly * TI + lx - 1];
         if (ly > 0 && lx < TI) s += csum[(2 * CMAX + c) * CELLS + (ly - 1) * TI + lx];
         if (ly > 0 && lx > 0) s += csum[(3 * CMAX + c) * CELLS + (ly - 1) * TI + lx - 1];
-        pnodes[(((((int64_t)b * heads + head) * C + c) * NTy + ty) * (TJ + 1) + ly) * rowlen + tx * (TI + 1) + lx] = s;
+        // tile-major: the (C, 9, 9) block of a (tile, head) is contiguous -- consecutive lanes write consecutive floats (the first
+        // layout interleaved the tiles' 9-float row pieces: 36-byte writes straddling 32-byte sectors, 11.8 MB written for 6.5)
+        pnodes[((int64_t)blockIdx.x * heads + head) * C * ((TJ + 1) * (TI + 1)) + k] = s;
       }
       __syncthreads();                                   // before the next head clears the table
     }
@@ -364,9 +368,10 @@ __global__ __launch_bounds__(kThreads) void ce_nodes_kernel(const float *__restr
   const int head = (int)((tid / ((int64_t)w * h * C)) % heads);
   const int b = (int)(tid / ((int64_t)w * h * C * heads));
   const int ty = y / TJ, ly = y - ty * TJ, tx = x / TI, lx = x - tx * TI;
-  const int rowlen = NTx * (TI + 1);
-  const float *base = pnodes + (((int64_t)b * heads + head) * C + c) * NTy * (TJ + 1) * rowlen;
-  auto at = [&](int ty_, int ly_, int tx_, int lx_) { return base[((int64_t)ty_ * (TJ + 1) + ly_) * rowlen + tx_ * (TI + 1) + lx_]; };
+  constexpr int NODES = (TJ + 1) * (TI + 1);
+  auto at = [&](int ty_, int ly_, int tx_, int lx_) {
+    return pnodes[((((int64_t)b * NTy + ty_) * NTx + tx_) * heads + head) * C * NODES + (int64_t)c * NODES + ly_ * (TI + 1) + lx_];
+  };
   const bool up = ly == 0 && ty > 0, left = lx == 0 && tx > 0;
   float s = at(ty, ly, tx, lx);
   if (left) s += at(ty, ly, tx - 1, TI);

@@ -244,32 +244,50 @@ __global__ __launch_bounds__(kThreads) void maxpool_window_nhwc_kernel(const flo
   }
 }
 
-// SMALL windows (many output cells): one lane per (image, output cell, channel quad)
+// SMALL windows (many output cells): a workgroup owns 32 consecutive output cells x 8 channel quads of one image; a lane scans
+// one (cell, quad) window with 16-byte loads, the (32 channels x 32 cells) results are turned through LDS and leave as 128-byte
+// runs along the cell axis of the planar (B, C, OH * OW) outputs.  (The first version let every lane store its four channels
+// straight away: 4-byte writes 4 * M * 4 bytes apart -- 1010 MB of write traffic for 139 MB at M = 4225, 393 us; gpurun r05c.)
+// grid: B * ceil(M / 32) * ceil(C4 / 8)
 __global__ __launch_bounds__(kThreads) void maxpool_cell_nhwc_kernel(const float *__restrict__ x, float *__restrict__ pooled,
-                                                                    int32_t *__restrict__ index, int64_t total, int C4, int H,
-                                                                    int W, int kh, int kw, int OH, int OW) {
-  const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t >= total) return;
-  const int quad = (int)(t % C4);
-  const int m = (int)((t / C4) % (OH * OW));
-  const int b = (int)(t / ((int64_t)C4 * OH * OW));
-  const int oh = m / OW, ow = m - oh * OW;
-  const int r0 = oh * kh, r1 = min(H, r0 + kh), c0 = ow * kw, c1 = min(W, c0 + kw);
-  Cand4 best;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    best.v[k] = -INFINITY;
-    best.idx[k] = r0 * W + c0;
-  }
-  const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
-  for (int r = r0; r < r1; ++r)
-    for (int c = c0; c < c1; ++c) scan4(best, *reinterpret_cast<const float4 *>(px + ((int64_t)r * W + c) * C4 * 4), r * W + c);
+                                                                    int32_t *__restrict__ index, int C4, int H, int W, int kh, int kw,
+                                                                    int OH, int OW) {
+  __shared__ float sv[32][33];
+  __shared__ int si[32][33];
   const int M = OH * OW;
+  const int nq = (C4 + 7) / 8, nm = (M + 31) / 32;
+  const int qt = (int)(blockIdx.x % nq), mt = (int)((blockIdx.x / nq) % nm), b = (int)(blockIdx.x / ((unsigned)nq * nm));
+  const int ql = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  const int quad = qt * 8 + ql, m = mt * 32 + cl;
+  if (quad < C4 && m < M) {
+    const int oh = m / OW, ow = m - oh * OW;
+    const int r0 = oh * kh, r1 = min(H, r0 + kh), c0 = ow * kw, c1 = min(W, c0 + kw);
+    Cand4 best;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      best.v[k] = -INFINITY;
+      best.idx[k] = r0 * W + c0;
+    }
+    const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
+    for (int r = r0; r < r1; ++r)
+      for (int c = c0; c < c1; ++c) scan4(best, *reinterpret_cast<const float4 *>(px + ((int64_t)r * W + c) * C4 * 4), r * W + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sv[ql * 4 + k][cl] = best.v[k];
+      si[ql * 4 + k][cl] = best.idx[k];
+    }
+  }
+  __syncthreads();
+  const int ch_l = threadIdx.x >> 3, ch = qt * 32 + ch_l;
+  if (ch >= C4 * 4) return;
+  const int64_t row = ((int64_t)b * C4 * 4 + ch) * M;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int64_t o = ((int64_t)b * C4 * 4 + quad * 4 + k) * M + m;
-    pooled[o] = best.v[k];
-    if (index != nullptr) index[o] = best.idx[k];
+    const int cell = (threadIdx.x & 7) * 4 + k, mm = mt * 32 + cell;
+    if (mm < M) {
+      pooled[row + mm] = sv[ch_l][cell];
+      if (index != nullptr) index[row + mm] = si[ch_l][cell];
+    }
   }
 }
 
@@ -822,10 +840,9 @@ int skd_maxpool_argmax_nhwc(int B, int C, int H, int W, int kh, int kw, const fl
     if (grid > 2147483647) return 0;
     maxpool_window_nhwc_kernel<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(x, pooled, index, C4, H, W, kh, kw, OH, OW, QB, S);
   } else {
-    const int64_t total = (int64_t)B * OH * OW * C4;
-    if (cdiv(total, kThreads) > 2147483647) return 0;
-    maxpool_cell_nhwc_kernel<<<dim3((unsigned)cdiv(total, kThreads)), dim3(kThreads), 0, st>>>(x, pooled, index, total, C4, H, W, kh,
-                                                                                              kw, OH, OW);
+    const int64_t grid = (int64_t)B * cdiv((int64_t)OH * OW, 32) * cdiv(C4, 8);
+    if (grid > 2147483647) return 0;
+    maxpool_cell_nhwc_kernel<<<dim3((unsigned)grid), dim3(kThreads), 0, st>>>(x, pooled, index, C4, H, W, kh, kw, OH, OW);
   }
   return ok();
 }

@@ -826,6 +826,9 @@ def test_bench_under_torchrun_two_ranks_over_gloo():
     # channels-last layers exchange inside the ABN calls; the (B, C, 1, 1) pyramid stage is NCHW-contiguous: from Python
     assert comm["syncabn_in_abn_calls"] >= 50 and comm["abn_sync_call_ms"] > 0 and comm["syncabn_one_launch_calls"] >= 40
     assert comm["buckets"] >= 2 and comm["allreduce_wait_ms"] >= 0 and comm["backend"] == "gloo"
+    # the warm-up's safety net (bench.warm_up_with_fallback) ran and had nothing to do: first form, no fallback; over gloo on a
+    # shared device the configured form is the in-kernel exchange (over RCCL the default is the three-launch form)
+    assert comm["forms_tried"] == 1 and comm["fallback_reason"] is None and "exchange inside" in comm["form"], comm
 
 
 # ---------------------------------------------------------------------------------------------------

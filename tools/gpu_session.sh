@@ -122,7 +122,8 @@ PYEOF
     pmc2)
       # counters in their own passes (no --stats / sys-trace next to --pmc): HBM bytes and the MFMA pipe, over the microbench
       i=0
-      for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+      for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+                 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; do
         i=$((i+1))
         (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o k -- \
           python $R/tools/kernel_microbench.py pmc > $O/pmc$i.log 2>&1)
@@ -141,7 +142,7 @@ PYEOF
         done
         find $O/pmc$i -name "*kernel_trace.csv" -delete
       done
-      python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 >> $O/session.log 2>&1
+      python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 >> $O/session.log 2>&1
       stamp "pmc2 summarised" ;;
     timeline)
       # ONE kernel trace of the default step (teacher = hipGraph replay, D step on its stream; no HIP-event bracketing) -> per-stream
@@ -211,6 +212,9 @@ for l in sys.stdin:
     d = json.loads(l); print('   %.1f img/s %.2f ms/step comm=%s' % (d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
         done
       fi ;;
+    ce_lab)
+      timeout 200 python tools/ce_lab.py > $O/ce_lab.jsonl 2> $O/ce_lab.err
+      stamp "ce_lab rc=$?"; cat $O/ce_lab.jsonl | tee -a $O/session.log ;;
     dist)
       SKD_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline > $O/bench_dist.json 2> $O/bench_dist.err
