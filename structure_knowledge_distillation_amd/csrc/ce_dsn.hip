@@ -90,7 +90,8 @@ constexpr int kCeTgtMax = 8192;       // bytes of LDS for a tile's target rectan
 constexpr unsigned char kCeIgnore = 255, kCeBad = 254;
 
 // part[(wg*3 + 0..2)] = sum of -log p (main), sum of -log p (dsn), number of valid pixels (NaN when a label is out of range)
-// pnodes: (B, NTy, NTx, heads, C, TJ + 1, TI + 1) per-tile node sums of the UNSCALED gradient (tile-major), or NULL (loss only)
+// pnodes: (B, heads, C, NTy, TJ + 1, NTx, TI + 1) per-tile node sums of the UNSCALED gradient, or NULL (loss only).  (A tile-major
+// layout was measured too -- 7.0 instead of 11.8 MB written, but 15.4 instead of 7.9 MB read back by ce_nodes: gpurun r05c / r05d.)
 //
 // Thread layout (round 5, second version).  The first cell formulation gave one lane a whole cell (64 pixels x ~420 instructions,
 // 256 registers): 1056 waves for 1024 SIMDs -- one wave per SIMD, nothing to hide a dependent-issue stall behind: 254 us
@@ -114,7 +115,14 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
   __shared__ float red[4][NW];
   const int tid = threadIdx.x;
   const int rslot = tid & (kCeRows - 1), cell = tid >> 3, lj = cell / TI, li = cell % TI;
-  const int tx = (int)(blockIdx.x % NTx), ty = (int)((blockIdx.x / NTx) % NTy), b = (int)(blockIdx.x / ((unsigned)NTx * NTy));
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so XCD k takes the k-th CONTIGUOUS
+  // eighth of the tile list -- whole images at batch 8.  Neighbouring tiles share 128-byte lines of the 65-float logit rows and
+  // of the target rows; spread over eight L2s every one of them fetched those lines again (43.8 MB read from the fabric for
+  // 22 MB of data, profiles/r05d_pmc.json).
+  const unsigned ntiles = (unsigned)B * NTy * NTx, chunk = (ntiles + 7u) / 8u;
+  const unsigned tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int tx = (int)(tile % NTx), ty = (int)((tile / NTx) % NTy), b = (int)(tile / ((unsigned)NTx * NTy));
   const int j = ty * TJ + lj, i = tx * TI + li;
   const bool valid = j < h && i < w;
   const bool grad = pnodes != nullptr;
@@ -153,6 +161,7 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
   const unsigned o00 = j * w + i, o01 = j * w + i1, o10 = j1 * w + i, o11 = j1 * w + i1;     // the cell's four corner logits
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr int heads = TWO ? 2 : 1;
+  const int rowlen = NTx * (TI + 1);
   float loss_m = 0.f, loss_d = 0.f, cnt = 0.f, bad = 0.f;
   for (int head = 0; head < heads; ++head) {
     if (grad)
@@ -284,9 +293,7 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
         if (ly < TJ && lx > 0) s += csum[(1 * CMAX + c) * CELLS + ly * TI + lx - 1];
         if (ly > 0 && lx < TI) s += csum[(2 * CMAX + c) * CELLS + (ly - 1) * TI + lx];
         if (ly > 0 && lx > 0) s += csum[(3 * CMAX + c) * CELLS + (ly - 1) * TI + lx - 1];
-        // tile-major: the (C, 9, 9) block of a (tile, head) is contiguous -- consecutive lanes write consecutive floats (the first
-        // layout interleaved the tiles' 9-float row pieces: 36-byte writes straddling 32-byte sectors, 11.8 MB written for 6.5)
-        pnodes[((int64_t)blockIdx.x * heads + head) * C * ((TJ + 1) * (TI + 1)) + k] = s;
+        pnodes[(((((int64_t)b * heads + head) * C + c) * NTy + ty) * (TJ + 1) + ly) * rowlen + tx * (TI + 1) + lx] = s;
       }
       __syncthreads();                                   // before the next head clears the table
     }
@@ -308,11 +315,11 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
       s2 += red[2][k];
       s3 += red[3][k];
     }
-    part[(int64_t)blockIdx.x * 3 + 0] = s0;
-    part[(int64_t)blockIdx.x * 3 + 1] = s1;
+    part[(int64_t)tile * 3 + 0] = s0;
+    part[(int64_t)tile * 3 + 1] = s1;
     // a label outside [0, C) that is not ignore_index (raw Cityscapes ids, a mis-mapped label file) must not shrink the
     // valid set silently: the valid count becomes NaN, and with it the loss and every gradient of this call
-    part[(int64_t)blockIdx.x * 3 + 2] = s3 > 0.f ? __builtin_nanf("") : s2;
+    part[(int64_t)tile * 3 + 2] = s3 > 0.f ? __builtin_nanf("") : s2;
   }
 }
 
@@ -368,10 +375,9 @@ __global__ __launch_bounds__(kThreads) void ce_nodes_kernel(const float *__restr
   const int head = (int)((tid / ((int64_t)w * h * C)) % heads);
   const int b = (int)(tid / ((int64_t)w * h * C * heads));
   const int ty = y / TJ, ly = y - ty * TJ, tx = x / TI, lx = x - tx * TI;
-  constexpr int NODES = (TJ + 1) * (TI + 1);
-  auto at = [&](int ty_, int ly_, int tx_, int lx_) {
-    return pnodes[((((int64_t)b * NTy + ty_) * NTx + tx_) * heads + head) * C * NODES + (int64_t)c * NODES + ly_ * (TI + 1) + lx_];
-  };
+  const int rowlen = NTx * (TI + 1);
+  const float *base = pnodes + (((int64_t)b * heads + head) * C + c) * NTy * (TJ + 1) * rowlen;
+  auto at = [&](int ty_, int ly_, int tx_, int lx_) { return base[((int64_t)ty_ * (TJ + 1) + ly_) * rowlen + tx_ * (TI + 1) + lx_]; };
   const bool up = ly == 0 && ty > 0, left = lx == 0 && tx > 0;
   float s = at(ty, ly, tx, lx);
   if (left) s += at(ty, ly, tx - 1, TI);
@@ -434,7 +440,7 @@ int skd_ce_dsn_forward(int B, int C, int h, int w, int H, int W, const float *lo
         return 0;                                                                                                            \
       *done_ = true;                                                                                                         \
     }                                                                                                                        \
-    ce_cells_kernel<CM, TWO_><<<dim3((unsigned)wgs), dim3(kCeThreads), lds_, st>>>(logits_main, logits_dsn, target, pnodes,  \
+    ce_cells_kernel<CM, TWO_><<<dim3((unsigned)(8 * cdiv(wgs, 8))), dim3(kCeThreads), lds_, st>>>(logits_main, logits_dsn, target, pnodes,  \
                                                                                  part, B, C, h, w, H, W, ignore_index, sy, \
                                                                                  sx, NTy, NTx);                              \
   } while (0)

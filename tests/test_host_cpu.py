@@ -80,6 +80,19 @@ def test_criteria_host_wiring():
         a = C.CriterionPairWiseforWholeFeatAfterPool(scale, -5)(S, T)
         b = O.criterion_pair_wise(So, To, scale, -5)
         assert abs(float(a) - float(b)) < 1e-5 * abs(float(b))
+    # channels-last features (what NetModel hands the pair-wise criterion since round 5): pooled as they are
+    # (skd_maxpool_argmax_nhwc), same loss bits, the gradient comes back channels-last with the same values
+    for scale in (0.5, 0.1):
+        ref = C.CriterionPairWiseforWholeFeatAfterPool(scale, -5)
+        fs0 = S[2].detach().clone().requires_grad_(True)
+        l0 = ref([None, None, fs0] + [None] * 4, T)
+        l0.backward()
+        fs1 = S[2].detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ft1 = T[2].contiguous(memory_format=torch.channels_last)
+        l1 = ref([None, None, fs1] + [None] * 4, [None, None, ft1] + [None] * 4)
+        l1.backward()
+        assert float(l1) == float(l0)
+        assert fs1.grad.is_contiguous(memory_format=torch.channels_last) and torch.equal(fs1.grad.contiguous(), fs0.grad)
 
 
 def test_spectral_norm_wrapper_state_and_quirk():
