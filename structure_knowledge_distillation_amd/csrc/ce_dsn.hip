@@ -194,14 +194,15 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
         if (on) {
           const int64_t *trow = target + ((int64_t)b * H + Y) * W;
           const unsigned char *srow = tgt + (Y - RY0) * RW - RX0;
+          auto label = [&](int X) -> int {
+            if (staged) return srow[X];
+            const int64_t tt = trow[X];
+            return tt == (int64_t)ignore_index ? kCeIgnore : ((tt < 0 || tt >= C) ? kCeBad : (int)tt);
+          };
+          int t_next = label(Xlo);
           for (int X = Xlo; X <= Xhi; ++X) {
-            int t;
-            if (staged) {
-              t = srow[X];
-            } else {
-              const int64_t tt = trow[X];
-              t = tt == (int64_t)ignore_index ? kCeIgnore : ((tt < 0 || tt >= C) ? kCeBad : (int)tt);
-            }
+            const int t = t_next;
+            t_next = label(X < Xhi ? X + 1 : X);       // the next pixel's label is fetched behind this pixel's arithmetic
             // branch-free: an ignored / out-of-range pixel runs the same arithmetic with zero weights (divergent `continue`s made
             // the compiler copy the rL / rR arrays around the branch: ~40 moves per pixel)
             const bool okp = t < kCeBad;
@@ -209,21 +210,24 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
             bad += t == kCeBad ? first : 0.f;   // F.cross_entropy asserts on such a label; here it poisons the loss (NaN)
             cnt += okp ? first : 0.f;
             const Tap tX = tap_of(X, sx, w);
+            // (four interleaved max / sum chains: with two waves per SIMD a 19-long dependent chain of v_max / v_add is pure latency)
             float v[CMAX];
-            float mx = -INFINITY;
+            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
               v[c] = tX.l0 * t0[c] + tX.l1 * t1[c];
-              mx = fmaxf(mx, v[c]);
+              m4[c & 3] = fmaxf(m4[c & 3], v[c]);
             }
+            const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
             const float mxs = mx * kLog2e;
-            float z = 0.f, vt = 0.f;
+            float z4[4] = {0.f, 0.f, 0.f, 0.f}, vt = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
               vt = c == t ? v[c] : vt;
               v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], kLog2e, -mxs));     // exp(v - max)
-              z += v[c];
+              z4[c & 3] += v[c];
             }
+            const float z = (z4[0] + z4[1]) + (z4[2] + z4[3]);
             loss += okp ? logf(z) - (vt - mx) : 0.f;
             if (grad) {
               const float iz = 1.f / z;

@@ -833,10 +833,9 @@ int skd_maxpool_argmax_nhwc(int B, int C, int H, int W, int kh, int kw, const fl
   const int OH = (int)cdiv(H, kh), OW = (int)cdiv(W, kw), C4 = C / 4;
   const int wh = kh < H ? kh : H, ww = kw < W ? kw : W;
   if ((int64_t)wh * ww >= 64) {
-    // quads per workgroup: 32 (512-byte row pieces) unless that leaves the chip half empty -- the student's 17 MB map at the
-    // default 3 x 3 pooling is 8 x 9 windows: 72 workgroups of 32 quads, 288 of 8 (19 us -> measured in profiles/r05*_micro.jsonl)
-    int QB = C4 < 32 ? C4 : 32;
-    while (QB > 8 && QB % 2 == 0 && (int64_t)B * OH * OW * cdiv(C4, QB) < 512) QB /= 2;
+    // (fewer quads per workgroup for more workgroups on the student's small map was measured and is WORSE -- 26 instead of 19 us:
+    // 128-byte row pieces and a longer merge; gpurun r05e)
+    const int QB = C4 < 32 ? C4 : 32;
     int S = kThreads / QB;
     if (S > ww) S = ww;                                   // no more column slots than window columns
     const int64_t grid = (int64_t)B * OH * OW * cdiv(C4, QB);
