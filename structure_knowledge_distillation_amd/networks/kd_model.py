@@ -272,22 +272,27 @@ class NetModel():
             _lib.raise_on_device_errors()      # the read above synchronised: a timed-out in-kernel wait of this step is visible
         return v
 
-    def _publish_scalars(self):
+    def _publish_scalars(self, stream=None):
         """End of a step: the logged scalars (device tensors) are packed by one small kernel and sent to a pinned host buffer with
         ONE asynchronous copy; ``print_info`` / the attribute reads then cost one wait instead of one blocking ``.item()`` each.
         Measured (profiles/r05a_timeline.md): the five reads of train_and_eval.py:26 were five serial D2H copies ~27 us apart with the
-        GPU idle at every step boundary (the reference stalls four times INSIDE the step, kd_model.py:127-165)."""
+        GPU idle at every step boundary (the reference stalls four times INSIDE the step, kd_model.py:127-165).
+        ``stream``: where the LAST scalar of the step is produced (the D stream when the D step runs on its own): packing there keeps
+        the cross-stream hand-off (150-280 us under the profiler, profiles/r05f_timeline.md) out of the read-back's path."""
         tensors = {k: v for k, v in self._scalars.items() if torch.is_tensor(v)}
         if not tensors or not all(t.is_cuda and t.dtype == torch.float32 for t in tensors.values()):
             self._scalar_pending = None
             return
-        packed = torch.stack([t.reshape(()) for t in tensors.values()])
-        host = getattr(self, "_scalar_host", None)
-        if host is None or host.numel() != len(tensors):
-            host = self._scalar_host = torch.empty(len(tensors), dtype=torch.float32, pin_memory=True)
-        host.copy_(packed, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record(torch.cuda.current_stream(packed.device))
+        dev = next(iter(tensors.values())).device
+        stream = torch.cuda.current_stream(dev) if stream is None else stream
+        with torch.cuda.stream(stream):
+            packed = torch.stack([t.reshape(()) for t in tensors.values()])
+            host = getattr(self, "_scalar_host", None)
+            if host is None or host.numel() != len(tensors):
+                host = self._scalar_host = torch.empty(len(tensors), dtype=torch.float32, pin_memory=True)
+            host.copy_(packed, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(stream)
         self._scalar_pending = (tensors, host, event)
 
     mc_G_loss = property(lambda self: self._get_scalar("mc_G_loss"))
@@ -457,7 +462,6 @@ class NetModel():
             _lib.raise_on_device_errors()      # a host load, no synchronisation: errors of the steps already executed
         try:
             self._optimize_parameters()
-            self._publish_scalars()
         finally:
             parallel_old.clear_replica_batch()     # the per-rank sample weights belong to THIS step (set_input)
 
@@ -471,6 +475,8 @@ class NetModel():
             self.G_solver.step()
             if ho:
                 self.discriminator_backward()
+            if torch.device(self.args.device).type == "cuda":
+                self._publish_scalars()
             return
         # Same operations, same order per data dependency: the D step may start as soon as the student's logits have
         # received their gradient -- by then the student loss has finished back-propagating through D, so D's
@@ -497,6 +503,7 @@ class NetModel():
             side.wait_stream(main)
         with torch.cuda.stream(side):
             self.discriminator_backward()
+        self._publish_scalars(side)         # the G step's scalars were produced on the main stream before `ready` was recorded
         main.wait_stream(side)
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
