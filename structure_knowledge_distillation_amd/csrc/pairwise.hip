@@ -190,21 +190,6 @@ __device__ __forceinline__ void scan4(Cand4 &b, const float4 x, int flat) {
     }
 }
 
-// the same update when positions do NOT arrive in row-major order (column chunks of a wide window): PyTorch's result is "the
-// first maximum in row-major order, the last NaN when there is one" = the candidate order of better() -- independent of visit order
-__device__ __forceinline__ void scan4_any(Cand4 &b, const float4 x, int flat) {
-  const float xv[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const Cand cand{xv[k], flat}, cur{b.v[k], b.idx[k]};
-    // (the initial candidate is (-inf, window start): an all -inf window keeps it, like PyTorch's untouched maxindex)
-    if (better(cand, cur) && !(xv[k] == -INFINITY && b.v[k] == -INFINITY)) {
-      b.v[k] = xv[k];
-      b.idx[k] = flat;
-    }
-  }
-}
-
 // LARGE windows (the reference default pools 65 x 65 to 3 x 3): one workgroup per (image, output cell, block of QB channel
 // quads); its 256 lanes = QB quads x S column slots scan the window's rows, then the S candidates of a quad are merged in slot
 // order with the planar kernel's tie rule.  grid: B * OH * OW * ceil(C4 / QB)
@@ -228,29 +213,13 @@ __global__ __launch_bounds__(kThreads) void maxpool_window_nhwc_kernel(const flo
     best.idx[k] = r0 * W + c0;
   }
   if (on) {
-    // two rows x four column slots = eight 16-byte loads in flight per lane before the first compare (one row at a time left the
-    // 69 MB teacher map at 2.6 TB/s: 288 workgroups x 4 loads in flight do not cover the HBM latency); the scan below visits
-    // the positions in row-major order again, so the first-maximum / last-NaN rule is unchanged
+    // (two rows x four column slots in flight per lane with an order-independent update was measured too: 70 / 89 us instead of
+    // 19 / 27 -- the register arrays and the full candidate compare cost more than the deeper pipeline gains; gpurun r05g)
     const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int cb = c0 + s; cb < c1; cb += 4 * S) {            // (one pass for windows up to 4 * S columns wide)
-      for (int r = r0; r < r1; r += 2) {
-        float4 a[2][4];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int c = cb + u * S;
-            a[rr][u] = (r + rr < r1 && c < c1) ? *reinterpret_cast<const float4 *>(px + ((int64_t)(r + rr) * W + c) * C4 * 4) : zero4;
-          }
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int c = cb + u * S;
-            if (r + rr < r1 && c < c1) scan4_any(best, a[rr][u], (r + rr) * W + c);
-          }
-      }
+    for (int r = r0; r < r1; ++r) {
+      const float *pr = px + (int64_t)r * W * C4 * 4;
+#pragma unroll 4
+      for (int c = c0 + s; c < c1; c += S) scan4(best, *reinterpret_cast<const float4 *>(pr + (int64_t)c * C4 * 4), r * W + c);
     }
   }
   cand[threadIdx.x] = best;
