@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kCeThreads, SKD_CE_WAVES_PER_SIMD) void ce_cells_ke
             bad += t == kCeBad ? first : 0.f;   // F.cross_entropy asserts on such a label; here it poisons the loss (NaN)
             cnt += okp ? first : 0.f;
             const Tap tX = tap_of(X, sx, w);
-            // (four interleaved max / sum chains: with two waves per SIMD a 19-long dependent chain of v_max / v_add is pure latency)
+            // (four interleaved max / sum chains instead of 19-long dependent ones.  Also measured and NOT adopted, tools/ce_lab.py: two
+            // pixels per iteration as independent instruction streams -- 141 vs 136 us --, 3 / 4 waves per SIMD -- 169 / 201 vs 157 us)
             float v[CMAX];
             float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
