@@ -212,6 +212,18 @@ for l in sys.stdin:
     d = json.loads(l); print('   %.1f img/s %.2f ms/step comm=%s' % (d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
         done
       fi ;;
+    ab_r04)
+      # same-box A/B against the round-4 tree (git archive e78944f into _r04_tree/, built here, git-ignored): box-to-box variation is
+      # +-1 %, the round's gains are of that size, so the two trees alternate on ONE box
+      for i in 1 2 3; do
+        for t in new old; do
+          d=$R; [ $t = old ] && d=$R/_r04_tree
+          (cd $d && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > $O/ab_${t}_$i.json 2>> $O/ab.err
+          stamp "ab_r04 $t $i rc=$?"; python -c "
+import json,sys
+d=json.loads([l for l in open('$O/ab_${t}_$i.json') if l.startswith('{')][0]); print('   $t $i: %.2f img/s %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a $O/session.log
+        done
+      done ;;
     ce_lab)
       timeout 200 python tools/ce_lab.py > $O/ce_lab.jsonl 2> $O/ce_lab.err
       stamp "ce_lab rc=$?"; cat $O/ce_lab.jsonl | tee -a $O/session.log ;;
