@@ -403,7 +403,9 @@ def main():
              "skd_abn_forward_train_nhwc", "skd_abn_backward_reduce_nhwc", "skd_abn_backward_dx_nhwc",
              "skd_abn_relu_backward_reduce_nhwc", "skd_abn_relu_backward_dx_nhwc",
              "skd_abn_relu_backward_reduce_nhwc_x", "skd_abn_relu_backward_dx_nhwc_x", "skd_abn_backward_nhwc",
-             "skd_abn_relu_backward_nhwc"]
+             "skd_abn_relu_backward_nhwc",
+             # round 5: the kernels rewritten this round, as they run inside the step
+             "skd_ce_dsn_forward", "skd_maxpool_argmax_nhwc", "skd_maxpool3x3s2_backward_nhwc"]
     # Inside the timed region only the ROOFLINE entry is bracketed with HIP events (111 calls per step; bracketing all
     # ~700 hand-written calls costs 1.4 ms = 1.8 % of the step -- measured, profiles/r02 notes); the table of the other
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
@@ -549,6 +551,25 @@ def main():
             "skd_abn_backward_reduce_nhwc (leaky ABN, 8 B/elem)": summarise(recs.get("skd_abn_backward_reduce_nhwc", []), 8, nhwc="train"),
             "skd_abn_backward_dx_nhwc (leaky ABN, 12 B/elem)": summarise(recs.get("skd_abn_backward_dx_nhwc", []), 12, nhwc="train"),
         }
+        def plain(name, nbytes, what, bound):
+            r = recs.get(name, [])
+            if not r:
+                return None
+            tot_ms = sum(ms for ms, _ in r)
+            tot_b = sum(nbytes(d) for _, d in r)
+            # avg_elems = 0 keeps a kernel that is not HBM-bound out of the "worst HBM fraction" pick below
+            return {"launches": len(r), "avg_us": round(1e3 * tot_ms / len(r), 2), "avg_elems": round(tot_b / 4 / len(r)) if bound == "hbm" else 0,
+                    "achieved_GBs": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "bound": bound, "algorithmic_bytes": what}
+        line["kernels"].update({
+            "skd_ce_dsn_forward (fused upsample + CE of both heads + gradients, csrc/ce_dsn.hip)": plain(
+                "skd_ce_dsn_forward", lambda d: 8.0 * d[0] * a.size * a.size + 16.0 * d[0] * d[1] * d[2] * d[3],
+                "int64 target + 2 x (logits in + gradients out): 27.05 MB at batch 8", "valu (19-class softmax per up-sampled pixel, exp / log)"),
+            "skd_maxpool_argmax_nhwc (pair-wise pooling of the channels-last PSP features)": plain(
+                "skd_maxpool_argmax_nhwc", lambda d: 4.0 * d[0] * d[1] * d[2] * d[3], "one read of the feature map", "hbm"),
+            "skd_maxpool3x3s2_backward_nhwc (stem max-pool backward)": plain(
+                "skd_maxpool3x3s2_backward_nhwc", lambda d: 4.0 * d[0] * d[1] * d[2] * d[3] + 5.0 * d[0] * d[1] * (d[2] // 2 + 1) * (d[3] // 2 + 1),
+                "4 B per input element out + 5 B per output element in", "hbm"),
+        })
         line["kernels"] = {k: v for k, v in line["kernels"].items() if v}
         line["kernels_note"] = "HIP-event rates from three extra untimed steps run with the D step serial (no co-running stream)"
         if line["kernels"]:

@@ -7,8 +7,8 @@
 //   forward   nine 16-byte loads, the running maximum under PyTorch's rule (`val > max || isnan(val)`, windows scanned
 //             row-major from the first valid position, so ties keep the FIRST maximum and NaN propagates), and the
 //             winner's position inside its window as one byte (0..8) -- none at all for the frozen teacher;
-//   backward  gather form: every INPUT position looks at the <= 4 windows that contain it and adds the gradients of the
-//             ones it won -- no atomics, every element of dx written exactly once, deterministic.
+//   backward  gather form over 2 x 2 blocks of INPUT positions: the four windows that can contain them are loaded once and every
+//             position adds the gradients of the ones it won -- no atomics, every element of dx written exactly once, deterministic.
 // HBM-bound: forward reads x once (neighbouring windows hit L2) and writes 4 + 1 bytes per output element; backward
 // reads 4 + 1 bytes per output element and writes dx once.
 #include "skd_common.hpp"
