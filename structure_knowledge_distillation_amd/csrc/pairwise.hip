@@ -213,37 +213,12 @@ __global__ __launch_bounds__(kThreads) void maxpool_window_nhwc_kernel(const flo
     best.idx[k] = r0 * W + c0;
   }
   if (on) {
+    // One row per trip, four 16-byte loads in flight per lane.  Three attempts to go deeper were MEASURED and lost (gpurun r05e / r05g /
+    // r05k, profiles/r05k_pooling_variants.txt): fewer quads per workgroup for more workgroups (26 / 36 us instead of 19 / 27), two
+    // rows per trip through register arrays with an order-independent compare (70 / 89 us), two rows per trip in plain registers
+    // (36 / 63 us).  2.6 TB/s on the 69 MB teacher map is where this formulation stands.
     const float *px = x + (int64_t)b * H * W * C4 * 4 + (int64_t)quad * 4;
-    int r = r0;
-    if (c1 - c0 <= 4 * S) {
-      // windows of at most four column slots per lane (the default 32-wide window with S = 8): TWO rows per trip, eight 16-byte loads
-      // in flight before the first compare, scanned in row-major order (row r's columns, then row r + 1's): the same candidates in the
-      // same order as one row at a time.  (One row per trip left the 69 MB teacher map at 2.6 TB/s: 288 workgroups x 4 loads in
-      // flight do not cover the HBM latency.  A version with register ARRAYS and an order-independent compare ran 3x slower, r05g.)
-      const int ca = c0 + s, cbb = ca + S, cc = ca + 2 * S, cd = ca + 3 * S;
-      const bool va = ca < c1, vb = cbb < c1, vc = cc < c1, vd = cd < c1;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (; r + 1 < r1; r += 2) {
-        const float *p0 = px + (int64_t)r * W * C4 * 4, *p1 = p0 + (int64_t)W * C4 * 4;
-        const float4 a0 = va ? *reinterpret_cast<const float4 *>(p0 + (int64_t)ca * C4 * 4) : z4;
-        const float4 a1 = vb ? *reinterpret_cast<const float4 *>(p0 + (int64_t)cbb * C4 * 4) : z4;
-        const float4 a2 = vc ? *reinterpret_cast<const float4 *>(p0 + (int64_t)cc * C4 * 4) : z4;
-        const float4 a3 = vd ? *reinterpret_cast<const float4 *>(p0 + (int64_t)cd * C4 * 4) : z4;
-        const float4 b0 = va ? *reinterpret_cast<const float4 *>(p1 + (int64_t)ca * C4 * 4) : z4;
-        const float4 b1 = vb ? *reinterpret_cast<const float4 *>(p1 + (int64_t)cbb * C4 * 4) : z4;
-        const float4 b2 = vc ? *reinterpret_cast<const float4 *>(p1 + (int64_t)cc * C4 * 4) : z4;
-        const float4 b3 = vd ? *reinterpret_cast<const float4 *>(p1 + (int64_t)cd * C4 * 4) : z4;
-        if (va) scan4(best, a0, r * W + ca);
-        if (vb) scan4(best, a1, r * W + cbb);
-        if (vc) scan4(best, a2, r * W + cc);
-        if (vd) scan4(best, a3, r * W + cd);
-        if (va) scan4(best, b0, (r + 1) * W + ca);
-        if (vb) scan4(best, b1, (r + 1) * W + cbb);
-        if (vc) scan4(best, b2, (r + 1) * W + cc);
-        if (vd) scan4(best, b3, (r + 1) * W + cd);
-      }
-    }
-    for (; r < r1; ++r) {
+    for (int r = r0; r < r1; ++r) {
       const float *pr = px + (int64_t)r * W * C4 * 4;
 #pragma unroll 4
       for (int c = c0 + s; c < c1; c += S) scan4(best, *reinterpret_cast<const float4 *>(pr + (int64_t)c * C4 * 4), r * W + c);
