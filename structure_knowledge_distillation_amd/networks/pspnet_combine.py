@@ -239,15 +239,24 @@ class ResNet(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        if _fused(self, x):
+        if _fused(self, x) and not self.training and getattr(self.bn3, "activation", None) == "none":
+            # Frozen network: eval-mode BN + ReLU is a non-decreasing map per channel (its scale (|gamma| + eps) / sqrt(var + eps) is
+            # positive and every fp32 step of it -- subtract, multiply, multiply-add, max(., 0) -- is monotone), so it COMMUTES with
+            # the max-pool bit for bit: relu(bn(max(window))) == max(relu(bn(.)) over the window).  The pass over the 268 MB
+            # conv3 output becomes a pass over the 68 MB pooled map (pspnet_combine.py:131-135; VERDICT r04 missing 5).
             x = self.bn1.forward_relu(self.conv1(x))
             x = self.bn2.forward_relu(self.conv2(x))
-            x = self.bn3.forward_relu(self.conv3(x))
+            x = self.bn3.forward_relu(SF.max_pool_stem(self.conv3(x), self.maxpool))
         else:
-            x = self.relu1(self.bn1(self.conv1(x)))
-            x = self.relu2(self.bn2(self.conv2(x)))
-            x = self.relu3(self.bn3(self.conv3(x)))
-        x = SF.max_pool_stem(x, self.maxpool)       # csrc/maxpool.hip for channels-last maps, the stock op otherwise
+            if _fused(self, x):
+                x = self.bn1.forward_relu(self.conv1(x))
+                x = self.bn2.forward_relu(self.conv2(x))
+                x = self.bn3.forward_relu(self.conv3(x))
+            else:
+                x = self.relu1(self.bn1(self.conv1(x)))
+                x = self.relu2(self.bn2(self.conv2(x)))
+                x = self.relu3(self.bn3(self.conv3(x)))
+            x = SF.max_pool_stem(x, self.maxpool)       # csrc/maxpool.hip for channels-last maps, the stock op otherwise
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)

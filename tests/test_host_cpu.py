@@ -175,6 +175,11 @@ def test_inference_fusion_equals_unfused_graph():
         plain = net(x.clone().requires_grad_(True))
         for a, b in zip(fused, plain):
             assert rel(a, b) < 1e-5
+        # the frozen stem runs eval BN + ReLU AFTER the max-pool (a monotone map commutes with max): the same BITS as before it
+        with torch.no_grad():
+            c3 = net.conv3(net.bn2.forward_relu(net.conv2(net.bn1.forward_relu(net.conv1(x)))))
+            assert torch.equal(net.bn3.forward_relu(PC.SF.max_pool_stem(c3.clone(), net.maxpool)),
+                               PC.SF.max_pool_stem(net.bn3.forward_relu(c3.clone()), net.maxpool))
     from structure_knowledge_distillation_amd import libs
     with pytest.raises(RuntimeError):
         libs.abn_eval_fused(torch.randn(1, 2, 3, 3, requires_grad=True) * 1.0, None, None, torch.zeros(2), torch.ones(2))
