@@ -600,6 +600,35 @@ def test_teacher_dsn_head_is_optional_and_everything_else_unchanged():
     assert model.preds_T[1] is not None and model.mc_T_loss > 0
 
 
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_classifier_head_is_conv2d_with_a_two_stage_bias_gradient(channels_last):
+    """The 19-class heads (pspnet_combine.py:138-154) are ``nn.Conv2d`` with the same parameters and keys; only the REDUCTION of the
+    bias gradient is split in two (rows first) -- same numbers as the stock module's backward up to summation order."""
+    torch.manual_seed(0)
+    head = PC_MOD.ClassifierConv(32, 19, 1, 1, 0, bias=True).double()
+    stock = torch.nn.Conv2d(32, 19, 1, 1, 0, bias=True).double()
+    stock.load_state_dict(head.state_dict())
+    assert isinstance(head, torch.nn.Conv2d) and list(head.state_dict()) == ["weight", "bias"]
+    x = torch.randn(3, 32, 9, 11, dtype=torch.double)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(3, 19, 9, 11, dtype=torch.double)
+    ya, yb = head(xa), stock(xb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad) and torch.equal(head.weight.grad, stock.weight.grad)
+    assert rel(head.bias.grad, stock.bias.grad) < 1e-14
+    with torch.no_grad():
+        assert torch.equal(head(x), stock(x))
+    head.weight.requires_grad_(False)                     # frozen weight, live bias: no weight gradient is computed or returned
+    head.zero_grad()
+    head(x.clone().requires_grad_(True)).backward(g)
+    assert head.weight.grad is None and rel(head.bias.grad, stock.bias.grad) < 1e-14
+    net = PC_MOD.Res_pspnet(PC_MOD.BasicBlock, [2, 2, 2, 2], 19)
+    assert isinstance(net.head, PC_MOD.ClassifierConv) and isinstance(net.dsn[3], PC_MOD.ClassifierConv)
+
+
 def test_device_identity_tells_physical_gpus_apart():
     """utils.parallel.device_identity: what SyncMailbox uses to count the ranks that share ITS device (their grid-barrier launches
     are capped at 1 / N of the compute units).  Eight ranks on eight GPUs must never look like eight ranks on one -- whether or not
