@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pairwise-sweep", action="store_true")
+    ap.add_argument("--losses", default="pi,pa,ho", help="distillation terms of the step (BASELINE configs[2]: all three); the CPU "
+                                                       "rehearsal of the launcher runs 'pi,pa' at 256x256 (no 65x65 logits for D there)")
+    ap.add_argument("--device", default="cuda", choices=("cuda", "cpu"),
+                    help="'cpu' is the launcher REHEARSAL only (tests/test_distributed_cpu.py): it needs a C-ABI test double installed "
+                         "by the test's sitecustomize and refuses to run otherwise; nothing is measured in that mode")
     ap.add_argument("--dsn-ab", action="store_true", help="also re-time the step without the teacher's dead DSN head (informative; opt-in: "
                                                          "the default run stays exactly the measured configuration and nothing else)")
     return ap.parse_args()
@@ -347,8 +352,44 @@ def warm_up_with_fallback(build, warmup, world, dev, warm_timeout_s=30.0, run_ti
     raise SystemExit("bench.py: every form of the cross-replica exchange failed its warm-up: " + "; then ".join(reasons))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` (N > 1) started WITHOUT torchrun -- the N = 1 command with the number changed, which is how a
+    driver would start it: re-run this very command line under ``python -m torch.distributed.run`` (one process per GPU, 127.0.0.1
+    rendezvous on a free port), let rank 0's ONE JSON line through on the inherited stdout and return the launcher's exit code.
+    With fewer than N devices (and no SKD_DIST_BACKEND=gloo device sharing) nothing is started: a JSON line with "error" and rc 2."""
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count() if (a.device == "cuda" and torch.cuda.is_available()) else 0
+    shared = os.environ.get("SKD_DIST_BACKEND") == "gloo"      # N ranks on fewer devices: tests / 1-GPU boxes only (init_distributed)
+    if a.device == "cuda" and (ndev == 0 or (ndev < a.gpus and not shared)):
+        print(json.dumps({"metric": "distillation-step images/sec @512x512 (Pi+Pa+Ho)", "value": None, "unit": "images/sec",
+                          "n_gpus": a.gpus, "error": "--gpus %d asked for, %d GPU(s) visible to this process (torch.cuda.device_count()); "
+                                                     "one process per GPU is the only multi-GPU form" % (a.gpus, ndev)}), flush=True)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.environ.get("SKD_BENCH_ENTRY") or os.path.abspath(__file__)] + sys.argv[1:]     # (the tests' wrapper names itself there)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL, the SyncABN mailboxes)
+    env.setdefault("OMP_NUM_THREADS", "8")                      # torchrun would set 1 and say so on stderr
+    sys.stderr.write("bench.py: --gpus %d without torchrun: starting %s\n" % (a.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     from structure_knowledge_distillation_amd import _lib
@@ -362,14 +403,24 @@ def main():
     os.environ.setdefault("SKD_DIST_TIMEOUT_S", "300")       # torch.distributed collectives: same idea (utils/parallel.init_distributed)
     rank, world, local = P.init_distributed()
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % a.gpus)
-        a.gpus = world
-    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
-    _lib.load()
-    dev = torch.device("cuda", torch.cuda.current_device())
+        a.gpus = world                                       # torchrun's world is authoritative
+    if a.device == "cpu":
+        # launcher rehearsal (tests/test_distributed_cpu.py): the test's sitecustomize has installed a C-ABI double; without one
+        # there is nothing to run -- this package has no CPU path
+        if not _lib.test_backend_active():
+            raise SystemExit("bench.py --device cpu: no C-ABI test double installed (rehearsal mode of the tests only)")
+        dev = torch.device("cpu")
+        a.no_kernel_timing = a.no_pairwise_sweep = a.no_cpu_baseline = True
+        torch.cuda.synchronize = lambda *x, **k: None
+    else:
+        assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+        _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
     # args.batch_size is the reference's GLOBAL batch (nn.DataParallel scatters it); every rank holds a.batch images
-    args = default_args(batch_size=a.batch * world, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000)
+    terms = set(a.losses.split(","))
+    assert terms <= {"pi", "pa", "ho"}, a.losses
+    args = default_args(batch_size=a.batch * world, device=dev, weight_decay=5e-4, lambda_pa=0.5, num_steps=40000,
+                        pi="pi" in terms, pa="pa" in terms, ho="ho" in terms)
     gen = torch.Generator().manual_seed(100 + rank)
     images = (torch.randn(a.batch, 3, a.size, a.size, generator=gen) * 57.0).to(dev)
     labels = torch.randint(0, 19, (a.batch, a.size, a.size), generator=gen)
@@ -489,8 +540,11 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]%s: ResNet18-PSPNet student + frozen ResNet101-PSPNet teacher, "
-                               "Pi+Pa+Ho (SAGAN D, spectral norm, WGAN-GP), batch %d per GPU, %dx%d, 19 classes"
-                               % (" x %d ranks (configs[3])" % world if world > 1 else "", a.batch, a.size, a.size),
+                               "%s, batch %d per GPU, %dx%d, 19 classes"
+                               % (" x %d ranks (configs[3])" % world if world > 1 else "",
+                                  "Pi+Pa+Ho (SAGAN D, spectral norm, WGAN-GP)" if terms == {"pi", "pa", "ho"} else
+                                  "+".join(t.capitalize() for t in ("pi", "pa", "ho") if t in terms) + " ONLY (not the BASELINE configuration)",
+                                  a.batch, a.size, a.size),
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                    "losses_last_step": {k: round(float(v), 6) for k, v in
                                         zip(("G", "mc", "pi", "pa", "D"), losses)}},
@@ -579,7 +633,11 @@ def main():
     if comm is None and comm_setup is not None:          # --no-kernel-timing: still say which form of the exchange ran
         comm = {"form": comm_setup["form"], "fallback_reason": comm_setup["fallback_reason"], "forms_tried": comm_setup["attempts"]}
     if comm is not None:
+        comm["backend"] = dist.get_backend()
+        comm["ranks"] = dist.get_world_size()            # what the process group (RCCL on a GPU node) reports, not the flag
         line["comm"] = comm
+    if a.device == "cpu":
+        line["rehearsal"] = "launcher rehearsal on the C-ABI double (tests only): NOT a measurement"
     if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:

@@ -585,3 +585,45 @@ def test_bench_warm_up_falls_back_to_the_next_exchange_form_on_a_device_status_w
     # the reason is a timed-out exchange on at least one rank (the other may only have heard of it through the all-reduce)
     assert any("timed out" in o["info"]["fallback_reason"] or "status words" in o["info"]["fallback_reason"] for o in outs)
     assert outs[0]["losses"][0] != outs[1]["losses"][0]          # different shards
+
+
+# ---------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` started WITHOUT torchrun: the N = 1 command with the number changed must start its
+# own ranks (bench.self_launch: torch.distributed.run on 127.0.0.1, a free port), and rank 0's ONE JSON line must come out of the
+# parent's stdout with the parent's exit code 0.  Rehearsed on the CPU double through tests/integration/bench_cpu_double.py (the
+# wrapper only installs the double; bench.py refuses --device cpu without one).
+def _launch_bench(extra, env_extra=None, entry=None, timeout=800):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    entry = entry or os.path.join(ROOT, "tests", "integration", "bench_cpu_double.py")
+    p = subprocess.run([sys.executable, entry] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, [json.loads(l) for l in lines]
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_without_torchrun_launches_its_own_ranks_and_prints_one_line():
+    p, lines = _launch_bench(["--gpus", "2", "--device", "cpu", "--size", "256", "--batch", "1", "--losses", "pi,pa",
+                              "--steps", "2", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout                                 # rank 0 only
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 1e3 / line["ms_per_step"]) < 1e-2 * line["value"]      # whole-job images/s
+    assert line["comm"]["ranks"] == 2 and line["comm"]["backend"] == "gloo" and line["comm"]["form"]
+    assert line["comm"]["fallback_reason"] is None and "rehearsal" in line
+    assert all(v == v for v in line["config"]["losses_last_step"].values())
+    assert "torch.distributed.run" in p.stderr                       # the parent says what it started
+
+
+def test_bench_gpus_8_on_a_box_without_gpus_fails_with_a_device_count_message():
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("needs a box with fewer than 8 GPUs")
+    p, lines = _launch_bench(["--gpus", "8", "--steps", "20", "--warmup", "5"], entry=os.path.join(ROOT, "bench.py"),
+                             env_extra={"SKD_DIST_BACKEND": ""}, timeout=300)
+    assert p.returncode == 2
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 8
+    assert "GPU(s) visible" in lines[0]["error"] and "torchrun" not in lines[0]["error"]
