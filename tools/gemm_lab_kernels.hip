@@ -21,7 +21,8 @@ struct Stg {
 
 template <int RA, int RB, int RPP, int SEL = 3>
 __device__ __forceinline__ void lab_gload(Stg<RA, RB> &o, const float *__restrict__ X, const float *__restrict__ Wt, int64_t m0, int grow, int gkq,
-                                          int64_t wrow0, int64_t M, int K, int k0) {
+                                          int64_t wrow0, int64_t M, int K, int k0, int KW = 0) {
+  if (KW == 0) KW = K;            // row stride of the B operand (the padded-weights experiment)
   if (SEL & 1) {
 #pragma unroll
     for (int h = 0; h < RA; ++h) {
@@ -31,7 +32,7 @@ __device__ __forceinline__ void lab_gload(Stg<RA, RB> &o, const float *__restric
   }
   if (SEL & 2) {
 #pragma unroll
-    for (int h = 0; h < RB; ++h) o.b[h] = *reinterpret_cast<const float4 *>(Wt + wrow0 + (int64_t)(RPP * h) * K + k0 + gkq);
+    for (int h = 0; h < RB; ++h) o.b[h] = *reinterpret_cast<const float4 *>(Wt + wrow0 + (int64_t)(RPP * h) * KW + k0 + gkq);
   }
 }
 template <int RA, int RB, int RPP, int LDK, int TM>
@@ -44,7 +45,7 @@ __device__ __forceinline__ void lab_sstore(const Stg<RA, RB> v, float *stage, in
 
 template <int BK, int WM, int WN, int MINWG, int MODE, int WVM = 2, int WVN = 2>
 __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const float *__restrict__ X, const float *__restrict__ Wt,
-                                                             float *__restrict__ Y, int64_t M, int K, int N, int tiles_n) {
+                                                             float *__restrict__ Y, int64_t M, int K, int N, int tiles_n, int ld, int ldw) {
   constexpr int NT = 64 * WVM * WVN;             // threads
   constexpr int TM = 32 * WM * WVM, TN = 32 * WN * WVN;
   constexpr int LDK = BK + 4;
@@ -67,8 +68,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const fl
   const int nk = K / BK;
   const int t = threadIdx.x, grow = t / QK, gkq = (t % QK) * 4;
   const int srow = grow * LDK + gkq;
-  const int64_t wrow0 = (int64_t)(n0 + grow) * K;
+  const int64_t wrow0 = (int64_t)(n0 + grow) * ldw;
   Stg<RA, RB> st;
+  // MODE 7: every workgroup starts its K loop at a different K-tile (and wraps): at any instant the workgroups of the chip read
+  // DIFFERENT 64-byte columns of their power-of-two-strided rows (L2 channel spreading)
+  const int rot = MODE == 7 ? (int)((blockIdx.x * 5u) % (unsigned)nk) : 0;
+  auto ktile = [&](int kt) { int q = kt + rot; return (q >= nk ? q - nk : q) * BK; };
   const int lane = t & (kWave - 1), wid = t / kWave;
   const int wi = (wid / WVN) * 32 * WM, wj = (wid % WVN) * 32 * WN;
   const int half = lane >> 5, r = lane & 31;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const fl
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * WM * WN, 0);
     }
   };
-  lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, 0);
+  lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, ktile(0), ldw);
   lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds, srow);
   __syncthreads();
   int stage = 0;
@@ -131,15 +136,15 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const fl
     if (MODE == 6) {
       // two K-tiles ahead: st holds tile kt + 1 (already loaded), st2 receives tile kt + 2 while tile kt is multiplied
       Stg<RA, RB> st2;
-      if (nk > 1) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, BK);
+      if (nk > 1) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, BK);
       for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st2, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 2) * BK);
+        if (kt + 2 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st2, X, Wt, m0, grow, gkq, wrow0, M, ld, (kt + 2) * BK);
         mma(lds + stage * STAGE);
         if (kt + 1 < nk) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
         __syncthreads();
         stage ^= 1;
         if (kt + 1 >= nk) break;
-        if (kt + 3 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 3) * BK);
+        if (kt + 3 < nk) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, (kt + 3) * BK);
         mma(lds + stage * STAGE);
         if (kt + 2 < nk) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st2, lds + (stage ^ 1) * STAGE, srow);
         __syncthreads();
@@ -148,9 +153,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const fl
     } else {
       for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (MODE == 0 && more) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
-        if (MODE == 4 && more) lab_gload<RA, RB, ROWS_PER_PASS, 1>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
-        if (MODE == 5 && more) lab_gload<RA, RB, ROWS_PER_PASS, 2>(st, X, Wt, m0, grow, gkq, wrow0, M, K, (kt + 1) * BK);
+        if ((MODE == 0 || MODE == 7) && more) lab_gload<RA, RB, ROWS_PER_PASS>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, ktile(kt + 1), ldw);
+        if (MODE == 4 && more) lab_gload<RA, RB, ROWS_PER_PASS, 1>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, (kt + 1) * BK);
+        if (MODE == 5 && more) lab_gload<RA, RB, ROWS_PER_PASS, 2>(st, X, Wt, m0, grow, gkq, wrow0, M, ld, (kt + 1) * BK);
         mma(lds + stage * STAGE);
         if (MODE != 2) {
           if (more) lab_sstore<RA, RB, ROWS_PER_PASS, LDK, TM>(st, lds + (stage ^ 1) * STAGE, srow);
@@ -175,7 +180,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINWG) void tn_gemm_kernel(const fl
 }
 
 template <int BK, int WM, int WN, int MINWG, int MODE, int WVM = 2, int WVN = 2>
-int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N) {
+int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N, int pad = 0, int padw = -1) {
+  if (padw < 0) padw = pad;
   constexpr int TM = 32 * WM * WVM, TN = 32 * WN * WVN;
   constexpr size_t lds = sizeof(float) * 2 * (TM + TN) * (BK + 4);
   if (K % BK || N % TN) return 0;
@@ -187,7 +193,7 @@ int launch_tn(const float *X, const float *Wt, float *Y, int64_t M, int K, int N
   }
   const int tiles_n = N / TN;
   const int64_t tiles_m = (M + TM - 1) / TM;
-  tn_gemm_kernel<BK, WM, WN, MINWG, MODE, WVM, WVN><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WVM * WVN), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n);
+  tn_gemm_kernel<BK, WM, WN, MINWG, MODE, WVM, WVN><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(64 * WVM * WVN), lds, 0>>>(X, Wt, Y, M, K, N, tiles_n, K + pad, K + padw);
   return hipGetLastError() == hipSuccess;
 }
 
@@ -428,6 +434,26 @@ extern "C" int lab_tn_gemm(int variant, const float *X, const float *Wt, float *
     case 20: return launch_tn<16, 4, 2, 2, 0>(X, Wt, Y, M, K, N);         // 256 x 128 x 16, 4 waves of 128 x 64 (128 accumulators), 2 workgroups / CU
     case 21: return launch_tn<16, 2, 4, 2, 0>(X, Wt, Y, M, K, N);         // 128 x 256 x 16, 4 waves of 64 x 128
     case 22: return launch_tn<16, 4, 4, 1, 0>(X, Wt, Y, M, K, N);         // (= 8) 256 x 256 x 16, 4 waves of 128 x 128, 1 workgroup / CU
+    // round 6: SMALL tiles at HIGH occupancy -- what MIOpen's igemm kernels (bt128x64x16/32, 0.78-0.88 of the peak) do
+    case 23: return launch_tn<16, 2, 1, 5, 0>(X, Wt, Y, M, K, N);         // 128 x 64 x 16, 4 waves of 64 x 32 (32 accumulators), 5 workgroups / CU
+    case 24: return launch_tn<16, 1, 2, 5, 0>(X, Wt, Y, M, K, N);         // 64 x 128 x 16, 4 waves of 32 x 64
+    case 25: return launch_tn<16, 1, 1, 8, 0>(X, Wt, Y, M, K, N);         // 64 x 64 x 16, 4 waves of 32 x 32, 8 workgroups / CU
+    case 26: return launch_tn<16, 2, 1, 4, 0>(X, Wt, Y, M, K, N);         // 128 x 64 x 16, 4 workgroups / CU (128 registers)
+    case 27: return launch_tn<32, 2, 1, 2, 0>(X, Wt, Y, M, K, N);         // 128 x 64 x 32, 2 workgroups / CU (55 KB LDS)
+    case 28: return launch_tn<16, 2, 1, 5, 1>(X, Wt, Y, M, K, N);         // 128 x 64 x 16 5wg, no global loads in the loop
+    case 29: return launch_tn<16, 2, 1, 5, 3>(X, Wt, Y, M, K, N);         // 128 x 64 x 16 5wg, MFMA only
+    // round 6: is it the L2 CHANNELS?  rows of both operands are a power of two apart (K * 4 bytes): (a) row stride K + 32 floats
+    // (data differs: no check), (b) K loop rotated per workgroup
+    case 30: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N, 32);     // 128 x 128 x 16 3wg, row stride K + 32
+    case 31: return launch_tn<16, 2, 2, 3, 7>(X, Wt, Y, M, K, N);         // 128 x 128 x 16 3wg, rotated K loop
+    case 32: return launch_tn<16, 2, 1, 5, 0>(X, Wt, Y, M, K, N, 32);     // 128 x 64 x 16 5wg, row stride K + 32
+    case 33: return launch_tn<16, 2, 1, 5, 7>(X, Wt, Y, M, K, N);         // 128 x 64 x 16 5wg, rotated K loop
+    case 34: return launch_tn<32, 2, 2, 2, 0>(X, Wt, Y, M, K, N, 32);     // 128 x 128 x 32 2wg, row stride K + 32
+    case 35: return launch_tn<32, 2, 2, 2, 7>(X, Wt, Y, M, K, N);         // 128 x 128 x 32 2wg, rotated K loop
+    case 36: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N, 32, 0);  // 128 x 128 x 16 3wg, only the ACTIVATION rows padded
+    case 37: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N, 0, 32);  // 128 x 128 x 16 3wg, only the WEIGHT rows padded
+    case 38: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N, 0, 4);   //   ... weight rows padded by 4 floats (16 bytes)
+    case 39: return launch_tn<16, 2, 2, 3, 0>(X, Wt, Y, M, K, N, 0, 16);  //   ... by 16 floats (64 bytes)
     default: return -1;
   }
 }
@@ -439,6 +465,14 @@ extern "C" const char *lab_tn_name(int variant) {
                                 "128x128x32 2wg/cu 2-ahead",  "128x128x16 glds 3wg/cu",    "128x128x16 glds 4wg/cu",
                                 "256x128x16 8 waves 2wg/cu",  "128x256x16 8 waves 2wg/cu", "256x256x16 16 waves 1wg/cu",
                                 "128x128x16 persistent 3wg/cu", "128x128x16 persistent 2wg/cu",
-                                "256x128x16 4 waves 2wg/cu",  "128x256x16 4 waves 2wg/cu", "256x256x16 4 waves 1wg/cu"};
-  return variant >= 0 && variant < 23 ? names[variant] : nullptr;
+                                "256x128x16 4 waves 2wg/cu",  "128x256x16 4 waves 2wg/cu", "256x256x16 4 waves 1wg/cu",
+                                "128x64x16 5wg/cu",           "64x128x16 5wg/cu",          "64x64x16 8wg/cu",
+                                "128x64x16 4wg/cu",           "128x64x32 2wg/cu",          "128x64x16 5wg/cu no-gload",
+                                "128x64x16 5wg/cu mfma-only",
+                                "128x128x16 3wg/cu stride K+32 no-check", "128x128x16 3wg/cu rotated-K",
+                                "128x64x16 5wg/cu stride K+32 no-check",  "128x64x16 5wg/cu rotated-K",
+                                "128x128x32 2wg/cu stride K+32 no-check", "128x128x32 2wg/cu rotated-K",
+                                "128x128x16 3wg/cu X stride K+32 no-check", "128x128x16 3wg/cu W stride K+32 no-check",
+                                "128x128x16 3wg/cu W stride K+4 no-check",  "128x128x16 3wg/cu W stride K+16 no-check"};
+  return variant >= 0 && variant < 40 ? names[variant] : nullptr;
 }

@@ -212,6 +212,50 @@ for l in sys.stdin:
     d = json.loads(l); print('   %.1f img/s %.2f ms/step comm=%s' % (d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
         done
       fi ;;
+    selflaunch)
+      # round 6: `python bench.py --gpus 2` WITHOUT torchrun (the driver's command form): bench.self_launch starts the ranks itself.
+      # On a 1-GPU box the two ranks share the device over gloo (SKD_DIST_BACKEND=gloo); without that switch the same command must
+      # print the device-count error line and exit 2.
+      (SKD_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 2 --batch 4 --no-cpu-baseline) > $O/bench_selflaunch.json 2> $O/bench_selflaunch.err
+      stamp "selflaunch (gloo, shared device) rc=$?"; cut -c1-700 $O/bench_selflaunch.json | tee -a $O/session.log
+      (timeout 100 python bench.py --gpus 8 --steps 20 --warmup 5) > $O/bench_selflaunch_8.json 2> $O/bench_selflaunch_8.err
+      stamp "selflaunch --gpus 8 on this box rc=$? (2 expected on a 1-GPU box)"; cut -c1-400 $O/bench_selflaunch_8.json | tee -a $O/session.log ;;
+    dstream2)
+      # round 6: is the D step hidden when TWO ranks share the chip?  SKD_D_STREAM=1/0, SKD_D_GRAPH=0/1
+      for v in "SKD_D_STREAM=1" "SKD_D_STREAM=0" "SKD_D_GRAPH=1"; do
+        f="$O/bench_2ranks_$(echo $v | tr ' =' '__').json"
+        (env $v SKD_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --steps 5 --warmup 3 --batch 4 --no-cpu-baseline --no-kernel-timing) > "$f" 2>> $O/bench_2ranks.err
+        stamp "dstream2 $v rc=$?"; cut -c1-260 "$f" | tee -a $O/session.log
+      done ;;
+    ab_env)
+      # generic same-box A/B of environment switches: AB_ENVS="A=1;A=0;B=1 C=2" (one leg per ';'), three alternations, 20 timed steps
+      IFS=';' read -ra LEGS <<< "${AB_ENVS:-SKD_NOOP=0}"
+      for i in 1 2 3; do
+        for v in "${LEGS[@]}"; do
+          f="$O/ab_$(echo $v | tr ' =' '__')_$i.json"
+          (env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > "$f" 2>> $O/ab_env.err
+          stamp "ab_env [$v] $i rc=$?"; python -c "
+import json,sys
+d=json.loads([l for l in open('$f') if l.startswith('{')][0]); print('   [$v] $i: %.2f img/s %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a $O/session.log
+        done
+      done ;;
+    ab_const)
+      # same-box A/B of module constants (tools/ab_patch.py): AB_CONSTS="functional.PAD_WEIGHTS=True;functional.PAD_WEIGHTS=False"
+      IFS=';' read -ra LEGS <<< "${AB_CONSTS:-functional.PAD_WEIGHTS=True;functional.PAD_WEIGHTS=False}"
+      for i in 1 2 3; do
+        for v in "${LEGS[@]}"; do
+          f="$O/abc_$(echo $v | tr ' =.' '___')_$i.json"
+          (timeout 300 python tools/ab_patch.py $v -- bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > "$f" 2>> $O/ab_const.err
+          stamp "ab_const [$v] $i rc=$?"; python -c "
+import json,sys
+d=json.loads([l for l in open('$f') if l.startswith('{')][0]); print('   [$v] $i: %.2f img/s %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a $O/session.log
+        done
+      done ;;
+    tests_k)
+      # a -k selection of the GPU tests: TESTS_K="conv1x1 or bottleneck"
+      timeout 1200 python -m pytest tests -m gpu -q --tb=short -s --durations=8 -k "${TESTS_K:-conv1x1}" > $O/pytest_k.log 2>&1
+      stamp "tests_k [${TESTS_K:-conv1x1}] rc=$?"; grep -E "passed|failed|error" $O/pytest_k.log | tail -3 | tee -a $O/session.log
+      grep -E "^E  |^FAILED" $O/pytest_k.log | cut -c1-300 | head -40 | tee -a $O/session.log ;;
     ab_r04)
       # same-box A/B against the round-4 tree (git archive e78944f into _r04_tree/, built here, git-ignored): box-to-box variation is
       # +-1 %, the round's gains are of that size, so the two trees alternate on ONE box

@@ -105,6 +105,7 @@ def main():
     out.append("|---|---|---|---|---|---|---|---|---|")
     agg = collections.Counter()
     gaps_all, cat_main, cat_d, tails = [], collections.Counter(), collections.Counter(), collections.Counter()
+    stock, stock_n, stock_ctx = collections.Counter(), collections.Counter(), collections.defaultdict(collections.Counter)
     for k, (b0, b1) in enumerate(sel):
         inside = [r for r in rows if r[0] >= b0 and r[1] <= b1 + 1]
         mi = [(s, e) for s, e, q, _ in inside if q == main_q]
@@ -133,6 +134,17 @@ def main():
                 cur_end, cur_name = e, n
         if b1 - cur_end > GAP_US * 1e3:
             gaps_all.append((b1 - cur_end, overlap([[cur_end, b1]], ud), cur_name, "(step end: D stream's last kernel)", lo + k, (cur_end - b0) / 1e6))
+        # round 6: the STOCK kernels on the main stream by name, each with the library / hand-written kernel that
+        # follows it most often (the consumer names the producer: a zero-fill in front of a split-K wrw solver, a gradient add in
+        # front of an ABN backward ...)
+        for i, (s, e, n) in enumerate(ms):
+            c = category(n)
+            if c.startswith(("torch", "MIOpen layout")):
+                key = short(n)[:70]
+                stock[key] += e - s
+                stock_n[key] += 1
+                nxt = next((short(n2)[:60] for _, _, n2 in ms[i + 1:i + 6] if not category(n2).startswith(("torch", "MIOpen layout"))), "(none within 5)")
+                stock_ctx[key][nxt] += 1
         for s, e, q, n in inside:
             (cat_main if q == main_q else cat_d)[category(n)] += e - s
             if q == d_q and e > main_last:
@@ -145,6 +157,11 @@ def main():
     out.append("## Main stream, kernel time per step by category\n\n| category | ms / step |\n|---|---|")
     for c, v in cat_main.most_common():
         out.append("| %s | %.2f |" % (c, v / n / 1e6))
+    out.append("\n## Main stream: stock (torch / MIOpen tensor-op) kernels by name\n\n%.2f ms per step in %d launches.\n\n| kernel | launches / step | ms / step | "
+               "next non-stock kernel (most frequent) |\n|---|---|---|---|" % (sum(stock.values()) / n / 1e6, sum(stock_n.values()) // n))
+    for key, v in stock.most_common(30):
+        ctx = ", ".join("`%s` x%d" % (a, b // n) for a, b in stock_ctx[key].most_common(3))
+        out.append("| `%s` | %.1f | %.3f | %s |" % (key, stock_n[key] / n, v / n / 1e6, ctx))
     out.append("\n## D stream, kernel time per step by category\n\n| category | ms / step |\n|---|---|")
     for c, v in cat_d.most_common():
         out.append("| %s | %.2f |" % (c, v / n / 1e6))
