@@ -132,11 +132,26 @@ def pairwise_sweep(dev):
         flop_exec = 2.0 * B * (nt * (nt + 1) // 2) * 128 * 128 * (Cs + Ct)
         flop_useful = 2.0 * B * (M * (M + 1) // 2) * (Cs + Ct)       # unique entries of the symmetric matrices
 
+        def warm_up(fn, ms=30.0):
+            """>= 30 ms of back-to-back launches before anything is timed (round 6): the sweep follows host-side allocation and
+            random-number generation, i.e. a GPU that has dropped its clocks, and three warm-up launches read 5-10 % slow
+            (profiles/r06_gemm_lab_notes.md)."""
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            spent = 0.0
+            for _ in range(400):
+                w0.record()
+                for _ in range(4):
+                    fn()
+                w1.record()
+                w1.synchronize()
+                spent += w0.elapsed_time(w1)
+                if spent >= ms:
+                    break
+
         def timed(fn, reps=20):
             """every launch bracketed on its own: median AND minimum of `reps` (five back-to-back launches
             hid a 13 % spread between sessions); launches below ~60 us are timed back to back (event overhead)."""
-            for _ in range(3):
-                fn()
+            warm_up(fn)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
             for e0, e1 in ev:
                 e0.record()
@@ -147,8 +162,7 @@ def pairwise_sweep(dev):
             return t[len(t) // 2], t[0], t[-1]
 
         if M <= 289:
-            for _ in range(3):
-                call()
+            warm_up(call, 10.0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):

@@ -14,6 +14,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import warm_timed  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PEAK = 157.3
@@ -74,15 +77,10 @@ def main():
         assert lib.skd_leaky_relu(256 * (idx + 1), marker.data_ptr(), 1.0, st)
 
         def timed(fn):
-            for _ in range(3):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
+            # round 6: >= 30 ms of warm-up and the median of five groups (tools/_timing.py): with three warm-up launches the FIRST
+            # problem of the table read 15 % slow (the 'same problem, two speeds' of profiles/r03z: student 1333 us vs teacher 1153 us
+            # for the identical 512 -> 512 d4 call -- the student row is simply measured first)
+            return warm_timed(fn, reps)
 
         with torch.no_grad():
             fwd_ms = timed(lambda: F.conv2d(xin, w, bvec, s, p, d))

@@ -17,6 +17,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timing import warm_timed  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -234,15 +237,8 @@ def main():
             for _ in range(2):
                 assert fn()
             continue
-        for _ in range(3):
-            assert fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        assert fn()
+        ms = warm_timed(fn, reps, warm_ms=15.0)          # tools/_timing.py: warm clocks, median of five groups
         row = {"id": c["id"], "name": c["name"], "shape": c["shape"], "us": round(ms * 1e3, 2)}
         if c["algo_bytes"]:
             row["GBs"] = round(c["algo_bytes"] / (ms * 1e-3) / 1e9, 1)
