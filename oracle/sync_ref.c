@@ -143,7 +143,8 @@ static int exchange(sync_ctx *c, unsigned seq, int n, const float *src, int nwor
         const double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
         /* csrc/sync_dev.hpp: a wait that has lasted 0.1 s gives up at once when an earlier exchange already timed out */
         if (dt > c->timeout_s || (dt > 0.1 && __atomic_load_n(&g_status[0], __ATOMIC_ACQUIRE) != 0u)) {
-          __atomic_store_n(&g_status[0], seq | 0x80000000u, __ATOMIC_RELEASE);
+          { unsigned expected = 0u;       /* the first timed-out exchange's sequence number survives (csrc/sync_dev.hpp) */
+            __atomic_compare_exchange_n(&g_status[0], &expected, seq | 0x80000000u, 0, __ATOMIC_RELEASE, __ATOMIC_RELAXED); }
           return 0;
         }
         usleep(20);

@@ -8,18 +8,24 @@
 // 512x512), their log-softmax and, in backward, the same again -- roughly 2 GB of HBM traffic per step
 // for 2 x 2.6 MB of logits.  Here nothing of size H x W x C ever exists in memory, and (round 5) nothing of size
 // H x w x C either:
-//   cells    one lane per SOURCE CELL (image, j, i) and head: the output pixels whose top-left tap is source pixel (j, i)
-//            -- ~8 x 8 of them at 65 -> 512 -- are all interpolated from the cell's four corner logits, so the lane keeps
-//            those in registers, evaluates every pixel's softmax exactly ONCE, adds -log p[target] to the loss and pulls
-//            (softmax - onehot) back onto the four corners with the bilinear weights (row sums in registers, the four
-//            corner accumulators in lane-private LDS).  A workgroup owns a tile of 8 x 16 cells of both heads; its target
-//            rectangle (~66 x 130 int64) is read once, coalesced, into LDS as bytes.  The tile's (8+1) x (16+1) NODES are
-//            then summed from the <= 4 cells around each (fixed order) and written as per-tile partials.
+//   cells    EIGHT lanes per SOURCE CELL (image, j, i) and head (one per output row of the cell, folded with DPP): the output
+//            pixels whose top-left tap is source pixel (j, i) -- ~8 x 8 of them at 65 -> 512 -- are all interpolated from the
+//            cell's four corner logits, so the lanes keep those in registers, evaluate every pixel's softmax exactly ONCE, add
+//            -log p[target] to the loss and pull (softmax - onehot) back onto the four corners with the bilinear weights (row
+//            sums in registers, the four corner accumulators in LDS).  A workgroup (512 threads) owns a tile of 8 x 8 cells
+//            (kCeTJ x kCeTI) of both heads; its target rectangle (~66 x 66 int64 at 65 -> 512, kCeTgtMax bytes) is read once,
+//            coalesced, into LDS as bytes.  The tile's (8+1) x (8+1) NODES are then summed from the <= 4 cells around each
+//            (fixed order) and written as per-tile partials.  Tiles are walked in an XCD-aware order (neighbouring tiles share
+//            target and logit lines: one L2 fetches them, not eight).
 //   nodes    one lane per source logit: the <= 4 tiles that share the node, summed in a fixed order and scaled by
 //            head_weight / n_valid (the CE mean is only known when every workgroup has finished) -> dloss/dlogits.
 // Round 1-4 used a separable formulation (rows kernel -> (B, heads, C, H, w) row gradients -> columns kernel): every pixel's
 // softmax was evaluated twice and the 40 MB intermediate was written and read back: 147 MB of HBM traffic for 27 MB of
-// algorithmic bytes (profiles/r04g_pmc.json), 340 us.  Now: target 16.8 MB + logits + 2 x 6.1 MB of node partials.
+// algorithmic bytes (profiles/r04g_pmc.json), 340 us.  Now (profiles/r05e_pmc.json): target 16.8 MB + logits 5.3 MB read once,
+// 11.8 MB of node partials written (row-contiguous per tile) and 7.9 MB of them read back + 5.3 MB of gradients: 42.7 MB, 131 us.
+// Class counts: C <= 24 runs the CMAX = 24 instantiation (this network: 19).  24 < C <= 64 runs CMAX = 64: five 64-float
+// per-lane arrays under __launch_bounds__(512, 2) SPILL to scratch and the corner sums need 64 KB of dynamic + 8 KB of static LDS
+// (fits gfx950's 160 KB, nothing smaller) -- a correct but slow path that exists so that other label sets work at all.
 // Gather formulation: no float atomics, fixed summation order, bit-reproducible.
 // Index/weight arithmetic follows PyTorch's upsample_bilinear2d (align_corners=True):
 //     scale = (in - 1) / (out - 1) (fp32); src = scale * dst; i0 = (int)src; i1 = i0 + (i0 < in - 1);

@@ -24,6 +24,13 @@ unsigned *status_words();
 __device__ __forceinline__ void raise_status(unsigned *status, int which, unsigned code) {
   if (status != nullptr) __hip_atomic_store(status + which, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the FIRST failure's code survives until the host clears the word (once an exchange has timed out every later
+// exchange of the step gives up early and would otherwise overwrite the word with its own sequence number)
+__device__ __forceinline__ void raise_status_first(unsigned *status, int which, unsigned code) {
+  if (status == nullptr) return;
+  unsigned expected = 0u;
+  __hip_atomic_compare_exchange_strong(status + which, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // One-time initialisation that is PER DEVICE (hipFuncSetAttribute, attribute queries): a process may drive several
 // devices (the reference's own threading model), so a plain `static bool` is wrong there.

@@ -94,7 +94,7 @@ __device__ __forceinline__ bool sync_exchange(const SyncArgs &a, int word_lo, in
       }
       if (give_up) {
         *ok_s = 0u;
-        raise_status(a.status, kStatusSyncTimeout, a.seq | 0x80000000u);
+        raise_status_first(a.status, kStatusSyncTimeout, a.seq | 0x80000000u);      // the word names the exchange that timed out FIRST
         break;
       }
     }

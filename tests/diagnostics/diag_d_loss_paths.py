@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import step_torch as O  # noqa: E402
 from structure_knowledge_distillation_amd.networks import sagan_models  # noqa: E402
+_together = sagan_models.normalize_together
 from structure_knowledge_distillation_amd.utils import criterion as C  # noqa: E402
 import structure_knowledge_distillation_amd as S  # noqa: E402
 
@@ -31,12 +32,13 @@ for trial in range(3):
     row = ["trial %d  f64 %.8f  cpu-fp32 rel %.1e" % (trial, ref, abs(ref32 - ref) / abs(ref))]
     for together in ("1", "0"):
         for det in (False, True):
-            os.environ["SKD_SN_TOGETHER"] = together
+            # (the SKD_SN_TOGETHER switch is gone since round 5: the arm is selected the way tests/test_host_cpu.py does it)
+            sagan_models.normalize_together = _together if together == "1" else (lambda wrappers: False)
             D = sagan_models.Discriminator(1, 19, B, 65, 64).to(dev).train()
             D.load_state_dict({k: v.clone() for k, v in PD.items()})
             import contextlib
             ctx = torch.backends.cudnn.flags(enabled=False) if det else contextlib.nullcontext()
-            # NOTE: det=True here means im2col convolutions WITHOUT torch.use_deterministic_algorithms, so that SKD_SN_TOGETHER decides
+            # NOTE: det=True here means im2col convolutions WITHOUT torch.use_deterministic_algorithms, so that the spectral-norm arm decides
             with ctx:
                 with torch.no_grad():
                     D(pS.to(dev))

@@ -259,6 +259,14 @@ def _sync_timeout(rank, world):
         out["took"] = time.perf_counter() - t0
         out["nan"] = bool(torch.isnan(stat).all())
         out["after"] = _lib.device_status()
+        # a SECOND exchange nobody answers gives up early (the word is still raised) and must NOT overwrite it: the word names the
+        # exchange that timed out FIRST (csrc/sync_dev.hpp raise_status_first)
+        stat2 = torch.ones(2, 8, device=dev)
+        t1 = time.perf_counter()
+        IA._sync_grad_stats(stat2, dist.group.WORLD)
+        torch.cuda.synchronize()
+        out["took2"] = time.perf_counter() - t1
+        out["after2"] = _lib.device_status()
         try:
             _lib.raise_on_device_errors()
             out["raised"] = None
@@ -277,6 +285,7 @@ def test_exchange_timeout_raises_a_device_status_word_and_an_exception():
     o = outs[0]
     assert not any(o["before"]) and o["nan"] and 0.9 < o["took"] < 6.0, o          # the 1 s limit, plus launch / sync latency of a busy host
     assert o["after"][0] != 0 and o["raised"] is not None and "timed out waiting for a peer" in o["raised"], o
+    assert o["after2"][0] == o["after"][0] and o["took2"] < 0.9, o          # first failure kept; the second wait gave up after ~0.1 s
     assert not any(o["cleared"]) and not any(outs[1]["before"])
 
 
