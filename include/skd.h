@@ -486,6 +486,14 @@ int skd_status_words(void);
 int skd_status_read(unsigned *out);
 int skd_status_clear(void);
 int skd_abn_set_fused_max_workgroups(int n);
+/* The two operational switches of the one-launch passes as LIBRARY STATE (round 6): the one-launch (register-resident, grid
+ * barrier) passes at all -- environment default SKD_ABN_FUSED, on -- and the cross-replica exchange inside them -- SKD_ABN_SYNC_FUSED,
+ * on.  The environment is read ONCE (first query); set(1 / 0) overrides it for the process (utils/parallel.py: RCCL groups start
+ * with sync_fused = 0), set(-1) returns to the environment at the next query; get() = the effective value.  No getenv on the call path. */
+int skd_abn_set_fused(int on);
+int skd_abn_get_fused(void);
+int skd_abn_set_sync_fused(int on);
+int skd_abn_get_sync_fused(void);
 /* out[0] / out[1]: synchronised (*_sync) calls that ran as one launch with the exchange inside / as three launches (host counters) */
 int skd_abn_sync_form_counts(int64_t *out);
 

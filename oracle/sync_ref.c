@@ -273,6 +273,21 @@ int skd_abn_relu_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float 
 /* the grid-barrier cap of the product's one-launch passes has no host counterpart: accepted, reports "whole device" */
 int skd_abn_set_fused_max_workgroups(int n) { (void)n; return 256; }
 
+/* the two switches of the one-launch passes (include/skd.h section 13): the host double keeps the STATE (environment read once,
+ * setters override) so that the host logic above it can be exercised; it always runs the three-step form itself */
+static int g_fused_state = -1, g_sync_fused_state = -1;
+static int switch_state(int *state, const char *name) {
+  if (*state < 0) {
+    const char *e = getenv(name);
+    *state = !(e != NULL && e[0] == '0');
+  }
+  return *state;
+}
+int skd_abn_set_fused(int on) { g_fused_state = on < 0 ? -1 : (on != 0); return 1; }
+int skd_abn_get_fused(void) { return switch_state(&g_fused_state, "SKD_ABN_FUSED"); }
+int skd_abn_set_sync_fused(int on) { g_sync_fused_state = on < 0 ? -1 : (on != 0); return 1; }
+int skd_abn_get_sync_fused(void) { return switch_state(&g_sync_fused_state, "SKD_ABN_SYNC_FUSED"); }
+
 /* the host double always runs the three-step form */
 int skd_abn_sync_form_counts(int64_t *out) {
   if (!out) return 0;

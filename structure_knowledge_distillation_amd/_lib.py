@@ -119,6 +119,10 @@ SIGNATURES = {
     "skd_status_read": (_I, [_P]),
     "skd_status_clear": (_I, []),
     "skd_abn_set_fused_max_workgroups": (_I, [_I]),
+    "skd_abn_set_fused": (_I, [_I]),
+    "skd_abn_get_fused": (_I, []),
+    "skd_abn_set_sync_fused": (_I, [_I]),
+    "skd_abn_get_sync_fused": (_I, []),
     "skd_abn_sync_form_counts": (_I, [_P]),
 }
 

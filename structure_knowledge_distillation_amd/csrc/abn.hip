@@ -18,6 +18,8 @@
 // eval fwd 8 -- versus 16-24 / 20-40 for the reference launch sequence.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "skd_common.hpp"
 #include "sync_dev.hpp"
 
@@ -1791,18 +1793,25 @@ static int launch_apply_nhwc_train(int act, const float *x, const float *res, fl
 }
 
 // SKD_ABN_FUSED=0 keeps the two-launch passes -- the operational switch for a device that is shared with another grid-barrier
-// launch (multi-tenant GPU); default: the register-resident one-launch passes when they fit.  Read on every
-// call (a getenv is nanoseconds beside a launch): tests/test_kernels_gpu.py flips it inside one process.
-static bool fused_enabled() {
-  const char *e = getenv("SKD_ABN_FUSED");
-  return !(e != nullptr && e[0] == '0');
-}
+// launch (multi-tenant GPU); default: the register-resident one-launch passes when they fit.
+// SKD_ABN_SYNC_FUSED=0: the synchronised entries keep the three-launch form (statistics, exchange kernel, normalise).
+// Both are LIBRARY STATE (round 6): the environment is read ONCE, at the first query (getenv from autograd threads
+// while the host language calls setenv is not safe under glibc, and a process-wide variable is the wrong place for a default that
+// depends on the process group); skd_abn_set_fused / skd_abn_set_sync_fused change it afterwards (tests, utils/parallel.py's RCCL
+// default, bench.py's fallback chain), -1 = read the environment again at the next query.
 constexpr int kFuseFwdMaxNR = 17, kFuseBwdMaxNR = 9;
-// SKD_ABN_SYNC_FUSED=0: the synchronised entries keep the three-launch form (statistics, exchange kernel, normalise): A/B switch
-static bool sync_fused_enabled() {          // read on every call: tests switch it inside one process
-  const char *e = getenv("SKD_ABN_SYNC_FUSED");
-  return !(e != nullptr && e[0] == '0');
+static std::atomic<int> g_fused_state{-1}, g_sync_fused_state{-1};
+static bool switch_state(std::atomic<int> &state, const char *name) {
+  int v = state.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv(name);
+    v = !(e != nullptr && e[0] == '0');
+    state.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
 }
+static bool fused_enabled() { return switch_state(g_fused_state, "SKD_ABN_FUSED"); }
+static bool sync_fused_enabled() { return switch_state(g_sync_fused_state, "SKD_ABN_SYNC_FUSED"); }
 
 // The grid barrier of the one-launch passes needs every workgroup of the launch co-resident: the grid is
 // capped by what THIS device can hold at one 1024-thread workgroup per compute unit -- 256 on a whole MI355X, 32 on a
@@ -2568,6 +2577,19 @@ int skd_abn_sync_form_counts(int64_t *out) {
 // Upper bound of the workgroups of a one-launch (grid-barrier) pass, on top of the device's own limit (compute units):
 // ranks that share ONE device must share its compute units or their barrier kernels cannot all be resident.  n > 0 sets the
 // bound, n == 0 restores the default, n < 0 only queries.  Process-wide; returns the effective cap on the current device.
+// 1 / 0: the one-launch passes on / off; -1: back to the environment (SKD_ABN_FUSED / SKD_ABN_SYNC_FUSED, default on), read at
+// the next query.  The getters return the EFFECTIVE state (and resolve an unset one).
+int skd_abn_set_fused(int on) {
+  g_fused_state.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed);
+  return 1;
+}
+int skd_abn_get_fused(void) { return fused_enabled() ? 1 : 0; }
+int skd_abn_set_sync_fused(int on) {
+  g_sync_fused_state.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed);
+  return 1;
+}
+int skd_abn_get_sync_fused(void) { return sync_fused_enabled() ? 1 : 0; }
+
 int skd_abn_set_fused_max_workgroups(int n) {
   if (n >= 0) g_fuse_user_cap = (n > 0 && n < kRedMaxWG) ? n : kRedMaxWG;
   return fuse_wg_cap();

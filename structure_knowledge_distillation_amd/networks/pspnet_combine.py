@@ -53,7 +53,8 @@ class _ClassifierConvFn(torch.autograd.Function):
     """conv2d with a bias whose gradient is reduced in two stages.  The stock backward sums the (B, 19, 65, 65) gradient over
     (0, 2, 3) in one reduction with 19 outputs -- two workgroups' worth of parallelism: 89-94 us per head on MI355X, 0.18 ms of the
     step (profiles/r05l trace, main stream).  Summing the rows first (B * H * 19 outputs) and the row sums second takes two
-    launches of a few microseconds; the data gradient and the weight gradient are MIOpen's, as before."""
+    launches of a few microseconds; the data gradient and the weight gradient are MIOpen's, as before, asked for through the PUBLIC
+    ``torch.nn.grad`` wrappers (round 6: the positional ``aten.convolution_backward`` call is gone)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
@@ -65,17 +66,24 @@ class _ClassifierConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         stride, padding, dilation = ctx.conv
-        gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), list(dilation), False,
-                                                        [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        gx = torch.nn.grad.conv2d_input(x.shape, weight, g, stride, padding, dilation) if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(x, weight.shape, g, stride, padding, dilation) if ctx.needs_input_grad[1] else None
         gb = g.permute(0, 2, 3, 1).sum(2).sum((0, 1)) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
 
 
 class ClassifierConv(nn.Conv2d):
-    """``nn.Conv2d`` (same parameters, same state-dict keys: pspnet_combine.py:138-154) for the few-channel classifier heads."""
+    """``nn.Conv2d`` (same parameters, same state-dict keys: pspnet_combine.py:138-154) for the few-channel classifier heads.
+    The two-stage bias gradient covers what the heads are -- ungrouped, zero padding given as numbers; any other construction
+    takes the stock operator (never a silently wrong gradient)."""
+
+    def _plain(self):
+        return (self.groups == 1 and self.padding_mode == "zeros" and not isinstance(self.padding, str)
+                and not self.transposed and tuple(self.output_padding) == (0, 0))
 
     def forward(self, x):
-        if self.bias is None or not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+        if (self.bias is None or not self._plain()
+                or not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
             return super().forward(x)
         return _ClassifierConvFn.apply(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
 

@@ -56,7 +56,9 @@ def init_distributed(backend=None):
             # with, + ~1 ms per step); SKD_ABN_SYNC_FUSED=1 opts into the in-kernel form, and only then are the compute-unit
             # reserve and the RCCL channel cap applied (they cost every collective bandwidth and every ABN pass a
             # quarter of its parallelism, so they must not be process-wide defaults).
-            os.environ.setdefault("SKD_ABN_SYNC_FUSED", "0")
+            # (library state, not the process environment: ADVICE r05 -- a user's explicit SKD_ABN_SYNC_FUSED is honoured)
+            if "SKD_ABN_SYNC_FUSED" not in os.environ:
+                set_sync_fused(False)
             if sync_fused_over_rccl():
                 os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if os.environ.get("SKD_DIST_TIMEOUT_S"):
@@ -79,7 +81,22 @@ def init_distributed(backend=None):
 def sync_fused_over_rccl():
     """True when the synchronised InPlace-ABN layers may take the one-launch form (exchange inside the grid-barrier kernel) in a
     job whose collectives are RCCL kernels: opt-in (SKD_ABN_SYNC_FUSED=1), see init_distributed."""
-    return os.environ.get("SKD_ABN_SYNC_FUSED", "1") == "1"
+    return sync_fused()
+
+
+def sync_fused():
+    """The library's effective state of the in-kernel exchange switch (include/skd.h section 13: environment default read once,
+    overridden by set_sync_fused)."""
+    from .. import _lib
+    return bool(_lib.get().skd_abn_get_sync_fused())
+
+
+def set_sync_fused(on):
+    """True / False: the synchronised one-launch InPlace-ABN passes exchange inside the kernel / run as three launches; None: back to
+    the environment (SKD_ABN_SYNC_FUSED, default on).  Explicit library state -- nothing here touches os.environ, which the native
+    library no longer reads on the call path."""
+    from .. import _lib
+    _lib.get().skd_abn_set_sync_fused(-1 if on is None else int(bool(on)))
 
 
 def comm_form(group=None):
@@ -88,7 +105,8 @@ def comm_form(group=None):
         return "single rank"
     if not SyncMailbox.active():
         return "torch.distributed all_gather / all_reduce per exchange (SKD_SYNC_IPC=0 or the mailbox self-test failed)"
-    if os.environ.get("SKD_ABN_SYNC_FUSED", "1") == "1" and os.environ.get("SKD_ABN_FUSED", "1") != "0":
+    from .. import _lib
+    if sync_fused() and _lib.get().skd_abn_get_fused():
         return "ipc mailboxes, exchange inside the one-launch ABN kernels where the tensor fits (csrc/abn.hip, sync_dev.hpp)"
     return "ipc mailboxes, three launches per pass: statistics / one-workgroup exchange kernel / normalise (csrc/sync.hip)"
 

@@ -565,10 +565,12 @@ def _bench_fallback(rank, world):
 
     os.environ.pop("SKD_ABN_SYNC_FUSED", None)
     os.environ.pop("SKD_SYNC_IPC", None)
+    P.set_sync_fused(None)
     model, step, info = bench.warm_up_with_fallback(build, 3, world, dev, warm_timeout_s=1.5, run_timeout_s=20.0)
     losses = step(3)                                 # the "timed region": the surviving form works
     return {"info": info, "builds": len(builds), "losses": [float(v) for v in losses], "status": _lib.device_status(),
             "env": {k: os.environ.get(k) for k in ("SKD_ABN_SYNC_FUSED", "SKD_SYNC_IPC", "SKD_SYNC_TIMEOUT_S")},
+            "sync_fused": P.sync_fused(),
             "mailbox": P.SyncMailbox.active()}
 
 
@@ -579,7 +581,9 @@ def test_bench_warm_up_falls_back_to_the_next_exchange_form_on_a_device_status_w
         assert o["builds"] == 2 and o["info"]["attempts"] == 2, (r, o["builds"], o["info"])
         assert "three launches per pass" in o["info"]["form"], o["info"]["form"]          # mailboxes kept, no in-kernel exchange
         assert o["info"]["fallback_reason"] and "as configured" in o["info"]["fallback_reason"], o["info"]
-        assert o["env"] == {"SKD_ABN_SYNC_FUSED": "0", "SKD_SYNC_IPC": None, "SKD_SYNC_TIMEOUT_S": "20.0"}, o["env"]
+        # the fallback changed LIBRARY state (skd_abn_set_sync_fused), not the process environment
+        assert o["env"] == {"SKD_ABN_SYNC_FUSED": None, "SKD_SYNC_IPC": None, "SKD_SYNC_TIMEOUT_S": "20.0"}, o["env"]
+        assert o["sync_fused"] is False
         assert o["mailbox"] and not any(o["status"])
         assert all(v == v and abs(v) < 1e6 for v in o["losses"]), o["losses"]
     # the reason is a timed-out exchange on at least one rank (the other may only have heard of it through the all-reduce)

@@ -119,7 +119,7 @@ def _sync_abn_nhwc_forms(rank, world):
         w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
         sl = slice(rank * 2, rank * 2 + 2)
         for form in ("fused", "fused_again", "three", "mixed"):
-            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "fused_again": "1", "three": "0", "mixed": "1" if rank == 0 else "0"}[form]
+            P.set_sync_fused({"fused": True, "fused_again": True, "three": False, "mixed": rank == 0}[form])     # library state, not the environment
             for kind in ("leaky", "relu", "relu_res"):
                 mod = libs.InPlaceABNSync(C, activation="leaky_relu" if kind == "leaky" else "none").to(dev).train()
                 with torch.no_grad():
@@ -136,7 +136,7 @@ def _sync_abn_nhwc_forms(rank, world):
                 out[(C, form, kind)] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "dr": None if rs.grad is None else rs.grad.cpu(),
                                         "dw": mod.weight.grad.cpu(), "db": mod.bias.grad.cpu(),
                                         "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
-    os.environ.pop("SKD_ABN_SYNC_FUSED", None)
+    P.set_sync_fused(None)
     out["status"] = _lib.device_status()
     out["forms"] = _lib.sync_form_counts()
     return out
@@ -202,7 +202,7 @@ def _sync_abn_world8(rank, world):
         x = torch.randn(world, C, hw, hw, generator=g) * 2 + 1
         gz = torch.randn(world, C, hw, hw, generator=g)
         for form in ("fused", "three", "mixed"):
-            os.environ["SKD_ABN_SYNC_FUSED"] = {"fused": "1", "three": "0", "mixed": "1" if rank % 2 == 0 else "0"}[form]
+            P.set_sync_fused({"fused": True, "three": False, "mixed": rank % 2 == 0}[form])
             mod = libs.InPlaceABNSync(C, activation="leaky_relu").to(dev).train()
             xs = x[rank:rank + 1].to(dev).requires_grad_(True)
             z = mod(cl(xs * 1.0))
@@ -210,7 +210,7 @@ def _sync_abn_world8(rank, world):
             torch.cuda.synchronize()
             _lib.raise_on_device_errors()
             out[(C, form)] = {"z": z.detach().contiguous().cpu(), "dx": xs.grad.cpu(), "rm": mod.running_mean.cpu(), "rv": mod.running_var.cpu()}
-    os.environ.pop("SKD_ABN_SYNC_FUSED", None)
+    P.set_sync_fused(None)
     out["forms"] = _lib.sync_form_counts()
     return out
 
@@ -429,13 +429,16 @@ def _netmodel_variants(rank, world):
     for name, env in VARIANTS.items():
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
-        try:
+        from structure_knowledge_distillation_amd.utils import parallel as _P
+        _P.set_sync_fused(None if "SKD_ABN_SYNC_FUSED" not in env else env["SKD_ABN_SYNC_FUSED"] == "1")   # library state: the
+        try:                                                                                               # environment is read once
             out[name] = _netmodel_step_once(rank, world, gen)
         except Exception:                  # reported by the test that asks for this variant; the others still run
             out[name] = {"error": traceback.format_exc()}
         finally:
             for k, v in saved.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            _P.set_sync_fused(None)
             torch.backends.cudnn.enabled = True            # NetModel's deterministic mode is process-wide
             torch.use_deterministic_algorithms(False)
             torch.cuda.synchronize()

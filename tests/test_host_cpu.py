@@ -627,6 +627,18 @@ def test_classifier_head_is_conv2d_with_a_two_stage_bias_gradient(channels_last)
     assert head.weight.grad is None and rel(head.bias.grad, stock.bias.grad) < 1e-14
     net = PC_MOD.Res_pspnet(PC_MOD.BasicBlock, [2, 2, 2, 2], 19)
     assert isinstance(net.head, PC_MOD.ClassifierConv) and isinstance(net.dsn[3], PC_MOD.ClassifierConv)
+    # constructions the two-stage form does not cover take the stock operator: same gradients as nn.Conv2d
+    for kw in ({"groups": 2}, {"padding": "same", "kernel_size": 3}, {"padding": 1, "kernel_size": 3, "padding_mode": "reflect"}):
+        args = dict(in_channels=32, out_channels=20, kernel_size=1, bias=True)
+        args.update(kw)
+        odd, ref = PC_MOD.ClassifierConv(**args).double(), torch.nn.Conv2d(**args).double()
+        ref.load_state_dict(odd.state_dict())
+        assert not odd._plain()
+        xo, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        go = torch.randn(3, 20, 9, 11, dtype=torch.double)
+        odd(xo).backward(go)
+        ref(xr).backward(go)
+        assert torch.equal(xo.grad, xr.grad) and torch.equal(odd.weight.grad, ref.weight.grad) and torch.equal(odd.bias.grad, ref.bias.grad), kw
 
 
 def test_device_identity_tells_physical_gpus_apart():

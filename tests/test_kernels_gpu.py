@@ -455,11 +455,14 @@ def test_operational_switches_of_the_one_launch_abn_passes(hip, monkeypatch):
         torch.cuda.synchronize()
         return z, st, rm, rv, e, dx, dw, db
 
-    monkeypatch.delenv("SKD_ABN_FUSED", raising=False)
+    # (library state since round 6: the environment variable is only the DEFAULT, read once; include/skd.h section 13)
+    assert hip.skd_abn_set_fused(1) and hip.skd_abn_get_fused() == 1
     one = run()
-    monkeypatch.setenv("SKD_ABN_FUSED", "0")
-    two = run()
-    monkeypatch.delenv("SKD_ABN_FUSED")
+    assert hip.skd_abn_set_fused(0) and hip.skd_abn_get_fused() == 0
+    try:
+        two = run()
+    finally:
+        hip.skd_abn_set_fused(-1)
     for a, c, name in zip(one, two, ("z", "stat", "rm", "rv", "e", "dx", "dw", "db")):
         close(c, a, 2e-5, name + " (SKD_ABN_FUSED=0 -> two-launch passes)", floor=float(a.abs().max()) * 1e-2)
     code = ("from structure_knowledge_distillation_amd import _lib; import torch; torch.zeros(1, device='cuda'); "
