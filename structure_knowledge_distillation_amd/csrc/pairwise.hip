@@ -592,91 +592,126 @@ __global__ __launch_bounds__(kThreads) void transpose_pad_kernel(const float *__
 
 // backward: D[c][m] = sum_n Fhat_S[c][n] * G[n][m];  dP[c][m] = coef * gscale * D[c][m] / norm[m]
 // Round 5: the A operand comes from a NODE-MAJOR copy of the student panel (transpose_pad_kernel, 18 MB at M = 4225 next to the
-// 606 MB of G), so both operands are k-major and the contraction runs through the very main loop of the Gram kernel.  Rounds 3-4
-// transposed A on the way into LDS (4 scalar ds_write_b32 per 16 bytes at a 129-float stride): 0.53 of the fp32 MFMA peak
-// against the Gram kernel's 0.63 with the same tiles (profiles/r04g_micro.jsonl).
-// grid = (ntm * ntc, B, KS).  KS == 1: the epilogue scales and writes dpooled.  KS > 1: split z contracts the node range
-// [z * kper, (z + 1) * kper) and stores its raw 128 x 128 partial into part[z][b][c][m]; pairwise_bwd_combine_kernel adds the
-// KS partials in index order (deterministic) and applies the scale.
+// 606 MB of G), so both operands are k-major and the contraction runs through the very main loop of the Gram kernel.
+//
+// Round 6: STREAM-K over (output tile, K-tile) units instead of a fixed split of the node range.  The problem has few output
+// tiles (Cs = 128 -> ONE row of 34 tiles per image at M = 4225: 272 in a batch of 8) and a long contraction (136 K-tiles); rounds
+// 3-5 cut every tile's node range into 4 fixed pieces: 1088 workgroups on the chip's 512 slots (two 64 KB-LDS workgroups per CU)
+// = 2.1 rounds, the last one a sixth full, and 71 MB of partials written and read back (0.50-0.56 of the fp32 MFMA peak against
+// the Gram kernel's 0.73 with the same main loop).  Now the 272 x 136 = 36 992 units are dealt
+// out as ONE contiguous range per workgroup, `nwg` = one round of the chip (2 per CU) -- every slot gets 72 or 73 K-tiles, nobody
+// waits for a straggler round.  A workgroup's range touches at most a head tile and a tail tile it does not own alone (their raw
+// 128 x 128 accumulators go to slot [w][0] / [w][1]) and whole tiles in between (scaled and written straight to dpooled).
+// pairwise_bwd_fixup_kernel then adds, per output tile, the slots of the workgroups that covered it IN WORKGROUP ORDER
+// (deterministic, bit-reproducible) and applies the scale.
+struct StreamK {
+  int64_t total;       // units = tiles * nkt
+  int nwg, nkt;        // workgroups of the launch, K-tiles per output tile
+};
+__host__ __device__ __forceinline__ int64_t sk_first_unit(const StreamK &k, int w) { return (int64_t)w * k.total / k.nwg; }
+// the workgroup whose range contains unit u: the largest w with sk_first_unit(w) <= u
+__host__ __device__ __forceinline__ int sk_owner(const StreamK &k, int64_t u) { return (int)(((u + 1) * k.nwg - 1) / k.total); }
+
 __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ ft,
                                                                    const float *__restrict__ G,
                                                                    const float *__restrict__ norm,
                                                                    const float *__restrict__ gscale,
                                                                    float *__restrict__ dpooled,
                                                                    float *__restrict__ part, int Cs,
-                                                                   int M, int ldm, int ldc, int ntm, int kper,
+                                                                   int M, int ldm, int ldc, int ntm, int ntc, StreamK sk,
                                                                    float coef) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels::lds_bytes
-  const int b = blockIdx.y, z = blockIdx.z;
-  const int tc = blockIdx.x / ntm, tm = blockIdx.x % ntm;
-  const int c0 = tc * kTile, m0 = tm * kTile;
-  const int kb = z * kper, ke = min(ldm, kb + kper);
-  Seg s;
-  s.A = ft + ((int64_t)b * ldm + kb) * ldc + c0;     // A(k = n, i = c) = Fhat_S[c][n], node-major copy: k-major
-  s.lda = ldc;
-  s.B = G + ((int64_t)b * ldm + kb) * ldm + m0;      // B(k = n, j = m) = G[n][m]
-  s.ldb = ldm;
-  s.K = ke - kb;
-  s.sign = 1.f;
-  f32x16 acc[2][2];
-  tile_gemm<1>(s, s, lds, acc);
-
+  const int w = blockIdx.x;
+  const int64_t u0 = sk_first_unit(sk, w), u1 = sk_first_unit(sk, w + 1);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
-  if (part != nullptr) {
-    float *dst = part + (((int64_t)z * gridDim.y + b) * Cs) * ldm;
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int m = m0 + wj + bj * 32 + (lane & 31);
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = c0 + wi + bi * 32 + frag_row(r, lane);
-          if (c < Cs) dst[(int64_t)c * ldm + m] = acc[bi][bj][r];
-        }
-    }
-    return;
-  }
   const float scale = coef * gscale[0];
+  const int tiles_per_image = ntm * ntc;
+  bool first = true;
+  for (int64_t u = u0; u < u1;) {
+    const int64_t t = u / sk.nkt;
+    const int kt0 = (int)(u - t * sk.nkt);
+    const int64_t tile_end = (t + 1) * sk.nkt;
+    const int kt1 = (int)((u1 < tile_end ? u1 : tile_end) - t * sk.nkt);
+    const int b = (int)(t / tiles_per_image), rem = (int)(t - (int64_t)b * tiles_per_image);
+    const int tc = rem / ntm, tm = rem - tc * ntm;
+    const int c0 = tc * kTile, m0 = tm * kTile;
+    Seg s;
+    s.A = ft + ((int64_t)b * ldm + (int64_t)kt0 * kBK) * ldc + c0;     // A(k = n, i = c) = Fhat_S[c][n], node-major copy: k-major
+    s.lda = ldc;
+    s.B = G + ((int64_t)b * ldm + (int64_t)kt0 * kBK) * ldm + m0;      // B(k = n, j = m) = G[n][m]
+    s.ldb = ldm;
+    s.K = (kt1 - kt0) * kBK;
+    s.sign = 1.f;
+    f32x16 acc[2][2];
+    tile_gemm<1>(s, s, lds, acc);
+    __syncthreads();                                   // the LDS ring is reused by the next segment's first panel
+    const bool whole = kt0 == 0 && kt1 == sk.nkt;
+    if (whole) {
 #pragma unroll
-  for (int bj = 0; bj < 2; ++bj) {
-    const int m = m0 + wj + bj * 32 + (lane & 31);
-    const float inv = m < M ? scale / norm[(int64_t)b * M + m] : 0.f;
+      for (int bj = 0; bj < 2; ++bj) {
+        const int m = m0 + wj + bj * 32 + (lane & 31);
+        const float inv = m < M ? scale / norm[(int64_t)b * M + m] : 0.f;
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+        for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wi + bi * 32 + frag_row(r, lane);
-        if (c < Cs) dpooled[((int64_t)b * Cs + c) * ldm + m] = acc[bi][bj][r] * inv;
+          for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wi + bi * 32 + frag_row(r, lane);
+            if (c < Cs) dpooled[((int64_t)b * Cs + c) * ldm + m] = acc[bi][bj][r] * inv;
+          }
       }
+    } else {
+      // raw partial of a shared tile: slot 0 = this workgroup's first segment, slot 1 = a later (its last) one; (128, 128) row-major
+      float *dst = part + ((int64_t)w * 2 + (first ? 0 : 1)) * (kTile * kTile);
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const int ml = wj + bj * 32 + (lane & 31);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(wi + bi * 32 + frag_row(r, lane)) * kTile + ml] = acc[bi][bj][r];
+      }
+    }
+    first = false;
+    u = t * sk.nkt + kt1;
   }
 }
 
-// dpooled[b][c][m4 .. m4+3] = coef * gscale / norm[b][m] * sum_z part[z][b][c][m]   (m >= M: 0); grid (ldm/4 / 256, Cs, B)
-__global__ __launch_bounds__(kThreads) void pairwise_bwd_combine_kernel(const float *__restrict__ part,
-                                                                       const float *__restrict__ norm,
-                                                                       const float *__restrict__ gscale,
-                                                                       float *__restrict__ dpooled, int KS, int B,
-                                                                       int Cs, int M, int ldm, float coef) {
-  const int m4 = (blockIdx.x * kThreads + threadIdx.x) * 4;
-  if (m4 >= ldm) return;
-  const int c = blockIdx.y, b = blockIdx.z;
-  const int64_t row = ((int64_t)b * Cs + c) * ldm + m4;
-  const int64_t zs = (int64_t)B * Cs * ldm;
-  float4 s = *reinterpret_cast<const float4 *>(part + row);
-  for (int z = 1; z < KS; ++z) {
-    const float4 v = *reinterpret_cast<const float4 *>(part + z * zs + row);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
+// One workgroup per output tile: dpooled[b][c][m] = coef * gscale / norm[b][m] * sum over the covering workgroups' slots, in
+// workgroup order (m >= M: 0).  A tile one workgroup computed alone was written by pairwise_bwd_kernel: nothing to do.
+__global__ __launch_bounds__(kThreads) void pairwise_bwd_fixup_kernel(const float *__restrict__ part,
+                                                                     const float *__restrict__ norm,
+                                                                     const float *__restrict__ gscale,
+                                                                     float *__restrict__ dpooled, int Cs, int M, int ldm,
+                                                                     int ntm, int ntc, StreamK sk, float coef) {
+  const int64_t t = blockIdx.x;
+  const int64_t ub = t * sk.nkt, ue = ub + sk.nkt;
+  const int wf = sk_owner(sk, ub), wl = sk_owner(sk, ue - 1);
+  if (wf == wl) return;                                  // one workgroup owned the whole tile
+  const int tiles_per_image = ntm * ntc;
+  const int b = (int)(t / tiles_per_image), rem = (int)(t - (int64_t)b * tiles_per_image);
+  const int tc = rem / ntm, tm = rem - tc * ntm;
+  const int c0 = tc * kTile, m0 = tm * kTile;
   const float scale = coef * gscale[0];
   const float *nr = norm + (int64_t)b * M;
-  float4 o;
-  o.x = m4 + 0 < M ? s.x * (scale / nr[m4 + 0]) : 0.f;
-  o.y = m4 + 1 < M ? s.y * (scale / nr[m4 + 1]) : 0.f;
-  o.z = m4 + 2 < M ? s.z * (scale / nr[m4 + 2]) : 0.f;
-  o.w = m4 + 3 < M ? s.w * (scale / nr[m4 + 3]) : 0.f;
-  *reinterpret_cast<float4 *>(dpooled + row) = o;
+  for (int q = threadIdx.x; q < kTile * kTile / 4; q += kThreads) {
+    const int cl = q >> 5, ml = (q & 31) * 4;            // 32 float4 per tile row
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = wf; w <= wl; ++w) {
+      // tile t is workgroup w's FIRST segment iff its range starts inside t
+      const int slot = sk_first_unit(sk, w) >= ub ? 0 : 1;
+      const float4 v = *reinterpret_cast<const float4 *>(part + ((int64_t)w * 2 + slot) * (kTile * kTile) + cl * kTile + ml);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int c = c0 + cl, m = m0 + ml;
+    if (c >= Cs) continue;
+    float4 o;
+    o.x = m + 0 < M ? s.x * (scale / nr[m + 0]) : 0.f;
+    o.y = m + 1 < M ? s.y * (scale / nr[m + 1]) : 0.f;
+    o.z = m + 2 < M ? s.z * (scale / nr[m + 2]) : 0.f;
+    o.w = m + 3 < M ? s.w * (scale / nr[m + 3]) : 0.f;
+    *reinterpret_cast<float4 *>(dpooled + ((int64_t)b * Cs + c) * ldm + m) = o;
+  }
 }
 
 
@@ -915,23 +950,28 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   return launch_final_sum(workspace, (int64_t)ntri * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
 }
 
-// Node-range splits of the backward contraction: enough workgroups for ~2 per CU slot pair (1024), at least 8 K-tiles each.
-static int bwd_splits(int B, int Cs, int ldm) {
-  const int64_t tiles = (int64_t)(ldm / kTile) * cdiv(Cs, kTile) * B;
-  int64_t ks = cdiv(1024, tiles);
-  const int64_t most = ldm / (8 * kBK);
-  if (ks > most) ks = most;
-  if (ks > 8) ks = 8;
-  return ks < 1 ? 1 : (int)ks;
+// Stream-K geometry of the backward contraction (see pairwise_bwd_kernel): one round of the chip -- 2 workgroups (64 KB of LDS
+// each) per compute unit, 512 on a whole MI355X; sized WITHOUT asking the device (the workspace query must work on a host without
+// one) -- but never fewer than 8 K-tiles per workgroup (pipeline fill / drain) and never more workgroups than units.
+constexpr int kStreamWG = 512;
+static StreamK bwd_stream_k(int B, int Cs, int ldm) {
+  StreamK k;
+  k.nkt = ldm / kBK;
+  k.total = (int64_t)(ldm / kTile) * cdiv(Cs, kTile) * B * k.nkt;
+  int64_t n = k.total / 8;
+  if (n > kStreamWG) n = kStreamWG;
+  if (n < 1) n = 1;
+  k.nwg = (int)n;
+  return k;
 }
 
-// [node-major copy of the student panel: B * ldm * ldc][KS > 1: KS * B * Cs * ldm partials]
+// [node-major copy of the student panel: B * ldm * ldc][2 slots of 128 x 128 floats per workgroup]
 int64_t skd_pairwise_backward_workspace_floats(int B, int Cs, int M) {
   if (B <= 0 || Cs <= 0 || M <= 0) return 1;
   const int ldm = skd_pairwise_ldm(M);
-  const int ks = bwd_splits(B, Cs, ldm);
+  const StreamK k = bwd_stream_k(B, Cs, ldm);
   const int64_t ldc = cdiv(Cs, kTile) * kTile;
-  return (int64_t)B * ldm * ldc + (ks > 1 ? (int64_t)ks * B * Cs * ldm : 0);
+  return (int64_t)B * ldm * ldc + (int64_t)k.nwg * 2 * kTile * kTile;
 }
 
 int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, const float *G,
@@ -941,25 +981,23 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, co
   if (ldm != skd_pairwise_ldm(M) || B > 65535) return 0;
   if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(dpooled)) & 15) return 0;
   const int ntm = ldm / kTile, ntc = (int)cdiv(Cs, kTile);
-  const int ks = bwd_splits(B, Cs, ldm);
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return 0;
   const int ldc = ntc * kTile;
+  const StreamK sk = bwd_stream_k(B, Cs, ldm);
+  const int64_t tiles = (int64_t)ntm * ntc * B;
+  if (tiles > 2147483647) return 0;
   float *ft = workspace, *part = workspace + (int64_t)B * ldm * ldc;
   // dL/dA_S = -2 G /(M^2 B); dFhat = Fhat (dA + dA^T) = -4/(M^2 B) Fhat G   (G symmetric)
   const float coef = (float)(-4.0 / ((double)M * (double)M * (double)B));
   if (!gemm_lds_ready()) return 0;
   hipStream_t st = as_stream(stream);
-  int kper = (int)(cdiv(cdiv(ldm, kBK), ks) * kBK);      // node range per split, a multiple of the K-tile
   transpose_pad_kernel<<<dim3((unsigned)(ldm / 32), (unsigned)(ldc / 32), B), dim3(kThreads), 0, st>>>(fhat_s, ft, Cs, ldm, ldc);
-  pairwise_bwd_kernel<<<dim3((unsigned)(ntm * ntc), B, ks), dim3(kThreads), Panels::lds_bytes, st>>>(
-      ft, G, norm_s, grad_loss, dpooled, ks > 1 ? part : nullptr, Cs, M, ldm, ldc, ntm, kper, coef);
+  pairwise_bwd_kernel<<<dim3((unsigned)sk.nwg), dim3(kThreads), Panels::lds_bytes, st>>>(
+      ft, G, norm_s, grad_loss, dpooled, part, Cs, M, ldm, ldc, ntm, ntc, sk, coef);
   if (!ok()) return 0;
-  if (ks > 1) {
-    pairwise_bwd_combine_kernel<<<dim3((unsigned)cdiv(ldm / 4, kThreads), Cs, B), dim3(kThreads), 0, st>>>(
-        part, norm_s, grad_loss, dpooled, ks, B, Cs, M, ldm, coef);
-    return ok();
-  }
-  return 1;
+  pairwise_bwd_fixup_kernel<<<dim3((unsigned)tiles), dim3(kThreads), 0, st>>>(part, norm_s, grad_loss, dpooled, Cs, M, ldm, ntm, ntc,
+                                                                            sk, coef);
+  return ok();
 }
 
 
