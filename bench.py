@@ -183,7 +183,8 @@ def pairwise_sweep(dev):
                            "unique_useful_TFLOPs": round(rate(flop_useful, ms), 2),
                            "frac_fp32_mfma_unique_useful": round(rate(flop_useful, ms) / MFMA_F32_PEAK_TFLOPS, 4)}
         if M >= 1089:
-            # the backward GEMM dP = Fhat_S G (2 B ldm^2 Cs executed flop on the zero-padded problem; round 5: both operands k-major)
+            # the backward GEMM dP = Fhat_S G (2 B ldm^2 Cs executed flop on the zero-padded problem; round 5: both operands k-major;
+            # round 6: stream-K over (output tile, K-tile) units, one round of the chip, fix-up in workgroup order)
             nrm = torch.rand(B, M, device=dev) + 0.5
             gl = torch.ones(1, device=dev)
             dp = torch.empty(B, Cs, ldm, device=dev)
@@ -195,7 +196,7 @@ def pairwise_sweep(dev):
             out["M=%d" % M]["backward"] = {"us": round(bms * 1e3, 1), "us_min": round(bmn * 1e3, 1), "us_max": round(bmx * 1e3, 1),
                                            "executed_TFLOPs": round(rate(fb, bms), 2),
                                            "frac_fp32_mfma_executed": round(rate(fb, bms) / MFMA_F32_PEAK_TFLOPS, 4),
-                                           "note": "whole skd_pairwise_backward call: node-major copy + GEMM (+ split combine)"}
+                                           "note": "whole skd_pairwise_backward call: node-major copy + stream-K GEMM + fix-up of the shared tiles"}
     return out
 
 

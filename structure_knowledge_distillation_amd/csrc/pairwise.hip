@@ -376,103 +376,127 @@ __global__ __launch_bounds__(kThreads) void l2_normalise_kernel(const float *__r
 // =============================================================================================
 constexpr int kTile = 128;
 constexpr int kBK = 32;             // K-tile: 16 k-steps of v_mfma_f32_32x32x2_f32
+// TI = rows of the output tile (columns of the k-major A panel): 128 (wave tile 64 x 64 = 2 x 2 MFMA blocks) or -- round 6, for
+// graphs whose 128 x 128 tiles do not fill the chip (M = 1089: 360 workgroups on 512 slots) -- 64 (wave tile 32 x 64 = 1 x 2).
+template <int TI>
 struct Panels {
-  static constexpr int offB = kBK * kTile;                // B panel follows the A panel
-  static constexpr int stage = 2 * kBK * kTile;           // floats per pipeline stage
-  static constexpr size_t lds_bytes = sizeof(float) * 2 * stage;   // double buffered: 64 KiB: 2 workgroups / CU
+  static constexpr int offB = kBK * TI;                   // B panel follows the A panel
+  static constexpr int stage = kBK * (TI + kTile);        // floats per pipeline stage
+  static constexpr size_t lds_bytes = sizeof(float) * 2 * stage;   // double buffered: 64 KiB (2 workgroups / CU) or 48 KiB (3)
 };
 
 // One K segment, both operands k-major: A(k, i) at A[k * lda + i], B(k, j) at B[k * ldb + j]; rows k >= K read as zero.
-// All tile-local: i, j in [0, 128).  (Rounds 3-4 also staged an i-major A through a transposing store for the backward GEMM;
-// since round 5 the backward reads a node-major copy instead -- transpose_pad_kernel -- and that path is gone.)
+// All tile-local: i in [0, TI), j in [0, 128).  (Rounds 3-4 also staged an i-major A through a transposing store for the backward
+// GEMM; since round 5 the backward reads a node-major copy instead -- transpose_pad_kernel -- and that path is gone.)
 struct Seg {
   const float *A, *B;
   int lda, ldb, K;
   float sign;
 };
 
+template <int TI>
 struct TileRegs {
-  float4 a[4], b[4];
+  float4 a[TI / 32], b[4];
 };
 
 // (the segment arrives as scalars BY VALUE: a `const Seg &` picked with `first ? s0 : s1` made the compiler keep both structs
 // in scratch memory and re-load the fields -- with a wait -- in front of every K-tile)
+template <int TI>
 __device__ __forceinline__ void panel_load(const float *__restrict__ sA, const float *__restrict__ sB, int lda, int ldb, int K,
-                                           int k0, TileRegs &r) {
+                                           int k0, TileRegs<TI> &r) {
   const int t = threadIdx.x;
-  const int row = t >> 5, c4 = (t & 31) * 4;            // 8 panel rows x 128 columns per pass
+  const int row = t >> 5, c4 = (t & 31) * 4;            // B: 8 panel rows x 128 columns per pass
+  constexpr int AQ = TI / 4;                             // float4 per A panel row (32 or 16)
+  constexpr int AR = kThreads / AQ;                      // A panel rows per pass (8 or 16)
+  constexpr int AH = kBK / AR;                           // passes (4 or 2)
+  const int arow = t / AQ, ac4 = (t % AQ) * 4;
   if (k0 + kBK <= K) {                                   // uniform: full K-tile, no guards
 #pragma unroll
     for (int h = 0; h < 4; ++h) r.b[h] = *reinterpret_cast<const float4 *>(sB + (int64_t)(k0 + row + 8 * h) * ldb + c4);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)(k0 + row + 8 * h) * lda + c4);
+    for (int h = 0; h < AH; ++h) r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)(k0 + arow + AR * h) * lda + ac4);
   } else {                                               // last, partial K-tile of a segment: rows k >= K are zero
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int k = k0 + row + 8 * h;
       r.b[h] = zero;
+      if (k < K) r.b[h] = *reinterpret_cast<const float4 *>(sB + (int64_t)k * ldb + c4);
+    }
+#pragma unroll
+    for (int h = 0; h < AH; ++h) {
+      const int k = k0 + arow + AR * h;
       r.a[h] = zero;
-      if (k < K) {
-        r.b[h] = *reinterpret_cast<const float4 *>(sB + (int64_t)k * ldb + c4);
-        r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)k * lda + c4);
-      }
+      if (k < K) r.a[h] = *reinterpret_cast<const float4 *>(sA + (int64_t)k * lda + ac4);
     }
   }
 }
 
-__device__ __forceinline__ void panel_store(float *st, const TileRegs &r, float sign) {
+template <int TI>
+__device__ __forceinline__ void panel_store(float *st, const TileRegs<TI> &r, float sign) {
   const int t = threadIdx.x;
   const int row = t >> 5, c4 = (t & 31) * 4;
+  constexpr int AQ = TI / 4, AR = kThreads / AQ, AH = kBK / AR;
+  const int arow = t / AQ, ac4 = (t % AQ) * 4;
 #pragma unroll
-  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(st + Panels::offB + (row + 8 * h) * kTile + c4) = r.b[h];
+  for (int h = 0; h < 4; ++h) *reinterpret_cast<float4 *>(st + Panels<TI>::offB + (row + 8 * h) * kTile + c4) = r.b[h];
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
+  for (int h = 0; h < AH; ++h) {
     float4 v = r.a[h];
     v.x *= sign; v.y *= sign; v.z *= sign; v.w *= sign;
-    *reinterpret_cast<float4 *>(st + (row + 8 * h) * kTile + c4) = v;
+    *reinterpret_cast<float4 *>(st + (arow + AR * h) * TI + ac4) = v;
   }
 }
 
 // 16 k-steps on one LDS stage.  Lane (l31 = lane & 31, kk = lane >> 5) feeds column / row l31 of the 32-wide operand
-// slices with k = 2 * ks + kk; the operands of step ks + 1 are read before the four MFMAs of step ks are issued.
-__device__ __forceinline__ void tile_compute(const float *st, f32x16 (&acc)[2][2]) {
+// slices with k = 2 * ks + kk; the operands of step ks + 1 are read before the MFMAs of step ks are issued.
+// Waves: 2 x 2; wave tile (TI / 2) x 64 = WM x 2 MFMA blocks, WM = TI / 64.
+template <int TI>
+__device__ __forceinline__ void tile_compute(const float *st, f32x16 (&acc)[TI / 64][2]) {
+  constexpr int WM = TI / 64;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int wi = (wid >> 1) * (TI / 2), wj = (wid & 1) * 64;
   const int kk = lane >> 5, l31 = lane & 31;
-  const float *pa = st + kk * kTile + wi + l31;
-  const float *pb = st + Panels::offB + kk * kTile + wj + l31;
-  float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
-  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two LDS reads (ds_read2_b32) of step 0
+  const float *pa = st + kk * TI + wi + l31;
+  const float *pb = st + Panels<TI>::offB + kk * kTile + wj + l31;
+  float a[WM], b0 = pb[0], b1 = pb[32];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) a[i] = pa[32 * i];
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the LDS reads (ds_read2_b32) of step 0
 #pragma unroll
   for (int ks = 0; ks < kBK / 2; ++ks) {
-    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+    float na[WM], nb0 = 0.f, nb1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) na[i] = 0.f;
     if (ks + 1 < kBK / 2) {
-      na0 = pa[(ks + 1) * 2 * kTile];
-      na1 = pa[(ks + 1) * 2 * kTile + 32];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) na[i] = pa[(ks + 1) * 2 * TI + 32 * i];
       nb0 = pb[(ks + 1) * 2 * kTile];
       nb1 = pb[(ks + 1) * 2 * kTile + 32];
     }
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    // pin the issue order: two MFMAs of step ks, the two LDS reads (ds_read2_b32) of step ks + 1, the other two MFMAs.
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = na[i];
+    b0 = nb0; b1 = nb1;
+    // pin the issue order: the first MFMAs of step ks, the LDS reads (ds_read2_b32) of step ks + 1, the other MFMAs.
     // The compiler waits with a full lgkmcnt(0) before step ks + 1 whatever is in flight, so the reads must be OLD by
     // then: issued in the middle of the MFMA group they have >= 128 cycles of matrix-pipe time to land (left to itself
-    // the scheduler put them right in front of the wait: one LDS round trip parked per four MFMAs, 16 per K-tile).
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          // MFMA
+    // the scheduler put them right in front of the wait: one LDS round trip parked per MFMA group, 16 per K-tile).
+    __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);                         // MFMA
     if (ks + 1 < kBK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);                         // MFMA
   }
 }
 
 // Runs segment s0 then (NSEG == 2) segment s1 through the double-buffered LDS ring into one accumulator set.
-template <int NSEG>
-__device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds, f32x16 (&acc)[2][2]) {
+template <int NSEG, int TI = kTile>
+__device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds, f32x16 (&acc)[TI / 64][2]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI / 64; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -481,12 +505,12 @@ __device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds
   const int n1 = NSEG == 2 ? (s1.K + kBK - 1) / kBK : 0;
   const int total = n0 + n1;
   if (total == 0) return;
-  constexpr int kStage = Panels::stage;
-  TileRegs regs;
+  constexpr int kStage = Panels<TI>::stage;
+  TileRegs<TI> regs;
   {
     const bool f = n0 > 0;
-    panel_load(f ? s0.A : s1.A, f ? s0.B : s1.B, f ? s0.lda : s1.lda, f ? s0.ldb : s1.ldb, f ? s0.K : s1.K, 0, regs);
-    panel_store(lds, regs, f ? s0.sign : s1.sign);
+    panel_load<TI>(f ? s0.A : s1.A, f ? s0.B : s1.B, f ? s0.lda : s1.lda, f ? s0.ldb : s1.ldb, f ? s0.K : s1.K, 0, regs);
+    panel_store<TI>(lds, regs, f ? s0.sign : s1.sign);
   }
   __syncthreads();
   int stage = 0;
@@ -495,10 +519,10 @@ __device__ __forceinline__ void tile_gemm(const Seg s0, const Seg s1, float *lds
     const bool more = nx < total;
     const bool first = nx < n0;                         // uniform: which segment the NEXT K-tile belongs to
     if (more)                                           // scalar selects of by-value fields: everything stays in SGPRs
-      panel_load(first ? s0.A : s1.A, first ? s0.B : s1.B, first ? s0.lda : s1.lda, first ? s0.ldb : s1.ldb,
-                 first ? s0.K : s1.K, first ? nx * kBK : (nx - n0) * kBK, regs);
-    tile_compute(lds + stage * kStage, acc);
-    if (more) panel_store(lds + (stage ^ 1) * kStage, regs, first ? s0.sign : s1.sign);
+      panel_load<TI>(first ? s0.A : s1.A, first ? s0.B : s1.B, first ? s0.lda : s1.lda, first ? s0.ldb : s1.ldb,
+                     first ? s0.K : s1.K, first ? nx * kBK : (nx - n0) * kBK, regs);
+    tile_compute<TI>(lds + stage * kStage, acc);
+    if (more) panel_store<TI>(lds + (stage ^ 1) * kStage, regs, first ? s0.sign : s1.sign);
     __syncthreads();
     stage ^= 1;
   }
@@ -510,22 +534,26 @@ __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * 
 // gram + loss.  G is symmetric, so only the nt*(nt+1)/2 tiles with ti <= tj are computed: an off-diagonal
 // tile counts twice in the loss and is stored twice (as is, and transposed into the mirror position, 16 bytes
 // per lane per store: the C/D fragment holds 4 consecutive rows per register quad).
-// grid = (nt*(nt+1)/2, B): blockIdx.x -> (ti, tj) by walking the rows of the upper triangle.
-__global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__restrict__ fs,
+// grid = (nt*(nt+1)/2 * (128 / TI), B): blockIdx.x -> (ti, tj) by walking the rows of the upper triangle; TI = 64: two workgroups
+// per 128 x 128 tile (its upper and its lower 64 rows), twice the workgroups of half the size for graphs that do not fill the chip.
+template <int TI>
+__global__ __launch_bounds__(kThreads, TI == kTile ? 2 : 3) void gram_loss_kernel(const float *__restrict__ fs,
                                                                 const float *__restrict__ ft,
                                                                 float *__restrict__ G,
                                                                 float *__restrict__ part, int Cs,
                                                                 int Ct, int ldm, int nt) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels::lds_bytes
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<TI>::lds_bytes
   __shared__ float red[2 * kWavesPerWG];
+  constexpr int HALVES = kTile / TI, WM = TI / 64;
   const int b = blockIdx.y;
-  int ti = 0, rem = blockIdx.x;
+  const int half = HALVES == 1 ? 0 : (int)(blockIdx.x % HALVES);
+  int ti = 0, rem = blockIdx.x / HALVES;
   while (rem >= nt - ti) {
     rem -= nt - ti;
     ++ti;
   }
   const int tj = ti + rem;
-  const int i0 = ti * kTile, j0 = tj * kTile;
+  const int i0 = ti * kTile + half * TI, j0 = tj * kTile;
   Seg st_, ss_;                                          // teacher (+), student (-): one accumulator set
   st_.A = ft + (int64_t)b * Ct * ldm + i0;
   st_.B = ft + (int64_t)b * Ct * ldm + j0;
@@ -537,16 +565,16 @@ __global__ __launch_bounds__(kThreads, 2) void gram_loss_kernel(const float *__r
   ss_.lda = ss_.ldb = ldm;
   ss_.K = Cs;
   ss_.sign = -1.f;
-  f32x16 acc[2][2];
-  tile_gemm<2>(st_, ss_, lds, acc);
+  f32x16 acc[WM][2];
+  tile_gemm<2, TI>(st_, ss_, lds, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int wi = (wid >> 1) * (TI / 2), wj = (wid & 1) * 64;
   const bool mirror = ti != tj;
   float *Gb = G != nullptr ? G + (int64_t)b * ldm * ldm : nullptr;
   float sq = 0.f, unused = 0.f;
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < WM; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
       const int col = j0 + wj + bj * 32 + (lane & 31);
@@ -612,7 +640,8 @@ __host__ __device__ __forceinline__ int64_t sk_first_unit(const StreamK &k, int 
 // the workgroup whose range contains unit u: the largest w with sk_first_unit(w) <= u
 __host__ __device__ __forceinline__ int sk_owner(const StreamK &k, int64_t u) { return (int)(((u + 1) * k.nwg - 1) / k.total); }
 
-__global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *__restrict__ ft,
+template <int TI>      // rows (channels) of an output tile: 128, or 64 for problems that do not fill the chip with 128-row tiles
+__global__ __launch_bounds__(kThreads, TI == kTile ? 2 : 3) void pairwise_bwd_kernel(const float *__restrict__ ft,
                                                                    const float *__restrict__ G,
                                                                    const float *__restrict__ norm,
                                                                    const float *__restrict__ gscale,
@@ -620,11 +649,12 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
                                                                    float *__restrict__ part, int Cs,
                                                                    int M, int ldm, int ldc, int ntm, int ntc, StreamK sk,
                                                                    float coef) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels::lds_bytes
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // Panels<kTile>::lds_bytes
   const int w = blockIdx.x;
   const int64_t u0 = sk_first_unit(sk, w), u1 = sk_first_unit(sk, w + 1);
+  constexpr int WM = TI / 64;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int wi = (wid >> 1) * (TI / 2), wj = (wid & 1) * 64;
   const float scale = coef * gscale[0];
   const int tiles_per_image = ntm * ntc;
   bool first = true;
@@ -635,7 +665,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
     const int kt1 = (int)((u1 < tile_end ? u1 : tile_end) - t * sk.nkt);
     const int b = (int)(t / tiles_per_image), rem = (int)(t - (int64_t)b * tiles_per_image);
     const int tc = rem / ntm, tm = rem - tc * ntm;
-    const int c0 = tc * kTile, m0 = tm * kTile;
+    const int c0 = tc * TI, m0 = tm * kTile;
     Seg s;
     s.A = ft + ((int64_t)b * ldm + (int64_t)kt0 * kBK) * ldc + c0;     // A(k = n, i = c) = Fhat_S[c][n], node-major copy: k-major
     s.lda = ldc;
@@ -643,8 +673,8 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
     s.ldb = ldm;
     s.K = (kt1 - kt0) * kBK;
     s.sign = 1.f;
-    f32x16 acc[2][2];
-    tile_gemm<1>(s, s, lds, acc);
+    f32x16 acc[WM][2];
+    tile_gemm<1, TI>(s, s, lds, acc);
     __syncthreads();                                   // the LDS ring is reused by the next segment's first panel
     const bool whole = kt0 == 0 && kt1 == sk.nkt;
     if (whole) {
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
         const int m = m0 + wj + bj * 32 + (lane & 31);
         const float inv = m < M ? scale / norm[(int64_t)b * M + m] : 0.f;
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
+        for (int bi = 0; bi < WM; ++bi)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int c = c0 + wi + bi * 32 + frag_row(r, lane);
@@ -661,13 +691,13 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
           }
       }
     } else {
-      // raw partial of a shared tile: slot 0 = this workgroup's first segment, slot 1 = a later (its last) one; (128, 128) row-major
-      float *dst = part + ((int64_t)w * 2 + (first ? 0 : 1)) * (kTile * kTile);
+      // raw partial of a shared tile: slot 0 = this workgroup's first segment, slot 1 = a later (its last) one; (TI, 128) row-major
+      float *dst = part + ((int64_t)w * 2 + (first ? 0 : 1)) * (TI * kTile);
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj) {
         const int ml = wj + bj * 32 + (lane & 31);
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
+        for (int bi = 0; bi < WM; ++bi)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dst[(wi + bi * 32 + frag_row(r, lane)) * kTile + ml] = acc[bi][bj][r];
       }
@@ -677,13 +707,13 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_bwd_kernel(const float *
   }
 }
 
-// One workgroup per output tile: dpooled[b][c][m] = coef * gscale / norm[b][m] * sum over the covering workgroups' slots, in
-// workgroup order (m >= M: 0).  A tile one workgroup computed alone was written by pairwise_bwd_kernel: nothing to do.
+// Four workgroups per output tile (32 rows each): dpooled[b][c][m] = coef * gscale / norm[b][m] * sum over the covering
+// workgroups' slots, in workgroup order (m >= M: 0).  A tile one workgroup computed alone was written by pairwise_bwd_kernel.
 __global__ __launch_bounds__(kThreads) void pairwise_bwd_fixup_kernel(const float *__restrict__ part,
                                                                      const float *__restrict__ norm,
                                                                      const float *__restrict__ gscale,
                                                                      float *__restrict__ dpooled, int Cs, int M, int ldm,
-                                                                     int ntm, int ntc, StreamK sk, float coef) {
+                                                                     int ntm, int ntc, StreamK sk, float coef, int TI) {
   const int64_t t = blockIdx.x;
   const int64_t ub = t * sk.nkt, ue = ub + sk.nkt;
   const int wf = sk_owner(sk, ub), wl = sk_owner(sk, ue - 1);
@@ -691,16 +721,17 @@ __global__ __launch_bounds__(kThreads) void pairwise_bwd_fixup_kernel(const floa
   const int tiles_per_image = ntm * ntc;
   const int b = (int)(t / tiles_per_image), rem = (int)(t - (int64_t)b * tiles_per_image);
   const int tc = rem / ntm, tm = rem - tc * ntm;
-  const int c0 = tc * kTile, m0 = tm * kTile;
+  const int c0 = tc * TI, m0 = tm * kTile;
   const float scale = coef * gscale[0];
   const float *nr = norm + (int64_t)b * M;
-  for (int q = threadIdx.x; q < kTile * kTile / 4; q += kThreads) {
+  const int per = TI * kTile / 16;                       // float4 per quarter of the tile
+  for (int q = blockIdx.y * per + threadIdx.x; q < (blockIdx.y + 1) * per; q += kThreads) {
     const int cl = q >> 5, ml = (q & 31) * 4;            // 32 float4 per tile row
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int w = wf; w <= wl; ++w) {
       // tile t is workgroup w's FIRST segment iff its range starts inside t
       const int slot = sk_first_unit(sk, w) >= ub ? 0 : 1;
-      const float4 v = *reinterpret_cast<const float4 *>(part + ((int64_t)w * 2 + slot) * (kTile * kTile) + cl * kTile + ml);
+      const float4 v = *reinterpret_cast<const float4 *>(part + ((int64_t)w * 2 + slot) * ((int64_t)TI * kTile) + cl * kTile + ml);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int c = c0 + cl, m = m0 + ml;
@@ -915,7 +946,7 @@ int skd_channel_l2_normalise(int B, int C, int M, const float *pooled, float *fh
 int64_t skd_pairwise_workspace_floats(int B, int M) {
   if (B <= 0 || M <= 0) return 1;
   const int64_t nt = cdiv(M, kTile);
-  return nt * (nt + 1) / 2 * B;
+  return nt * (nt + 1) / 2 * B * 2;          // (x 2: the half-height tiles of small graphs write one partial each)
 }
 
 static bool gemm_lds_ready() {
@@ -924,10 +955,14 @@ static bool gemm_lds_ready() {
   if (donep == nullptr) return false;
   bool &done = *donep;
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels::lds_bytes) != hipSuccess) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels::lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel<kTile>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<kTile>::lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gram_loss_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<64>::lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel<kTile>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<kTile>::lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pairwise_bwd_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Panels<64>::lds_bytes) != hipSuccess) return false;
     done = true;
   }
   return true;
@@ -943,21 +978,32 @@ int skd_pairwise_gram_loss(int B, int Cs, int Ct, int M, int ldm, const float *f
   const int nt = ldm / kTile;
   const int ntri = nt * (nt + 1) / 2;
   if (!gemm_lds_ready()) return 0;
-  gram_loss_kernel<<<dim3((unsigned)ntri, B), dim3(kThreads), Panels::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace, Cs,
-                                                                                             Ct, ldm, nt);
+  // fewer 128 x 128 tiles than two rounds of the chip's 512 slots: half-height tiles, twice the workgroups (M = 1089: 720 instead of 360)
+  const int halves = (int64_t)ntri * B < 1024 ? 2 : 1;
+  if (halves == 2)
+    gram_loss_kernel<64><<<dim3((unsigned)ntri * 2, B), dim3(kThreads), Panels<64>::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace, Cs,
+                                                                                                     Ct, ldm, nt);
+  else
+    gram_loss_kernel<kTile><<<dim3((unsigned)ntri, B), dim3(kThreads), Panels<kTile>::lds_bytes, st>>>(fhat_s, fhat_t, G, workspace,
+                                                                                                         Cs, Ct, ldm, nt);
   if (!ok()) return 0;
   // utils.py:181: / (M*M) / B
-  return launch_final_sum(workspace, (int64_t)ntri * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
+  return launch_final_sum(workspace, (int64_t)ntri * halves * B, loss, 1.0 / ((double)M * (double)M) / (double)B, st);
 }
 
 // Stream-K geometry of the backward contraction (see pairwise_bwd_kernel): one round of the chip -- 2 workgroups (64 KB of LDS
 // each) per compute unit, 512 on a whole MI355X; sized WITHOUT asking the device (the workspace query must work on a host without
 // one) -- but never fewer than 8 K-tiles per workgroup (pipeline fill / drain) and never more workgroups than units.
 constexpr int kStreamWG = 512;
+// rows of an output tile: 128, or 64 when 128-row tiles would give fewer than 512 workgroups of >= 8 K-tiles (M = 1089: 324)
+static int bwd_tile_rows(int B, int Cs, int ldm) {
+  const int64_t units = (int64_t)(ldm / kTile) * cdiv(Cs, kTile) * B * (ldm / kBK);
+  return units / 8 < kStreamWG ? 64 : kTile;
+}
 static StreamK bwd_stream_k(int B, int Cs, int ldm) {
   StreamK k;
   k.nkt = ldm / kBK;
-  k.total = (int64_t)(ldm / kTile) * cdiv(Cs, kTile) * B * k.nkt;
+  k.total = (int64_t)(ldm / kTile) * cdiv(Cs, bwd_tile_rows(B, Cs, ldm)) * B * k.nkt;
   int64_t n = k.total / 8;
   if (n > kStreamWG) n = kStreamWG;
   if (n < 1) n = 1;
@@ -980,9 +1026,10 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, co
   if (B <= 0 || Cs <= 0 || M <= 0 || !fhat_s || !G || !norm_s || !grad_loss || !dpooled) return 0;
   if (ldm != skd_pairwise_ldm(M) || B > 65535) return 0;
   if ((reinterpret_cast<uintptr_t>(fhat_s) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(dpooled)) & 15) return 0;
-  const int ntm = ldm / kTile, ntc = (int)cdiv(Cs, kTile);
+  const int TI = bwd_tile_rows(B, Cs, ldm);
+  const int ntm = ldm / kTile, ntc = (int)cdiv(Cs, TI);
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return 0;
-  const int ldc = ntc * kTile;
+  const int ldc = (int)cdiv(Cs, kTile) * kTile;          // node-major copy: channel rows padded to 128 (covers 64-row tiles too)
   const StreamK sk = bwd_stream_k(B, Cs, ldm);
   const int64_t tiles = (int64_t)ntm * ntc * B;
   if (tiles > 2147483647) return 0;
@@ -992,11 +1039,15 @@ int skd_pairwise_backward(int B, int Cs, int M, int ldm, const float *fhat_s, co
   if (!gemm_lds_ready()) return 0;
   hipStream_t st = as_stream(stream);
   transpose_pad_kernel<<<dim3((unsigned)(ldm / 32), (unsigned)(ldc / 32), B), dim3(kThreads), 0, st>>>(fhat_s, ft, Cs, ldm, ldc);
-  pairwise_bwd_kernel<<<dim3((unsigned)sk.nwg), dim3(kThreads), Panels::lds_bytes, st>>>(
-      ft, G, norm_s, grad_loss, dpooled, part, Cs, M, ldm, ldc, ntm, ntc, sk, coef);
+  if (TI == 64)
+    pairwise_bwd_kernel<64><<<dim3((unsigned)sk.nwg), dim3(kThreads), Panels<64>::lds_bytes, st>>>(
+        ft, G, norm_s, grad_loss, dpooled, part, Cs, M, ldm, ldc, ntm, ntc, sk, coef);
+  else
+    pairwise_bwd_kernel<kTile><<<dim3((unsigned)sk.nwg), dim3(kThreads), Panels<kTile>::lds_bytes, st>>>(
+        ft, G, norm_s, grad_loss, dpooled, part, Cs, M, ldm, ldc, ntm, ntc, sk, coef);
   if (!ok()) return 0;
-  pairwise_bwd_fixup_kernel<<<dim3((unsigned)tiles), dim3(kThreads), 0, st>>>(part, norm_s, grad_loss, dpooled, Cs, M, ldm, ntm, ntc,
-                                                                            sk, coef);
+  pairwise_bwd_fixup_kernel<<<dim3((unsigned)tiles, 4), dim3(kThreads), 0, st>>>(part, norm_s, grad_loss, dpooled, Cs, M, ldm, ntm, ntc,
+                                                                            sk, coef, TI);
   return ok();
 }
 
