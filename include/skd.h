@@ -529,6 +529,27 @@ int skd_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const floa
                           skd_stream_t stream);
 int skd_maxpool3x3s2_backward_nhwc(int B, int C, int H, int W, int OH, int OW, const float *dy, const uint8_t *arg,
                                    float *dx, skd_stream_t stream);
+/* Round 6: the TRAINING stem in two fused passes per direction (networks/pspnet_combine.py:176-180: conv3 -> bn3 -> relu3 ->
+ * maxpool of the student): BatchNorm (given batch statistics: skd_abn_stats_nhwc / the cross-replica combine) -> ReLU -> the
+ * max-pool above, x (B, H, W, C) the raw convolution output, C a power of two in [4, 1024].
+ *   forward          pooled (B, OH, OW, C) = maxpool(relu(bn(x))) and arg, bit for bit what skd_abn_apply_nhwc_to(relu) followed by
+ *                    skd_maxpool3x3s2_nhwc produce -- the (B, H, W, C) normalised tensor is never written;
+ *   backward_reduce  edz / eydz [C] of the BatchNorm for the gradient un-pooled through arg and masked with relu'(bn(x))
+ *                    (recomputed from x): skd_maxpool3x3s2_backward_nhwc + skd_abn_relu_backward_reduce_nhwc_x without the
+ *                    (B, H, W, C) gradient; workspace: skd_abn_nhwc_workspace_floats(B * H * W, C);
+ *   backward_dx      dx (B, H, W, C) (+ dweight / dbias, `accumulate` as in skd_abn_relu_backward_dx_nhwc_x) from the (exchanged,
+ *                    for InPlaceABNSync) edz / eydz. */
+int skd_abn_relu_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *mean,
+                                   const float *var, const float *weight, const float *bias, float eps, float *pooled,
+                                   uint8_t *arg, skd_stream_t stream);
+int skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x,
+                                                   const float *dpooled, const uint8_t *arg, const float *mean,
+                                                   const float *var, const float *weight, const float *bias, float *edz,
+                                                   float *eydz, float eps, float *workspace, skd_stream_t stream);
+int skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *dpooled,
+                                               const uint8_t *arg, const float *mean, const float *var, const float *weight,
+                                               const float *bias, const float *edz, const float *eydz, float *dx,
+                                               float *dweight, float *dbias, float eps, int accumulate, skd_stream_t stream);
 
 #ifdef __cplusplus
 }

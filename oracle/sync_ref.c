@@ -273,6 +273,51 @@ int skd_abn_relu_backward_nhwc_sync(void *ctx, int64_t rows, int C, const float 
 /* the grid-barrier cap of the product's one-launch passes has no host counterpart: accepted, reports "whole device" */
 int skd_abn_set_fused_max_workgroups(int n) { (void)n; return 256; }
 
+/* ---- the training stem fused (include/skd.h section 12, round 6): restated as the op SEQUENCE it replaces -- normalise + ReLU,
+ *      then the max-pool (networks/pspnet_combine.py:176-180); backward: un-pool, then the BatchNorm + ReLU backward passes ---- */
+int skd_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, float *y, uint8_t *arg, stream_t st);
+int skd_maxpool3x3s2_backward_nhwc(int B, int C, int H, int W, int OH, int OW, const float *dy, const uint8_t *arg, float *dx,
+                                   stream_t st);
+
+int skd_abn_relu_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *mean, const float *var,
+                                   const float *weight, const float *bias, float eps, float *pooled, uint8_t *arg, stream_t st) {
+  if (B <= 0 || C < 4 || (C & (C - 1)) || C > 1024 || !x || !mean || !var || !pooled || !arg) return 0;
+  const int64_t rows = (int64_t)B * H * W;
+  float *y = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (!y) return 0;
+  int ok_ = skd_abn_apply_nhwc_to(rows, C, x, NULL, y, mean, var, weight, bias, eps, 3 /* ReLU */, 0.f, st);
+  if (ok_) ok_ = skd_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, y, pooled, arg, st);
+  free(y);
+  return ok_;
+}
+
+int skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *dpooled,
+                                                   const uint8_t *arg, const float *mean, const float *var, const float *weight,
+                                                   const float *bias, float *edz, float *eydz, float eps, float *ws, stream_t st) {
+  if (B <= 0 || C < 4 || (C & (C - 1)) || C > 1024 || !x || !dpooled || !arg || !mean || !var || !edz || !eydz || !ws) return 0;
+  const int64_t rows = (int64_t)B * H * W;
+  float *dy = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (!dy) return 0;
+  int ok_ = skd_maxpool3x3s2_backward_nhwc(B, C, H, W, OH, OW, dpooled, arg, dy, st);
+  if (ok_) ok_ = skd_abn_relu_backward_reduce_nhwc_x(rows, C, x, dy, mean, var, weight, bias, edz, eydz, eps, ws, st);
+  free(dy);
+  return ok_;
+}
+
+int skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *dpooled,
+                                               const uint8_t *arg, const float *mean, const float *var, const float *weight,
+                                               const float *bias, const float *edz, const float *eydz, float *dx, float *dweight,
+                                               float *dbias, float eps, int accumulate, stream_t st) {
+  if (B <= 0 || C < 4 || (C & (C - 1)) || C > 1024 || !x || !dpooled || !arg || !mean || !var || !edz || !eydz || !dx) return 0;
+  const int64_t rows = (int64_t)B * H * W;
+  float *dy = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (!dy) return 0;
+  int ok_ = skd_maxpool3x3s2_backward_nhwc(B, C, H, W, OH, OW, dpooled, arg, dy, st);
+  if (ok_) ok_ = skd_abn_relu_backward_dx_nhwc_x(rows, C, x, dy, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, accumulate, st);
+  free(dy);
+  return ok_;
+}
+
 /* the two switches of the one-launch passes (include/skd.h section 13): the host double keeps the STATE (environment read once,
  * setters override) so that the host logic above it can be exercised; it always runs the three-step form itself */
 static int g_fused_state = -1, g_sync_fused_state = -1;

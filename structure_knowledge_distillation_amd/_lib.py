@@ -101,6 +101,10 @@ SIGNATURES = {
     "skd_ppm_fold_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
     "skd_maxpool3x3s2_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_maxpool3x3s2_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_abn_relu_maxpool3x3s2_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "skd_abn_relu_maxpool3x3s2_backward_dx_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                                         _I, _P]),
     "skd_seg_confusion": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "skd_sum_f32": (_I, [_L, _P, _P, _F, _P, _P]),
     "skd_sync_handle_bytes": (_I, []),

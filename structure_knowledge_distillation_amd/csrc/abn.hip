@@ -1734,6 +1734,232 @@ __global__ __launch_bounds__(kRedThreads) void abn_bwd_fused_nhwc_kernel(
   }
 }
 
+// =============================================================================================
+// Student stem (round 6): training BatchNorm -> ReLU -> MaxPool2d(3, 2, 1, ceil_mode) on the (8, 128, 256, 256)
+// conv3 output (networks/pspnet_combine.py:176-180) WITHOUT the 268 MB normalised tensor.  The reference (and rounds 1-5) ran
+// statistics, normalise + ReLU (read 268 MB, write 268 MB), pool (read 268 MB) and in backward un-pool (write 268 MB), reduce
+// (read 2 x 268), dx (read 2 x 268, write 268).  Here:
+//   forward   statistics (the ordinary pass), then ONE kernel that reads x, evaluates y = relu(bn(x)) per element with the
+//             forward's own expression (bn_pre) and pools y under PyTorch's rule, writing only the 68 MB pooled map + one byte of
+//             argmax per element (the winner's position inside its window, csrc/maxpool.hip's code) -- bit for bit what
+//             normalise-then-pool produces, indices included (ties at zero after the ReLU go to the first window position in both);
+//   backward  two passes over 2 x 2 INPUT blocks (the four positions of a block only ever belong to the same four windows, see
+//             maxpool.hip): the pooled gradient is gathered through the argmax bytes, masked with bn_pre(x) > 0 recomputed from x,
+//             and enters the usual edz / eydz reduction and dx formula.  The un-pooled 268 MB gradient never exists.
+// =============================================================================================
+__device__ __forceinline__ void pool_take(float v, int code, float &best, int &arg) {
+  if (v > best || v != v) {        // PyTorch's max-pool rule (first maximum wins, NaN propagates); maxpool.hip: take()
+    best = v;
+    arg = code;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void abn_relu_maxpool_nhwc_kernel(
+    const float *__restrict__ x, float *__restrict__ pooled, uint8_t *__restrict__ arg, const float *__restrict__ mean,
+    const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ bias, float eps, int64_t items,
+    int H, int W, int OH, int OW, int C4) {
+  const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (item >= items) return;
+  const int q = (int)(item % C4);
+  const int ox = (int)((item / C4) % OW);
+  const int oy = (int)((item / ((int64_t)C4 * OW)) % OH);
+  const int b = (int)(item / ((int64_t)C4 * OW * OH));
+  float m[4], is[4], gm[4], bt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = mean[q * 4 + k];
+    is[k] = inv_std_of(var[q * 4 + k], eps);
+    gm[k] = gamma_of(weight, q * 4 + k, eps);
+    bt[k] = beta_of(bias, q * 4 + k);
+  }
+  const int ys = 2 * oy - 1, xs = 2 * ox - 1;
+  const int y0 = ys < 0 ? 0 : ys, x0 = xs < 0 ? 0 : xs;
+  const int y1 = ys + 3 < H ? ys + 3 : H, x1 = xs + 3 < W ? xs + 3 : W;
+  const float ninf = -__builtin_huge_valf();
+  float best[4] = {ninf, ninf, ninf, ninf};
+  const int first = (y0 - ys) * 3 + (x0 - xs);
+  int a[4] = {first, first, first, first};
+  const float *src = x + ((int64_t)b * H * W) * C4 * 4 + q * 4;
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + ((int64_t)yy * W + xx) * C4 * 4);
+      const int code = (yy - ys) * 3 + (xx - xs);
+      const float V[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pool_take(act_fwd<SKD_ACT_RELU>(bn_pre(V[k], m[k], is[k], gm[k], bt[k]), 0.f), code, best[k], a[k]);
+    }
+  *reinterpret_cast<float4 *>(pooled + item * 4) = make_float4(best[0], best[1], best[2], best[3]);
+  *reinterpret_cast<uchar4 *>(arg + item * 4) =
+      make_uchar4((unsigned char)a[0], (unsigned char)a[1], (unsigned char)a[2], (unsigned char)a[3]);
+}
+
+// One 2 x 2 input block (i, j) of image b, channel quad at column `col`: the four windows (i, j), (i, j+1), (i+1, j), (i+1, j+1)
+// that can contain its positions, and per position p = 2 * dy + dx the gathered gradient (maxpool.hip's code table, terms in
+// window order).  valid[p]: the position exists.
+struct PoolBlock {
+  float g[4][4];      // [position][channel]
+  bool valid[4];
+};
+__device__ __forceinline__ void pool_block_gather(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int b, int i, int j,
+                                                  int H, int W, int OH, int OW, int C, int col, PoolBlock &o) {
+  float4 g[4];
+  uchar4 a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int oy = i + (k >> 1), ox = j + (k & 1);
+    if (oy < OH && ox < OW) {
+      const int64_t off = (((int64_t)b * OH + oy) * OW + ox) * C + col;
+      a[k] = *reinterpret_cast<const uchar4 *>(arg + off);
+      g[k] = *reinterpret_cast<const float4 *>(dy + off);
+    } else {
+      a[k] = make_uchar4(255, 255, 255, 255);          // no such window: matches no code
+      g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // position -> (window, code) pairs, in window order:  (2i, 2j): (0, 4)   (2i, 2j+1): (0, 5) (1, 3)   (2i+1, 2j): (0, 7) (2, 1)
+  //                                                     (2i+1, 2j+1): (0, 8) (1, 6) (2, 2) (3, 0)
+  const unsigned char A[4][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w},
+                                 {a[2].x, a[2].y, a[2].z, a[2].w}, {a[3].x, a[3].y, a[3].z, a[3].w}};
+  const float G[4][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w},
+                         {g[2].x, g[2].y, g[2].z, g[2].w}, {g[3].x, g[3].y, g[3].z, g[3].w}};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    if (A[0][c] == 4) r0 += G[0][c];
+    if (A[0][c] == 5) r1 += G[0][c];
+    if (A[1][c] == 3) r1 += G[1][c];
+    if (A[0][c] == 7) r2 += G[0][c];
+    if (A[2][c] == 1) r2 += G[2][c];
+    if (A[0][c] == 8) r3 += G[0][c];
+    if (A[1][c] == 6) r3 += G[1][c];
+    if (A[2][c] == 2) r3 += G[2][c];
+    if (A[3][c] == 0) r3 += G[3][c];
+    o.g[0][c] = r0;
+    o.g[1][c] = r1;
+    o.g[2][c] = r2;
+    o.g[3][c] = r3;
+  }
+  o.valid[0] = true;
+  o.valid[1] = 2 * j + 1 < W;
+  o.valid[2] = 2 * i + 1 < H;
+  o.valid[3] = o.valid[1] && o.valid[2];
+}
+
+// edz / eydz of the fused stem: rows of the reduction geometry = 2 x 2 blocks (B * H2 * W2), the expectation over B * H * W positions
+template <int U>
+__global__ __launch_bounds__(kRedThreads) void abn_pool_grad_nhwc2_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const uint8_t *__restrict__ arg, const float *__restrict__ mean,
+    const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ bias, float *__restrict__ part,
+    unsigned *counters, float *__restrict__ edz, float *__restrict__ eydz, float eps, int64_t blocks, int H, int W, int OH,
+    int OW, int H2, int W2, RedGeom g) {
+  __shared__ double lds[kRedThreads * 4];
+  __shared__ double fin[kRedThreads * 2];
+  __shared__ unsigned ticket_s;
+  const int t = threadIdx.x;
+  const int cb = blockIdx.x % g.CB, rg = blockIdx.x / g.CB;
+  const int cq = t & (g.CW4 - 1), rsub = t >> g.log2CW4;
+  const int col = (cb * g.CW4 + cq) * 4, C = g.C4 * 4;
+  float m[4], is[4], gm[4], bt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = mean[col + k];
+    is[k] = inv_std_of(var[col + k], eps);
+    gm[k] = gamma_of(weight, col + k, eps);
+    bt[k] = beta_of(bias, col + k);
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t slab = (int64_t)g.rpp * U;
+  for (int64_t base = (int64_t)rg * slab + rsub; base < blocks; base += (int64_t)g.RG * slab) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + (int64_t)u * g.rpp;
+      if (r < blocks) {
+        const int j = (int)(r % W2), i = (int)((r / W2) % H2), b = (int)(r / ((int64_t)W2 * H2));
+        PoolBlock pb;
+        pool_block_gather(dy, arg, b, i, j, H, W, OH, OW, C, col, pb);
+        const float *px = x + (((int64_t)b * H + 2 * i) * W + 2 * j) * C + col;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (!pb.valid[p]) continue;
+          const float4 v = *reinterpret_cast<const float4 *>(px + ((int64_t)(p >> 1) * W + (p & 1)) * C);
+          const float X[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float dz = bn_pre(X[k], m[k], is[k], gm[k], bt[k]) > 0.f ? pb.g[p][k] : 0.f;
+            const float y = (X[k] - m[k]) * is[k];
+            s1[k] += dz;
+            s2[k] += y * dz;
+          }
+        }
+      }
+    }
+  }
+  if (!red_finish(s1, s2, part, counters + cb, g, cb, rg, lds, fin, &ticket_s)) return;
+  const int CW = g.CW4 * 4;
+  if (t < CW) {
+    const int c = cb * CW + t;
+    const double cnt = (double)(blocks / ((int64_t)H2 * W2)) * H * W;      // B * H * W positions
+    edz[c] = (float)(fin[(t >> 2) * 8 + (t & 3)] / cnt);
+    eydz[c] = (float)(fin[(t >> 2) * 8 + 4 + (t & 3)] / cnt);
+  }
+}
+
+// dx of the fused stem: a thread owns one (2 x 2 block, channel quad); dweight / dbias by the first C4 threads of workgroup 0
+__global__ __launch_bounds__(kThreads) void abn_pool_grad_dx_nhwc_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const uint8_t *__restrict__ arg, const float *__restrict__ mean,
+    const float *__restrict__ var, const float *__restrict__ weight, const float *__restrict__ bias, const float *__restrict__ edz,
+    const float *__restrict__ eydz, float *__restrict__ dx, float *dweight, float *dbias, float eps, int64_t items, int H, int W,
+    int OH, int OW, int H2, int W2, int C4, int accumulate, float norm) {
+  const int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (item >= items) return;
+  const int q = (int)(item % C4);
+  const int j = (int)((item / C4) % W2);
+  const int i = (int)((item / ((int64_t)C4 * W2)) % H2);
+  const int b = (int)(item / ((int64_t)C4 * W2 * H2));
+  const int col = q * 4, C = C4 * 4;
+  float m[4], is[4], gm[4], bt[4], e[4], ey[4], mul[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = mean[col + k];
+    is[k] = inv_std_of(var[col + k], eps);
+    gm[k] = gamma_of(weight, col + k, eps);
+    bt[k] = beta_of(bias, col + k);
+    e[k] = edz[col + k];
+    ey[k] = eydz[col + k];
+    mul[k] = gm[k] * is[k];
+  }
+  PoolBlock pb;
+  pool_block_gather(dy, arg, b, i, j, H, W, OH, OW, C, col, pb);
+  const int64_t o0 = (((int64_t)b * H + 2 * i) * W + 2 * j) * C + col;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (!pb.valid[p]) continue;
+    const int64_t o = o0 + ((int64_t)(p >> 1) * W + (p & 1)) * C;
+    const float4 v = *reinterpret_cast<const float4 *>(x + o);
+    const float X[4] = {v.x, v.y, v.z, v.w};
+    float D[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dz = bn_pre(X[k], m[k], is[k], gm[k], bt[k]) > 0.f ? pb.g[p][k] : 0.f;
+      const float y = (X[k] - m[k]) * is[k];
+      D[k] = (dz - e[k] - y * ey[k]) * mul[k];
+    }
+    *reinterpret_cast<float4 *>(dx + o) = make_float4(D[0], D[1], D[2], D[3]);
+  }
+  if (item < C4) {                                  // (item == q here: block 0, one thread per channel quad)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = col + k;
+      if (dweight != nullptr) {                     // bn.cu:217-229 accumulates; accumulate == 0 writes
+        const float wv = weight[c];
+        const float gwt = wv > 0.f ? ey[k] * norm : (wv < 0.f ? -ey[k] * norm : 0.f);
+        dweight[c] = accumulate ? dweight[c] + gwt : gwt;
+      }
+      if (dbias != nullptr) dbias[c] = accumulate ? dbias[c] + e[k] * norm : e[k] * norm;
+    }
+  }
+}
+
 constexpr int kStatsU = 8, kGrad0U = 8, kGrad1U = 4;
 
 // Rows in flight per thread and trip (U): the tuned maximum for large tensors; halved while the launch would leave
@@ -2431,6 +2657,58 @@ int skd_abn_relu_backward_dx_nhwc(int64_t rows, int C, const float *x, const flo
     abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, true><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g, accumulate);
   else
     abn_grad_dx_nhwc_kernel<SKD_ACT_NONE, 1, false><<<grid, block, 0, st>>>(x, out, dout, mean, var, weight, nullptr, edz, eydz, dx, dres, dweight, dbias, eps, 0.f, rows, g, accumulate);
+  return ok();
+}
+
+// ---- student stem: BN -> ReLU -> MaxPool2d(3, 2, 1, ceil_mode) fused (round 6; include/skd.h section 1b) ----------------------
+static bool stem_geom_ok(int B, int C, int H, int W, int OH, int OW) {
+  if (B <= 0 || C < 4 || C > 4 * kThreads || (C & (C - 1)) || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return false;
+  // every window starts inside the input (ceil_mode rule) and the windows cover it (csrc/maxpool.hip: pool_geom_ok)
+  return 2 * (OH - 1) - 1 < H && 2 * (OW - 1) - 1 < W && 2 * (OH - 1) + 1 >= H - 1 && 2 * (OW - 1) + 1 >= W - 1;
+}
+
+int skd_abn_relu_maxpool3x3s2_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *mean, const float *var,
+                                   const float *weight, const float *bias, float eps, float *pooled, uint8_t *arg,
+                                   skd_stream_t stream) {
+  if (!stem_geom_ok(B, C, H, W, OH, OW) || !x || !mean || !var || !pooled || !arg) return 0;
+  if (!aligned16(x) || !aligned16(pooled) || (reinterpret_cast<uintptr_t>(arg) & 3)) return 0;
+  const int64_t items = (int64_t)B * OH * OW * (C / 4);
+  if (cdiv(items, kThreads) > 2147483647) return 0;
+  abn_relu_maxpool_nhwc_kernel<<<dim3((unsigned)cdiv(items, kThreads)), dim3(kThreads), 0, as_stream(stream)>>>(
+      x, pooled, arg, mean, var, weight, bias, eps, items, H, W, OH, OW, C / 4);
+  return ok();
+}
+
+int skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *dpooled,
+                                                   const uint8_t *arg, const float *mean, const float *var, const float *weight,
+                                                   const float *bias, float *edz, float *eydz, float eps, float *workspace,
+                                                   skd_stream_t stream) {
+  if (!stem_geom_ok(B, C, H, W, OH, OW) || !x || !dpooled || !arg || !mean || !var || !edz || !eydz || !workspace) return 0;
+  if (!aligned16(x) || !aligned16(dpooled) || (reinterpret_cast<uintptr_t>(arg) & 3)) return 0;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const int64_t blocks = (int64_t)B * H2 * W2;
+  RedGeom rg;
+  const int u = pick_u(blocks, C, 2, rg);                // (two blocks = eight positions in flight per thread)
+  if (u == 0) return 0;
+  unsigned *cnt = red_counters();
+  if (cnt == nullptr) return 0;
+  abn_pool_grad_nhwc2_kernel<2><<<dim3((unsigned)(rg.RG * rg.CB)), dim3(kRedThreads), 0, as_stream(stream)>>>(
+      x, dpooled, arg, mean, var, weight, bias, workspace, cnt, edz, eydz, eps, blocks, H, W, OH, OW, H2, W2, rg);
+  return ok();
+}
+
+int skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(int B, int C, int H, int W, int OH, int OW, const float *x, const float *dpooled,
+                                               const uint8_t *arg, const float *mean, const float *var, const float *weight,
+                                               const float *bias, const float *edz, const float *eydz, float *dx, float *dweight,
+                                               float *dbias, float eps, int accumulate, skd_stream_t stream) {
+  if (!stem_geom_ok(B, C, H, W, OH, OW) || !x || !dpooled || !arg || !mean || !var || !edz || !eydz || !dx) return 0;
+  if (!aligned16(x) || !aligned16(dpooled) || !aligned16(dx) || (reinterpret_cast<uintptr_t>(arg) & 3) || (dweight && !weight)) return 0;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const int64_t items = (int64_t)B * H2 * W2 * (C / 4);
+  if (cdiv(items, kThreads) > 2147483647) return 0;
+  abn_pool_grad_dx_nhwc_kernel<<<dim3((unsigned)cdiv(items, kThreads)), dim3(kThreads), 0, as_stream(stream)>>>(
+      x, dpooled, arg, mean, var, weight, bias, edz, eydz, dx, dweight, dbias, eps, items, H, W, OH, OW, H2, W2, C / 4, accumulate,
+      (float)((int64_t)B * H * W));
   return ok();
 }
 

@@ -384,14 +384,22 @@ def _pool_out(n, ceil_mode):
     return o
 
 
+stem_pool_out = _pool_out
+
+
+def is_stem_pool(pool):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1[, ceil_mode]) without dilation / returned indices: what csrc/maxpool.hip and
+    the fused stem kernels implement."""
+    def _pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return (isinstance(pool, torch.nn.MaxPool2d) and _pair(pool.kernel_size) == (3, 3) and _pair(pool.stride) == (2, 2)
+            and _pair(pool.padding) == (1, 1) and _pair(pool.dilation) == (1, 1) and not pool.return_indices)
+
+
 def max_pool_stem(x, pool):
     """``pool(x)`` for the stem's nn.MaxPool2d(3, 2, 1, ceil_mode=True) (pspnet_combine.py:135): channels-last fp32
     tensors take csrc/maxpool.hip, anything else the stock operator."""
-    def _pair(v):
-        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
-    if (x.dtype == torch.float32 and _is_cl(x) and (x.is_cuda or _lib.test_backend_active())
-            and _pair(pool.kernel_size) == (3, 3) and _pair(pool.stride) == (2, 2) and _pair(pool.padding) == (1, 1)
-            and _pair(pool.dilation) == (1, 1) and not pool.return_indices):
+    if (x.dtype == torch.float32 and _is_cl(x) and (x.is_cuda or _lib.test_backend_active()) and is_stem_pool(pool)):
         return _MaxPool3x3s2.apply(x, _pool_out(x.shape[2], pool.ceil_mode), _pool_out(x.shape[3], pool.ceil_mode))
     return pool(x)
 

@@ -537,6 +537,88 @@ def abn_relu_train(x, weight, bias, running_mean, running_var, residual=None, mo
     return _ABNRelu.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, group)
 
 
+class _ABNReluMaxPool(autograd.Function):
+    """Training-time ``maxpool3x3s2(relu(bn_batch(x)))`` of the student's stem (networks/pspnet_combine.py:176-180: bn3 -> relu3 ->
+    maxpool on the (B, 128, 256, 256) conv3 output) WITHOUT the normalised tensor (csrc/abn.hip, "student stem"): forward =
+    statistics + ONE kernel that normalises, rectifies and pools on the fly (68 MB written instead of 268 + 68, argmax as one byte
+    per element); backward = the edz / eydz reduction and the dx pass, both gathering the pooled gradient through the argmax bytes
+    and recomputing the ReLU mask from x.  Values, indices and gradients are those of abn_relu_train followed by the stem pool
+    (bit for bit in the forward; the backward's reductions add in another order).  Channels-last fp32 only; cross-replica
+    statistics exactly as in _ABNRelu's three-launch form (statistics -> exchange -> apply / reduce -> exchange -> dx)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, oh, ow, momentum, eps, group):
+        _lib.require_device(x, weight, bias, running_mean, running_var)
+        if x.dtype != torch.float32 or not _is_nhwc(x):
+            raise TypeError("abn_relu_maxpool_train: channels-last fp32 tensors only")
+        _check_contiguous(weight, bias, running_mean, running_var)
+        ctx.eps = float(eps)
+        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        geo = _Geom(x)
+        c = geo.c
+        b, _, h, w = x.shape
+        lib, st = _lib.get(), _lib.stream_of(x)
+        stat = x.new_empty((2, c))
+        mean, var = stat[0], stat[1]
+        ws = geo.workspace(lib, x)
+        geo.stats(lib, x, mean, var, ws, st)
+        if ctx.group is None:
+            if running_mean is not None and running_var is not None:
+                _lib.check(lib.skd_abn_update_running(c, running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
+                                                      var.data_ptr(), float(momentum), float(geo.count), st), "skd_abn_update_running")
+        else:
+            mean, var = _sync_stats(stat, c, geo.count, ctx.group, running_mean, running_var, momentum, lib, st)
+        pooled = x.new_empty((b, oh, ow, c)).permute(0, 3, 1, 2)          # channels-last memory
+        arg = torch.empty((b, oh, ow, c), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.skd_abn_relu_maxpool3x3s2_nhwc(b, c, h, w, oh, ow, x.data_ptr(), mean.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+                                                      _lib.ptr(bias), ctx.eps, pooled.data_ptr(), arg.data_ptr(), st),
+                   "skd_abn_relu_maxpool3x3s2_nhwc")
+        ctx.geom = (b, c, h, w, oh, ow)
+        ctx.save_for_backward(x, arg, weight, bias, mean, var)
+        return pooled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpooled):
+        x, arg, weight, bias, mean, var = ctx.saved_tensors
+        b, c, h, w, oh, ow = ctx.geom
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0:3]
+        dpooled = dpooled if _is_nhwc(dpooled) else dpooled.contiguous(memory_format=torch.channels_last)
+        lib, st = _lib.get(), _lib.stream_of(x)
+        geo = _Geom(x)
+        stat = x.new_empty((2, c))
+        edz, eydz = stat[0], stat[1]
+        ws = geo.workspace(lib, x)
+        _lib.check(lib.skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(
+            b, c, h, w, oh, ow, x.data_ptr(), dpooled.data_ptr(), arg.data_ptr(), mean.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+            _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), ctx.eps, ws.data_ptr(), st), "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc")
+        if ctx.group is not None:
+            _sync_grad_stats(stat, ctx.group)
+        dx = torch.empty_like(x)
+        dweight = torch.empty_like(weight) if (need_dw and weight is not None) else None
+        dbias = torch.empty_like(weight) if (need_db and weight is not None) else None
+        _lib.check(lib.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(
+            b, c, h, w, oh, ow, x.data_ptr(), dpooled.data_ptr(), arg.data_ptr(), mean.data_ptr(), var.data_ptr(), _lib.ptr(weight),
+            _lib.ptr(bias), edz.data_ptr(), eydz.data_ptr(), dx.data_ptr(), _lib.ptr(dweight), _lib.ptr(dbias), ctx.eps, 0, st),
+            "skd_abn_relu_maxpool3x3s2_backward_dx_nhwc")
+        return (dx if need_dx else None), dweight, dbias, None, None, None, None, None, None, None
+
+
+def abn_relu_maxpool_supported(x):
+    """channels-last fp32 tensor with a channel count the channels-last kernels take (a power of two in [4, 1024])."""
+    return x.dtype == torch.float32 and _is_nhwc(x) and not _nhwc_unsupported(x) and (x.is_cuda or _lib.test_backend_active())
+
+
+def abn_relu_maxpool_train(x, weight, bias, running_mean, running_var, oh, ow, momentum=0.1, eps=1e-05, group=None, sync=True):
+    """maxpool3x3s2(relu(bn_batch(x))), (oh, ow) = the pooled size (torch's rule for kernel 3, stride 2, padding 1, ceil_mode as the
+    caller's pool has it), with the running-statistics update: the training stem in two fused passes per direction."""
+    if not sync:
+        group = None
+    elif group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = dist.group.WORLD
+    return _ABNReluMaxPool.apply(x, weight, bias, running_mean, running_var, int(oh), int(ow), momentum, eps, group)
+
+
 def abn_eval_fused(x, weight, bias, running_mean, running_var, eps=1e-05, activation=ACT_RELU, slope=0.01,
                    residual=None):
     """Inference-only InPlace-ABN: ``x <- act(bn_running(x) [+ residual])`` in ONE in-place pass.

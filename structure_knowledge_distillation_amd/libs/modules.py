@@ -6,7 +6,8 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .inplace_abn import abn_eval_fused, abn_relu_train, inplace_abn, inplace_abn_sync
+from .inplace_abn import (abn_eval_fused, abn_relu_maxpool_supported, abn_relu_maxpool_train, abn_relu_train, inplace_abn,
+                          inplace_abn_sync)
 
 _sync_group = {"group": None, "explicit": False}
 
@@ -77,6 +78,19 @@ class _ABNBase(nn.Module):
             return self.fused_eval(x, "relu", residual)
         out = self(x)
         return torch.relu(out if residual is None else out + residual)
+
+    def forward_relu_maxpool(self, x, pool):
+        """``pool(relu(self(x)))`` for an ``activation='none'`` module followed by nn.ReLU and the stem's
+        nn.MaxPool2d(3, 2, 1) (networks/pspnet_combine.py:176-180).  Training on a channels-last fp32 tensor: two fused passes
+        per direction that never write the normalised tensor (abn_relu_maxpool_train); anything else: forward_relu, then the pool."""
+        from .. import functional as SF
+        if (self.activation == "none" and self.training and abn_relu_maxpool_supported(x) and SF.is_stem_pool(pool)):
+            sync = isinstance(self, InPlaceABNSync)
+            group = _sync_group["group"] if (sync and _sync_group["explicit"]) else None
+            oh, ow = SF.stem_pool_out(x.shape[2], pool.ceil_mode), SF.stem_pool_out(x.shape[3], pool.ceil_mode)
+            return abn_relu_maxpool_train(x, self.weight, self.bias, self.running_mean, self.running_var, oh, ow, self.momentum,
+                                          self.eps, group, sync=sync)
+        return SF.max_pool_stem(self.forward_relu(x), pool)
 
     def extra_repr(self):
         rep = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"

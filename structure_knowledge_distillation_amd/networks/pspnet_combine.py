@@ -38,6 +38,7 @@ FUSED_TAIL = True     # conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> r
                       # profiles/r03c_bench_ab_teacher_tail{0,1}.json: -1.1 ... -2.0 ms per step
 BLAS_TAILS = True     # the 1x1 reduce convolutions and stride-1 down-sample branches as library GEMMs with the folded BN (+ ReLU)
                       # in the epilogue (functional.conv1x1_bn_blas); profiles/r02f: 68.2 -> 66.9 ms per step
+STEM_FUSED = True     # training stem: bn3 -> relu3 -> maxpool without the normalised tensor (libs.modules.forward_relu_maxpool, round 6)
 PSP_FOLD = True       # conv3x3(cat(up(priors), feats)) = conv3x3(feats) + fold(priors x W) (csrc/ppm.hip); profiles/r02d: 77.4 -> 72.2 ms
 
 
@@ -290,12 +291,16 @@ class ResNet(nn.Module):
             if _fused(self, x):
                 x = self.bn1.forward_relu(self.conv1(x))
                 x = self.bn2.forward_relu(self.conv2(x))
-                x = self.bn3.forward_relu(self.conv3(x))
+                # training: bn3 -> relu3 -> maxpool in two fused passes per direction (csrc/abn.hip "student stem", round 6): the
+                # 268 MB normalised conv3 output is never written, its gradient never un-pooled into memory; STEM_FUSED = False or an
+                # input the fused kernels do not take: forward_relu, then csrc/maxpool.hip (channels-last) / the stock pool
+                x = (self.bn3.forward_relu_maxpool(self.conv3(x), self.maxpool) if STEM_FUSED
+                     else SF.max_pool_stem(self.bn3.forward_relu(self.conv3(x)), self.maxpool))
             else:
                 x = self.relu1(self.bn1(self.conv1(x)))
                 x = self.relu2(self.bn2(self.conv2(x)))
                 x = self.relu3(self.bn3(self.conv3(x)))
-            x = SF.max_pool_stem(x, self.maxpool)       # csrc/maxpool.hip for channels-last maps, the stock op otherwise
+                x = SF.max_pool_stem(x, self.maxpool)       # csrc/maxpool.hip for channels-last maps, the stock op otherwise
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)

@@ -1306,6 +1306,125 @@ def test_maxpool3x3s2_nhwc(hip, ref, geom):
     assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH + 1, OW, P(gpu(x)), P(yg), None, None) == 0
 
 
+@pytest.mark.parametrize("geom", [(8, 128, 256, 256), (2, 128, 128, 96), (1, 4, 9, 12), (2, 8, 65, 33), (3, 16, 1, 2), (2, 64, 17, 64)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_abn_relu_maxpool_stem(hip, ref, geom, affine):
+    """Round 6, the training stem fused (skd_abn_relu_maxpool3x3s2_nhwc / _backward_reduce_nhwc / _backward_dx_nhwc; networks/
+    pspnet_combine.py:176-180: bn3 -> relu3 -> maxpool).  Forward: pooled values AND argmax bytes bit for bit what the library's own
+    normalise + ReLU pass followed by its max-pool produce (the sequence the fusion replaces), and the C oracle's restatement of
+    that sequence to the usual bound.  Backward: edz / eydz / dx / dweight / dbias against the un-fused GPU sequence (un-pool, then the
+    BatchNorm + ReLU backward passes: same gathered terms in the same order, reductions in another order) and against the oracle."""
+    from structure_knowledge_distillation_amd.functional import _pool_out
+    B, C, H, W = geom
+    OH, OW = _pool_out(H, True), _pool_out(W, True)
+    rows = B * H * W
+    g = torch.Generator().manual_seed(H * 3 + W + C)
+    x = torch.randn(B, H, W, C, generator=g) * 2.0 + torch.randn(1, 1, 1, C, generator=g)
+    x[torch.rand(B, H, W, C, generator=g) < 0.05] = 0.75                # exact ties between window positions
+    w = torch.randn(C, generator=g) if affine else None
+    b = torch.randn(C, generator=g) * 0.5 if affine else None
+    if affine:
+        w[0], w[1] = 0.0, -abs(w[1])                                     # gamma = |w| + eps; zero weight: zero dweight
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    ws = torch.empty(max(1, hip.skd_abn_nhwc_workspace_floats(rows, C)), device=DEV)
+    stat = torch.empty(2, C, device=DEV)
+    assert hip.skd_abn_stats_nhwc(rows, C, P(xg), P(stat[0]), P(stat[1]), P(ws), None)
+    # ---- forward
+    pooled = torch.full((B, OH, OW, C), float("nan"), device=DEV)
+    arg = torch.full((B, OH, OW, C), 255, dtype=torch.uint8, device=DEV)
+    assert hip.skd_abn_relu_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(xg), P(stat[0]), P(stat[1]), P(wg), P(bg), 1e-5, P(pooled), P(arg), None)
+    y = torch.empty(B, H, W, C, device=DEV)
+    assert hip.skd_abn_apply_nhwc_to(rows, C, P(xg), None, P(y), P(stat[0]), P(stat[1]), P(wg), P(bg), 1e-5, 3, 0.0, None)
+    pooled_u, arg_u = torch.empty_like(pooled), torch.empty_like(arg)
+    assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(y), P(pooled_u), P(arg_u), None)
+    assert torch.equal(pooled, pooled_u) and torch.equal(arg, arg_u), "fused stem forward differs from normalise-then-pool"
+    want, idx = torch.nn.functional.max_pool2d(y.permute(0, 3, 1, 2), 3, 2, 1, ceil_mode=True, return_indices=True)
+    a = arg.long()
+    oy, ox = torch.arange(OH, device=DEV).view(1, OH, 1, 1), torch.arange(OW, device=DEV).view(1, 1, OW, 1)
+    assert torch.equal((2 * oy - 1 + a // 3) * W + (2 * ox - 1 + a % 3), idx.permute(0, 2, 3, 1)), "argmax differs from torch's indices"
+    small = rows * C <= (1 << 23)
+    st_c = stat.cpu()
+    if small:
+        pr, ar = torch.empty(B, OH, OW, C), torch.empty(B, OH, OW, C, dtype=torch.uint8)
+        assert ref.skd_abn_relu_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(x), P(st_c[0]), P(st_c[1]), P(w), P(b), 1e-5, P(pr), P(ar), None)
+        close(pooled, pr, 2e-5, "fused stem forward vs oracle")
+        differ = arg.cpu() != ar                  # only where two window positions are within rounding of each other
+        assert float(differ.float().mean()) <= 1e-3 and float((pooled.cpu() - pr)[differ].abs().max() if differ.any() else 0.0) <= 1e-4
+    # ---- backward
+    gp = torch.randn(B, OH, OW, C, generator=g)
+    gpg = gpu(gp)
+    e, e_u = torch.empty(2, C, device=DEV), torch.empty(2, C, device=DEV)
+    assert hip.skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(B, C, H, W, OH, OW, P(xg), P(gpg), P(arg), P(stat[0]), P(stat[1]), P(wg), P(bg),
+                                                             P(e[0]), P(e[1]), 1e-5, P(ws), None)
+    dy = torch.empty(B, H, W, C, device=DEV)
+    assert hip.skd_maxpool3x3s2_backward_nhwc(B, C, H, W, OH, OW, P(gpg), P(arg), P(dy), None)
+    assert hip.skd_abn_relu_backward_reduce_nhwc_x(rows, C, P(xg), P(dy), P(stat[0]), P(stat[1]), P(wg), P(bg), P(e_u[0]), P(e_u[1]), 1e-5, P(ws), None)
+    scale = float(dy.abs().mean()) + 1e-12
+    close(e, e_u, 1e-5, "fused stem edz / eydz vs the un-fused GPU sequence", floor=scale)
+    dx = torch.full((B, H, W, C), float("nan"), device=DEV)
+    dw, db = (torch.full((C,), 3.0, device=DEV), torch.full((C,), -2.0, device=DEV)) if affine else (None, None)
+    dx_u = torch.empty_like(dx)
+    dw_u, db_u = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if affine else (None, None)
+    assert hip.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(B, C, H, W, OH, OW, P(xg), P(gpg), P(arg), P(stat[0]), P(stat[1]), P(wg), P(bg),
+                                                         P(e_u[0]), P(e_u[1]), P(dx), P(dw), P(db), 1e-5, 1, None)
+    assert hip.skd_abn_relu_backward_dx_nhwc_x(rows, C, P(xg), P(dy), P(stat[0]), P(stat[1]), P(wg), P(bg), P(e_u[0]), P(e_u[1]), P(dx_u), P(dw_u),
+                                              P(db_u), 1e-5, 0, None)
+    assert torch.equal(dx, dx_u), "fused stem dx differs from the un-fused sequence on the same edz / eydz"
+    if affine:
+        assert torch.equal(dw - 3.0, (dw_u + 3.0) - 3.0) or float((dw - 3.0 - dw_u).abs().max()) <= 1e-5 * float(dw_u.abs().max() + 1.0)
+        close(db + 2.0, db_u, 1e-5, "dbias (accumulate = 1)", floor=float(db_u.abs().max()) + 2.0)
+        assert float(dw[0]) == 3.0                                        # zero weight: nothing added (bn.cu:217-223)
+    if small:
+        er, dxr = torch.empty(2, C), torch.empty(B, H, W, C)
+        wsr = torch.empty(max(1, ref.skd_abn_nhwc_workspace_floats(rows, C)))
+        assert ref.skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(B, C, H, W, OH, OW, P(x), P(gp), P(arg.cpu()), P(st_c[0]), P(st_c[1]), P(w), P(b),
+                                                                 P(er[0]), P(er[1]), 1e-5, P(wsr), None)
+        close(e, er, 2e-5, "fused stem edz / eydz vs oracle", floor=scale)
+        dwr, dbr = (torch.zeros(C), torch.zeros(C)) if affine else (None, None)
+        assert ref.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(B, C, H, W, OH, OW, P(x), P(gp), P(arg.cpu()), P(st_c[0]), P(st_c[1]), P(w), P(b),
+                                                             P(er[0]), P(er[1]), P(dxr), P(dwr), P(dbr), 1e-5, 0, None)
+        dx2 = torch.empty_like(dx)
+        assert hip.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(B, C, H, W, OH, OW, P(xg), P(gpg), P(arg), P(stat[0]), P(stat[1]), P(wg), P(bg),
+                                                             P(e[0]), P(e[1]), P(dx2), None, None, 1e-5, 0, None)
+        close(dx2, dxr, 5e-5, "fused stem dx vs oracle", floor=float(gp.abs().max()) * float(((w.abs() if affine else torch.ones(C)) / (st_c[1] + 1e-5).sqrt()).max()))
+    # ---- argument checks: odd channel count, impossible pooled size, missing pointers
+    assert hip.skd_abn_relu_maxpool3x3s2_nhwc(B, C + 1, H, W, OH, OW, P(xg), P(stat[0]), P(stat[1]), None, None, 1e-5, P(pooled), P(arg), None) == 0
+    assert hip.skd_abn_relu_maxpool3x3s2_nhwc(B, C, H, W, OH + 1, OW, P(xg), P(stat[0]), P(stat[1]), None, None, 1e-5, P(pooled), P(arg), None) == 0
+    assert hip.skd_abn_relu_maxpool3x3s2_nhwc(B, C, H, W, OH, OW, P(xg), P(stat[0]), P(stat[1]), None, None, 1e-5, P(pooled), None, None) == 0
+    assert hip.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(B, C, H, W, OH, OW, P(xg), P(gpg), P(arg), P(stat[0]), P(stat[1]), None, None,
+                                                         P(e[0]), P(e[1]), P(dx), P(e[0]), None, 1e-5, 0, None) == 0      # dweight without weight
+
+
+def test_student_stem_fused_equals_unfused_modules(monkeypatch):
+    """libs.modules.forward_relu_maxpool (what pspnet_combine.ResNet.forward calls for the training student when STEM_FUSED) against
+    forward_relu followed by the stem pool, full size: identical output bits, identical running statistics, gradients to rounding."""
+    from structure_knowledge_distillation_amd import libs
+    from structure_knowledge_distillation_amd import functional as SF
+    torch.manual_seed(11)
+    pool = torch.nn.MaxPool2d(3, 2, 1, ceil_mode=True)
+    bn_a = libs.InPlaceABNSync(128, activation="none").to(DEV).train()
+    bn_b = libs.InPlaceABNSync(128, activation="none").to(DEV).train()
+    with torch.no_grad():
+        bn_a.weight.normal_(); bn_a.bias.normal_(0, 0.5)
+        bn_b.load_state_dict(bn_a.state_dict())
+    x = (torch.randn(8, 128, 256, 256, device=DEV) * 1.5 + 0.3).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone(memory_format=torch.channels_last).requires_grad_(True), x.clone(memory_format=torch.channels_last).requires_grad_(True)
+    ya = bn_a.forward_relu_maxpool(xa * 1.0, pool)
+    yb = SF.max_pool_stem(bn_b.forward_relu(xb * 1.0), pool)
+    assert ya.shape == (8, 128, 129, 129) and ya.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ya, yb) and torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    close(xa.grad, xb.grad, 2e-5, "stem dx, fused vs un-fused")
+    close(bn_a.weight.grad, bn_b.weight.grad, 2e-5, "stem dweight", floor=float(bn_b.weight.grad.abs().max()))
+    close(bn_a.bias.grad, bn_b.bias.grad, 2e-5, "stem dbias", floor=float(bn_b.bias.grad.abs().max()))
+    # an input the fused kernels do not take (NCHW) goes through forward_relu + the stock pool
+    xn = torch.randn(2, 128, 17, 19, device=DEV)
+    out = bn_a.forward_relu_maxpool(xn, pool)
+    assert out.shape == (2, 128, 9, 10)
+
+
 @pytest.mark.parametrize("cfg", [(8, 1024, 256, 65, True), (2, 128, 128, 129, True), (2, 512, 128, 33, False)])
 def test_frozen_bottleneck_blas_tail(cfg, monkeypatch):
     """Frozen-teacher Bottleneck on the GPU: the 1x1 reduce convolution + BN + ReLU (and the stride-1 down-sample branch)
