@@ -339,7 +339,7 @@ class NetModel():
         """kd_model.py:121-122.  The frozen teacher is 100 % static -- same weights, same shapes, no autograd, ~330 launches
         issued op by op from Python -- so (SKD_TEACHER_GRAPH, default on) its forward is captured ONCE per input shape into a
         hipGraph and replayed: one host call per step instead of ~330 launches plus their Python dispatch (VERDICT r03 item 4;
-        DESIGN.md section 9.4 has the A/B).  The graph owns its input / activation / output buffers (2.6 GB at batch 8,
+        DESIGN.md Appendix A.3 has the A/B).  The graph owns its input / activation / output buffers (2.6 GB at batch 8,
         resident in HBM between steps -- 288 GB per GPU is what makes that free); ``preds_T`` are the graph's output tensors:
         STATIC buffers that the next replay overwrites.  Inside a step that is safe by stream order (main.wait_stream(D stream)
         at the end of a step keeps the next replay behind every reader); a consumer that wants to keep teacher outputs ACROSS

@@ -95,6 +95,49 @@ def test_sync_abn_two_ranks_equals_one_rank_on_the_whole_batch():
 
 
 # ---------------------------------------------------------------------------------------------------
+def _sync_stem(rank, world):
+    """Round 6: the fused training stem (bn3 -> relu3 -> maxpool, libs.modules.forward_relu_maxpool) with cross-replica statistics:
+    statistics -> exchange -> normalise-rectify-pool; gather-reduce -> exchange -> gather-dx."""
+    from structure_knowledge_distillation_amd import libs
+    g = torch.Generator().manual_seed(3)
+    n = 2 * world
+    x = (torch.randn(n, 8, 9, 11, generator=g) * 2 + 0.5)
+    gz = torch.randn(n, 8, 5, 6, generator=g)
+    w, b = torch.randn(8, generator=g), torch.randn(8, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    pool = torch.nn.MaxPool2d(3, 2, 1, ceil_mode=True)
+    mod = libs.InPlaceABNSync(8, activation="none").train()
+    with torch.no_grad():
+        mod.weight.copy_(w); mod.bias.copy_(b)
+    xs = x[sl].contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z = mod.forward_relu_maxpool(xs * 1.0, pool)
+    (z * gz[sl]).sum().backward()
+    return {"z": z.detach().contiguous(), "dx": xs.grad.contiguous(), "dw": mod.weight.grad, "db": mod.bias.grad,
+            "rm": mod.running_mean.clone(), "rv": mod.running_var.clone()}
+
+
+def test_fused_stem_two_ranks_equals_one_rank_on_the_whole_batch():
+    from oracle import abn_torch
+    outs = _run("_sync_stem")
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4, 8, 9, 11, generator=g) * 2 + 0.5)
+    gz = torch.randn(4, 8, 5, 6, generator=g)
+    w, b = torch.randn(8, generator=g), torch.randn(8, generator=g)
+    xo = x.double().requires_grad_(True)
+    wo, bo = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rm, rv = torch.zeros(8, dtype=torch.float64), torch.ones(8, dtype=torch.float64)
+    yo = torch.relu(abn_torch.abn_autograd(xo, wo, bo, rm, rv, True, 0.1, 1e-5, "none", 0.01))        # pspnet_combine.py:176-180
+    zo = torch.nn.functional.max_pool2d(yo, 3, 2, 1, ceil_mode=True)
+    (zo * gz.double()).sum().backward()
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        assert rel(outs[r]["z"], zo[sl]) < 1e-5 and rel(outs[r]["dx"], xo.grad[sl]) < 1e-4
+        assert rel(outs[r]["rm"], rm) < 1e-6 and rel(outs[r]["rv"], rv) < 1e-6        # pooled n = N * S * world
+    assert rel(0.5 * (outs[0]["dw"] + outs[1]["dw"]), 0.5 * wo.grad) < 1e-4
+    assert rel(0.5 * (outs[0]["db"] + outs[1]["db"]), 0.5 * bo.grad) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
 def _sync_abn_nhwc(rank, world):
     """Channels-last tensors take the ONE-CALL synchronised entries (skd_abn_forward_train_nhwc_sync / skd_abn_backward_nhwc_sync /
     skd_abn_relu_backward_nhwc_sync, include/skd.h section 12) whenever the group has mailboxes: in-place leaky form, fused

@@ -626,7 +626,7 @@ def _netmodel_step_world8(rank, world, dev=None):
     for name, ho in (("ho", True), ("pa", False)):
         torch.manual_seed(30 + rank)
         model = NetModel(default_args(batch_size=_B * world, ho=ho, device=dev, weight_decay=5e-4, lambda_pa=0.5))
-        assert not model._teacher_graph_on          # N > 1: eager teacher (DESIGN.md section 9.4)
+        assert not model._teacher_graph_on          # N > 1: eager teacher (DESIGN.md Appendix A.3)
         for m in model.student.modules():
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0.0

@@ -718,3 +718,39 @@ def test_dist_timeout_and_miopen_find_switches(monkeypatch):
             assert torch.backends.cudnn.benchmark is want
     finally:
         torch.backends.cudnn.benchmark = keep
+
+
+@pytest.mark.parametrize("geom", [(2, 8, 9, 11), (1, 16, 8, 8), (2, 4, 5, 6), (1, 4, 1, 2)])
+def test_fused_stem_on_the_double_equals_forward_relu_then_pool(geom):
+    """libs.modules.forward_relu_maxpool (round 6; what ResNet.forward calls for the training student) on the C double: output bits,
+    running statistics and gradients of forward_relu followed by the stem pool; inputs the fused form does not take (NCHW, eval,
+    another pool) fall back to that sequence."""
+    from structure_knowledge_distillation_amd import libs
+    from structure_knowledge_distillation_amd import functional as SF
+    B, C, H, W = geom
+    torch.manual_seed(B + C + H)
+    pool = torch.nn.MaxPool2d(3, 2, 1, ceil_mode=True)
+    bn_a, bn_b = libs.InPlaceABNSync(C, activation="none").train(), libs.InPlaceABNSync(C, activation="none").train()
+    with torch.no_grad():
+        bn_a.weight.normal_(); bn_a.bias.normal_()
+        bn_b.load_state_dict(bn_a.state_dict())
+    x = (torch.randn(B, C, H, W) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone(memory_format=torch.channels_last).requires_grad_(True), x.clone(memory_format=torch.channels_last).requires_grad_(True)
+    ya = bn_a.forward_relu_maxpool(xa * 1.0, pool)
+    yb = SF.max_pool_stem(bn_b.forward_relu(xb * 1.0), pool)
+    assert torch.equal(ya, yb) and torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert rel(xa.grad, xb.grad) < 1e-6 and rel(bn_a.weight.grad, bn_b.weight.grad) < 1e-6 and rel(bn_a.bias.grad, bn_b.bias.grad) < 1e-6
+    # fall-backs: NCHW input, a pool that is not the stem's, eval mode
+    xn = torch.randn(B, C, H, W)
+    assert torch.equal(bn_a.forward_relu_maxpool(xn.clone(), pool), pool(bn_b.forward_relu(xn.clone())))
+    other = torch.nn.MaxPool2d(2, 2)
+    if H >= 2 and W >= 2:
+        assert torch.equal(bn_a.forward_relu_maxpool(x.clone(memory_format=torch.channels_last), other),
+                           other(bn_b.forward_relu(x.clone(memory_format=torch.channels_last))))
+    with torch.no_grad():
+        bn_a.eval(); bn_b.eval()
+        assert torch.equal(bn_a.forward_relu_maxpool(x.clone(memory_format=torch.channels_last), pool),
+                           SF.max_pool_stem(bn_b.forward_relu(x.clone(memory_format=torch.channels_last)), pool))

@@ -172,6 +172,34 @@ def build_cases(lib, torch, dev, st):
         4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW, keep=(mx, my, mdy, mdx, marg))
     add("maxpool3x3s2_backward_nhwc", [B_, C_, Hh, Ww], lambda: lib.skd_maxpool3x3s2_backward_nhwc(B_, C_, Hh, Ww, OH, OW, p(mdy), p(marg), p(mdx), st),
         4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW)
+    # round 6, the training stem fused (csrc/abn.hip "student stem"): forward = read x once, write pooled + argmax; backward reduce =
+    # read x + (pooled gradient, argmax); backward dx = the same + write dx
+    smean, svar = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+    sgam, sbet = torch.ones(C_, device=dev), torch.zeros(C_, device=dev)
+    sws = torch.empty(max(1, lib.skd_abn_nhwc_workspace_floats(B_ * Hh * Ww, C_)), device=dev)
+    sstat, sdw, sdb = torch.empty(2, C_, device=dev), torch.empty(C_, device=dev), torch.empty(C_, device=dev)
+    add("abn_relu_maxpool3x3s2 (stem fwd, fused)", [B_, C_, Hh, Ww], lambda:
+        lib.skd_abn_relu_maxpool3x3s2_nhwc(B_, C_, Hh, Ww, OH, OW, p(mx), p(smean), p(svar), p(sgam), p(sbet), 1e-5, p(my), p(marg), st),
+        4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW, keep=(smean, svar, sgam, sbet, sws, sstat, sdw, sdb))
+    add("abn_relu_maxpool3x3s2_backward_reduce (stem bwd, fused)", [B_, C_, Hh, Ww], lambda:
+        lib.skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc(B_, C_, Hh, Ww, OH, OW, p(mx), p(mdy), p(marg), p(smean), p(svar), p(sgam), p(sbet),
+                                                           p(sstat[0]), p(sstat[1]), 1e-5, p(sws), st),
+        4 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW)
+    add("abn_relu_maxpool3x3s2_backward_dx (stem bwd, fused)", [B_, C_, Hh, Ww], lambda:
+        lib.skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(B_, C_, Hh, Ww, OH, OW, p(mx), p(mdy), p(marg), p(smean), p(svar), p(sgam), p(sbet),
+                                                       p(sstat[0]), p(sstat[1]), p(mdx), p(sdw), p(sdb), 1e-5, 0, st),
+        8 * B_ * C_ * Hh * Ww + 5 * B_ * C_ * OH * OW)
+    # ... and the un-fused sequence it replaces on the same tensors: normalise + ReLU, (pool above), (un-pool above), reduce, dx
+    sy = torch.empty(B_, Hh, Ww, C_, device=dev)
+    add("abn_apply_nhwc_to(relu) (stem fwd, un-fused part)", [B_ * Hh * Ww, C_], lambda:
+        lib.skd_abn_apply_nhwc_to(B_ * Hh * Ww, C_, p(mx), None, p(sy), p(smean), p(svar), p(sgam), p(sbet), 1e-5, 3, 0.0, st),
+        8 * B_ * C_ * Hh * Ww, keep=(sy,))
+    add("abn_relu_backward_reduce_nhwc_x (stem bwd, un-fused part)", [B_ * Hh * Ww, C_], lambda:
+        lib.skd_abn_relu_backward_reduce_nhwc_x(B_ * Hh * Ww, C_, p(mx), p(sy), p(smean), p(svar), p(sgam), p(sbet), p(sstat[0]), p(sstat[1]), 1e-5,
+                                                p(sws), st), 8 * B_ * C_ * Hh * Ww)
+    add("abn_relu_backward_dx_nhwc_x (stem bwd, un-fused part)", [B_ * Hh * Ww, C_], lambda:
+        lib.skd_abn_relu_backward_dx_nhwc_x(B_ * Hh * Ww, C_, p(mx), p(sy), p(smean), p(svar), p(sgam), p(sbet), p(sstat[0]), p(sstat[1]), p(mdx),
+                                            p(sdw), p(sdb), 1e-5, 0, st), 12 * B_ * C_ * Hh * Ww)
     # the pair-wise criterion's max-pool with argmax (csrc/pairwise.hip, NCHW planes): read the feature maps once
     for planes, kh in ((8 * 128, 32), (8 * 512, 32), (8 * 512, 1)):
         fx = torch.randn(planes, 65, 65, device=dev)
