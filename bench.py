@@ -475,7 +475,9 @@ def main():
              "skd_abn_relu_backward_reduce_nhwc_x", "skd_abn_relu_backward_dx_nhwc_x", "skd_abn_backward_nhwc",
              "skd_abn_relu_backward_nhwc",
              # round 5: the kernels rewritten this round, as they run inside the step
-             "skd_ce_dsn_forward", "skd_maxpool_argmax_nhwc", "skd_maxpool3x3s2_backward_nhwc"]
+             "skd_ce_dsn_forward", "skd_maxpool_argmax_nhwc", "skd_maxpool3x3s2_backward_nhwc",
+             # round 6: the training stem fused (bn3 -> relu3 -> max-pool without the normalised tensor)
+             "skd_abn_relu_maxpool3x3s2_nhwc", "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc", "skd_abn_relu_maxpool3x3s2_backward_dx_nhwc"]
     # Inside the timed region only the ROOFLINE entry is bracketed with HIP events (111 calls per step; bracketing all
     # ~700 hand-written calls costs 1.4 ms = 1.8 % of the step -- measured, profiles/r02 notes); the table of the other
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
@@ -642,6 +644,17 @@ def main():
             "skd_maxpool3x3s2_backward_nhwc (stem max-pool backward)": plain(
                 "skd_maxpool3x3s2_backward_nhwc", lambda d: 4.0 * d[0] * d[1] * d[2] * d[3] + 5.0 * d[0] * d[1] * (d[2] // 2 + 1) * (d[3] // 2 + 1),
                 "4 B per input element out + 5 B per output element in", "hbm"),
+            "skd_abn_relu_maxpool3x3s2_nhwc (student stem: normalise + ReLU + max-pool in one pass, round 6)": plain(
+                "skd_abn_relu_maxpool3x3s2_nhwc", lambda d: 4.0 * d[0] * d[1] * d[2] * d[3] + 5.0 * d[0] * d[1] * (d[2] // 2 + 1) * (d[3] // 2 + 1),
+                "4 B per input element in + 5 B per pooled element out (the normalised tensor is never written)", "hbm"),
+            "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc (student stem: edz / eydz through the argmax bytes)": plain(
+                "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc",
+                lambda d: 4.0 * d[0] * d[1] * d[2] * d[3] + 5.0 * d[0] * d[1] * (d[2] // 2 + 1) * (d[3] // 2 + 1),
+                "4 B per input element in + 5 B per pooled element in", "hbm"),
+            "skd_abn_relu_maxpool3x3s2_backward_dx_nhwc (student stem: dx, the un-pooled gradient never exists)": plain(
+                "skd_abn_relu_maxpool3x3s2_backward_dx_nhwc",
+                lambda d: 8.0 * d[0] * d[1] * d[2] * d[3] + 5.0 * d[0] * d[1] * (d[2] // 2 + 1) * (d[3] // 2 + 1),
+                "4 B per input element in + 4 out + 5 B per pooled element in", "hbm"),
         })
         line["kernels"] = {k: v for k, v in line["kernels"].items() if v}
         line["kernels_note"] = "HIP-event rates from three extra untimed steps run with the D step serial (no co-running stream)"

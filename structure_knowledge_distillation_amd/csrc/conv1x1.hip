@@ -139,7 +139,11 @@ __device__ __forceinline__ void tile_mma(const float *stage, f32x16 (&acc)[2][2]
 // Epilogue of one 32 x 32 accumulator block: rows row0 + frag_row(q), column col.  FULL: every row of the tile exists (all
 // but the last row tile) -- no per-element branches, and the sixteen residual loads are issued together before the first
 // use (round 2 interleaved load -> wait -> store per element behind a branch: 64 serialised HBM round trips per lane).
-template <int ACT, bool HAS_RES, bool FULL>
+// NT: the residual is read and the output written with the non-temporal hint (round 6).  For WIDE outputs (the super-tile order,
+// K = 512 / N = 2048) the 554 MB residual + output stream of a launch shares each XCD's 4 MB L2 with the operands it is trying to
+// keep (2 MB of activations per panel group, 1 MB of weights per chunk) and evicts them: counters showed the activations fetched
+// ~4 x (617 MB read for 350 MB algorithmic, profiles/r05j_pmc.json case 135).  Neither stream is read again by this kernel.
+template <int ACT, bool HAS_RES, bool FULL, bool NT>
 __device__ __forceinline__ void store_block(const f32x16 &acc, const float *__restrict__ R, float *__restrict__ Y, int64_t row0,
                                             int col, int64_t M, int N, float mu, float is, float ga, float be, float slope) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -150,7 +154,7 @@ __device__ __forceinline__ void store_block(const f32x16 &acc, const float *__re
     const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
     off[q] = row * N + col;
     rv[q] = 0.f;
-    if (HAS_RES && (FULL || row < M)) rv[q] = R[off[q]];
+    if (HAS_RES && (FULL || row < M)) rv[q] = NT ? __builtin_nontemporal_load(R + off[q]) : R[off[q]];
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -159,11 +163,14 @@ __device__ __forceinline__ void store_block(const f32x16 &acc, const float *__re
     if (HAS_RES) z += rv[q];
     if (ACT == SKD_ACT_RELU) z = z < 0.f ? 0.f : z;
     if (ACT == SKD_ACT_LEAKY_RELU) z = z < 0.f ? z * slope : z;
-    if (FULL || row < M) Y[off[q]] = z;
+    if (FULL || row < M) {
+      if (NT) __builtin_nontemporal_store(z, Y + off[q]);
+      else Y[off[q]] = z;
+    }
   }
 }
 
-template <int ACT, bool HAS_RES, bool PRO>
+template <int ACT, bool HAS_RES, bool PRO, bool NT>
 __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
     const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
@@ -244,9 +251,9 @@ __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     for (int bi = 0; bi < 2; ++bi) {
       const int64_t row0 = m0 + wi + bi * 32;
       if (full)
-        store_block<ACT, HAS_RES, true>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
+        store_block<ACT, HAS_RES, true, NT>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
       else
-        store_block<ACT, HAS_RES, false>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
+        store_block<ACT, HAS_RES, false, NT>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
     }
   }
 }
@@ -262,7 +269,7 @@ __global__ void pack_eval_params_kernel(int K, const float *__restrict__ mean, c
   pack[3 * (int64_t)K + k] = bias != nullptr ? bias[k] : 0.f;
 }
 
-template <int ACT, bool HAS_RES, bool PRO>
+template <int ACT, bool HAS_RES, bool PRO, bool NT = false>
 static int launch(const float *X, const float *Wt, const float *R, float *Y, const float *mean, const float *var,
                   const float *weight, const float *bias, const float *ppack, float eps, float slope, int64_t M, int K, int N,
                   hipStream_t st) {
@@ -270,7 +277,7 @@ static int launch(const float *X, const float *Wt, const float *R, float *Y, con
   bool *rdy = ready.get();
   if (rdy == nullptr) return 0;
   if (!*rdy) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES, PRO>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_abn_kernel<ACT, HAS_RES, PRO, NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kConvLds + sizeof(float) * 4 * kProMaxK)) != hipSuccess) return 0;
     *rdy = true;
   }
@@ -285,11 +292,12 @@ static int launch(const float *X, const float *Wt, const float *R, float *Y, con
   if (ct < 1) ct = 1;
   if (pm < 1) pm = 1;
   if (ct >= tiles_n) { ct = tiles_n; pm = 1; }              // narrow output: plain panel-major order
+  else if (!NT) return launch<ACT, HAS_RES, PRO, true>(X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, st);   // wide: NT epilogue
   while (tiles_n % ct) --ct;                                // chunks of equal width (tiles_n is a power of two in this network)
   const int64_t panels_per_xcd = cdiv(cdiv(tiles_m, 8), pm) * pm;   // row panels padded to whole groups on each of the 8 XCDs
   if (panels_per_xcd * 8 * tiles_n > 2147483647) return 0;
   const int64_t grid = panels_per_xcd * 8 * tiles_n;
-  conv1x1_abn_kernel<ACT, HAS_RES, PRO><<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(
+  conv1x1_abn_kernel<ACT, HAS_RES, PRO, NT><<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(
       X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n, pm, ct);
   return ok();
 }

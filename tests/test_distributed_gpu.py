@@ -584,9 +584,11 @@ def test_netmodel_ho_step_two_ranks_one_launch_syncabn_matches_three_launch_form
     for r in range(2):
         # 29 training ABN layers, forward + backward; the (B, C, 1, 1) pyramid stage is NCHW-contiguous and exchanges from Python,
         # and with the compute units split between the two ranks the 256 x 256 stem tensors do not fit half a register file: those
-        # few calls take the three-launch form beside peers -- the protocol does not care (observed: 50 one-launch, 6 three-launch)
-        assert one[r]["forms"][0] >= 40 and one[r]["forms"][0] + one[r]["forms"][1] == 56, one[r]["forms"]
-        assert three[r]["forms"] == (0, 56), three[r]["forms"]
+        # few calls take the three-launch form beside peers -- the protocol does not care (observed: 50 one-launch, 4 three-launch).
+        # Round 6: the stem's bn3 is part of the fused normalise-rectify-pool passes (statistics -> skd_abn_sync_stats -> ...,
+        # exchanged by the mailbox kernels directly, not through the one-call *_sync entries these counters count): 28 layers = 56 - 2
+        assert one[r]["forms"][0] >= 40 and one[r]["forms"][0] + one[r]["forms"][1] == 54, one[r]["forms"]
+        assert three[r]["forms"] == (0, 54), three[r]["forms"]
         for k, v in one[r]["losses"].items():
             assert abs(v - three[r]["losses"][k]) <= 1e-5 * abs(v), (r, k, v, three[r]["losses"][k])
     for k in one[0]["after"]:
@@ -735,7 +737,8 @@ def _check_world8(both, on_gpu=True):
             assert abs(outs_pa[r]["losses"][k] - ref) <= 1e-4 * abs(ref) + 1e-12, ("Pi + Pa step", r, k, outs_pa[r]["losses"][k], ref)
         if ipc:
             for o in (outs[r], outs_pa[r]):
-                assert o["forms"][0] + o["forms"][1] == 56, o["forms"]      # every channels-last layer through the one-call entries
+                assert o["forms"][0] + o["forms"][1] == 54, o["forms"]      # every channels-last layer through the one-call entries
+                                                                             # (28: the stem's bn3 exchanges inside the fused stem passes)
         logits = outs[r]["logits"][0].double().requires_grad_(True)
         P = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in PD.items()}
         lm = O.LeakyMasks(outs[r]["masks"][:4])          # the decisions of the rank's own G-step critic forward

@@ -256,6 +256,18 @@ d=json.loads([l for l in open('$f') if l.startswith('{')][0]); print('   [$v] $i
       timeout 1200 python -m pytest tests -m gpu -q --tb=short -s --durations=8 -k "${TESTS_K:-conv1x1}" > $O/pytest_k.log 2>&1
       stamp "tests_k [${TESTS_K:-conv1x1}] rc=$?"; grep -E "passed|failed|error" $O/pytest_k.log | tail -3 | tee -a $O/session.log
       grep -E "^E  |^FAILED" $O/pytest_k.log | cut -c1-300 | head -40 | tee -a $O/session.log ;;
+    pmc_only)
+      # FETCH_SIZE / WRITE_SIZE passes over a -k style selection of the microbench (PMC_ONLY="conv1x1"): HBM traffic of a few kernels
+      i=0
+      for set in "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i+1))
+        (cd /tmp && timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o k -- \
+          python $R/tools/kernel_microbench.py pmc 2 "${PMC_ONLY:-conv1x1}" > $O/pmc$i.log 2>&1)
+        stamp "pmc_only pass $i ($set) rc=$?"
+        find $O/pmc$i -name "*kernel_trace.csv" -delete
+      done
+      python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 >> $O/session.log 2>&1
+      stamp "pmc_only summarised" ;;
     ab_r04)
       # same-box A/B against the round-4 tree (git archive e78944f into _r04_tree/, built here, git-ignored): box-to-box variation is
       # +-1 %, the round's gains are of that size, so the two trees alternate on ONE box
