@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTM = 128, kTN = 128, kBK = 16, kLDK = kBK + 4, kMinWG = 3;
 constexpr int kQK = kBK / 4;                               // float4 per panel row
 constexpr int kRPP = kThreads / kQK;                       // panel rows covered by one pass of the workgroup (64)
-constexpr int kRA = kTM / kRPP, kRB = kTN / kRPP;          // float4 per thread, operand and K-tile (2 + 2)
+constexpr int kRB = kTN / kRPP;                            // float4 of the B panel per thread and K-tile (2); A: TM / kRPP (2 or 1)
 constexpr int kStageFloats = (kTM + kTN) * kLDK;           // 5120 floats = 20,480 bytes
 constexpr size_t kConvLds = sizeof(float) * 2 * kStageFloats;
 constexpr int kProMaxK = 512;                             // prologue form: the (4, K) parameter table rides in LDS (<= 8 KB)
@@ -49,19 +49,20 @@ __device__ __forceinline__ float inv_std_of(float var, float eps) { return (var 
 // Per K-tile a thread moves four float4 of the A panel (rows t/8 + 32h, k quad t%8) and four of the B panel from global memory
 // to LDS.  The loads are issued at the top of a trip, the LDS stores after the trip's MFMAs (a whole K-tile of matrix-pipe
 // time for them to land), the staging registers are not loop-carried (nothing for the compiler to copy).
+template <int TM>          // TM = rows of the output tile: 128, or 64 for the tiles of a launch's last, partial round (see the kernel)
 struct Staging {
-  float4 a[kRA], b[kRB];
+  float4 a[TM / kRPP], b[kRB];
 };
 struct ProParams {         // PRO: the k quad's mean / invstd / gamma / beta of the BatchNorm applied to A on the way in
   float4 pm, pi, pg, pb;   // (kept apart from Staging: a struct with members that one instantiation never writes stayed in scratch)
 };
 
-template <bool PRO>
-__device__ __forceinline__ void stage_load(Staging &s, const float *__restrict__ X, const float *__restrict__ Wt, int k0,
-                                           int gkq, const int64_t (&arow)[kRA], int64_t wrow0, int K) {
+template <bool PRO, int TM>
+__device__ __forceinline__ void stage_load(Staging<TM> &s, const float *__restrict__ X, const float *__restrict__ Wt, int k0,
+                                           int gkq, const int64_t (&arow)[TM / kRPP], int64_t wrow0, int K) {
   const float *xa = X + k0 + gkq, *wb = Wt + k0 + gkq;
 #pragma unroll
-  for (int h = 0; h < kRA; ++h) s.a[h] = *reinterpret_cast<const float4 *>(xa + arow[h]);
+  for (int h = 0; h < TM / kRPP; ++h) s.a[h] = *reinterpret_cast<const float4 *>(xa + arow[h]);
 #pragma unroll
   for (int h = 0; h < kRB; ++h) s.b[h] = *reinterpret_cast<const float4 *>(wb + wrow0 + (int64_t)(kRPP * h) * K);
 }
@@ -72,9 +73,10 @@ __device__ __forceinline__ float pro_one(float x, float m, float is, float g, fl
   return z < 0.f ? 0.f : z;
 }
 
-template <bool PRO>
-__device__ __forceinline__ void stage_store(const Staging s, float *stage, int srow, const float *ptab, int K, int kq) {
-  float *sa = stage + srow, *sb = stage + kTM * kLDK + srow;
+template <bool PRO, int TM>
+__device__ __forceinline__ void stage_store(const Staging<TM> s, float *stage, int srow, const float *ptab, int K, int kq) {
+  constexpr int kRA = TM / kRPP;
+  float *sa = stage + srow, *sb = stage + TM * kLDK + srow;
   if (PRO) {   // ptab (LDS copy of ppack): mean | invstd | gamma | beta, each K floats; kq = first of this thread's four k
     ProParams pp;
     pp.pm = *reinterpret_cast<const float4 *>(ptab + kq);
@@ -98,41 +100,50 @@ __device__ __forceinline__ void stage_store(const Staging s, float *stage, int s
   for (int h = 0; h < kRB; ++h) *reinterpret_cast<float4 *>(sb + kRPP * h * kLDK) = s.b[h];
 }
 
-// One K-tile out of LDS: per group of 8 k four conflict-free ds_read_b128 (a0, a1, b0, b1: FOUR consecutive k of the lane's
-// row) feed sixteen MFMAs; the reads of group g + 1 are issued before the MFMAs of group g (software pipelining in registers).
-__device__ __forceinline__ void tile_mma(const float *stage, f32x16 (&acc)[2][2]) {
+// One K-tile out of LDS: per group of 8 k conflict-free ds_read_b128 (a0 [, a1], b0, b1: FOUR consecutive k of the lane's row) feed
+// 8 * WM MFMAs; the reads of group g + 1 are issued before the MFMAs of group g (software pipelining in registers).
+// Waves 2 x 2, wave tile (TM / 2) x 64 = WM x 2 blocks of 32 x 32 (WM = TM / 64).
+template <int TM>
+__device__ __forceinline__ void tile_mma(const float *stage, f32x16 (&acc)[TM / 64][2]) {
+  constexpr int WM = TM / 64;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+  const int wi = (wid >> 1) * (TM / 2), wj = (wid & 1) * 64;
   const int half = lane >> 5, r = lane & 31;
   const float *pa = stage + (wi + r) * kLDK + half * 4;
-  const float *pb = stage + (kTM + wj + r) * kLDK + half * 4;
-  float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 32 * kLDK);
-  float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK);
-  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the four reads of group 0 (the pipeline below is matched in order)
+  const float *pb = stage + (TM + wj + r) * kLDK + half * 4;
+  float4 a[WM], b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK);
+#pragma unroll
+  for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const float4 *>(pa + 32 * i * kLDK);
+  __builtin_amdgcn_sched_group_barrier(0x100, WM + 2, 0);  // the reads of group 0 (the pipeline below is matched in order)
 #pragma unroll
   for (int g = 0; g < kBK / 8; ++g) {
-    float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+    float4 na[WM], nb0 = b0, nb1 = b1;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) na[i] = a[i];
     if (g + 1 < kBK / 8) {
-      na0 = *reinterpret_cast<const float4 *>(pa + (g + 1) * 8);
-      na1 = *reinterpret_cast<const float4 *>(pa + 32 * kLDK + (g + 1) * 8);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) na[i] = *reinterpret_cast<const float4 *>(pa + 32 * i * kLDK + (g + 1) * 8);
       nb0 = *reinterpret_cast<const float4 *>(pb + (g + 1) * 8);
       nb1 = *reinterpret_cast<const float4 *>(pb + 32 * kLDK + (g + 1) * 8);
     }
-    const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
     const float B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[t], B0[t], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[t], B1[t], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B0[t], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B1[t], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const float av = t == 0 ? a[i].x : t == 1 ? a[i].y : t == 2 ? a[i].z : a[i].w;
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B0[t], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B1[t], acc[i][1], 0, 0, 0);
+      }
     }
-    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = na[i];
+    b0 = nb0; b1 = nb1;
     // pin the issue order (left alone the scheduler sinks the reads to just before their first use and every group starts
-    // with an exposed LDS round trip): 4 MFMAs, the next group's four reads, the other 12 MFMAs (768 matrix-pipe cycles cover them)
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if (g + 1 < kBK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    // with an exposed LDS round trip): the first k's MFMAs, the next group's reads, the other MFMAs (their matrix-pipe cycles cover them)
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * WM, 0);
+    if (g + 1 < kBK / 8) __builtin_amdgcn_sched_group_barrier(0x100, WM + 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6 * WM, 0);
   }
 }
 
@@ -170,41 +181,17 @@ __device__ __forceinline__ void store_block(const f32x16 &acc, const float *__re
   }
 }
 
-template <int ACT, bool HAS_RES, bool PRO, bool NT>
-__global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
-    const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
-    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
-    const float *__restrict__ bias, const float *__restrict__ ppack, float eps, float slope, int64_t M, int K, int N,
-    int tiles_n, int pm, int ct) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md; used for traffic only, any
-  // placement is correct) and every XCD has its own L2: the tiles_n workgroups that share one 128 x K activation panel are
-  // therefore given to ONE XCD, back to back in its dispatch order -- the panel is fetched into one L2 instead of eight.
-  // Counters before (profiles/r03d_gemm_lab_pmc.json, K = 256, N = 1024): 421 MB fetched for 174 MB of algorithmic reads
-  // (8 x the 35 MB of activations); time-neutral in isolation (the Infinity Cache absorbs the fills), less traffic beside the
-  // D stream.  Row panel p lives on XCD p % 8; the grid is padded to a multiple of 8 panels, the padding exits here.
-  //
-  // Round 4 (VERDICT r03 item 6i): for WIDE outputs that order thrashes the weights instead.  At K = 512, N = 2048 the 16 column
-  // tiles of a panel stream all of W (4 MB = one XCD's whole L2) past every panel: counters showed 850 MB fetched for 350 MB of
-  // algorithmic reads.  So an XCD walks SUPER-TILES: groups of `pm` row panels (<= 2 MB of activations) x chunks of `ct` column
-  // tiles (<= 1 MB of weights): for group: for chunk: for panel in group: for column tile in chunk.  A weight chunk is reused
-  // by pm panels back to back, a panel group stays L2-resident across the chunks; W traffic falls from ~one sweep per panel to one
-  // per group.  ct == tiles_n (narrow outputs, e.g. K = 256 / N = 1024: 23 of the 33 launches of a teacher forward) degenerates
-  // to the panel-major order above.
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int per_group = pm * tiles_n;
-  const int group = j / per_group, r = j - group * per_group;
-  const int per_chunk = pm * ct;
-  const int chunk = r / per_chunk, r2 = r - chunk * per_chunk;
-  const int pl = r2 / ct;
-  const int tn = chunk * ct + (r2 - pl * ct);
-  const int64_t tm = ((int64_t)group * pm + pl) * 8 + xcd;
-  if (tm * kTM >= M || tn >= tiles_n) return;
-  const int64_t m0 = tm * kTM;
-  const int n0 = tn * kTN;
-  f32x16 acc[2][2];
+// One output tile of TM x 128: K loop through the double-buffered LDS ring, then the epilogue.
+template <int TM, int ACT, bool HAS_RES, bool PRO, bool NT>
+__device__ __forceinline__ void conv1x1_tile(const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R,
+                                             float *__restrict__ Y, const float *__restrict__ mean, const float *__restrict__ var,
+                                             const float *__restrict__ weight, const float *__restrict__ bias,
+                                             const float *__restrict__ ppack, float eps, float slope, int64_t M, int K, int N,
+                                             int64_t m0, int n0, float *lds) {
+  constexpr int WM = TM / 64, kRA = TM / kRPP;
+  f32x16 acc[WM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -224,23 +211,23 @@ __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     for (int i = gt * 4; i < 4 * K; i += kThreads * 4) *reinterpret_cast<float4 *>(ptab + i) = *reinterpret_cast<const float4 *>(ppack + i);
     __syncthreads();
   }
-  Staging st;
-  stage_load<PRO>(st, X, Wt, 0, gkq, arow, wrow0, K);
-  stage_store<PRO>(st, lds, srow, ptab, K, gkq);
+  Staging<TM> st;
+  stage_load<PRO, TM>(st, X, Wt, 0, gkq, arow, wrow0, K);
+  stage_store<PRO, TM>(st, lds, srow, ptab, K, gkq);
   __syncthreads();
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) stage_load<PRO>(st, X, Wt, (kt + 1) * kBK, gkq, arow, wrow0, K);
-    tile_mma(lds + stage * kStageFloats, acc);
-    if (more) stage_store<PRO>(st, lds + (stage ^ 1) * kStageFloats, srow, ptab, K, (kt + 1) * kBK + gkq);
+    if (more) stage_load<PRO, TM>(st, X, Wt, (kt + 1) * kBK, gkq, arow, wrow0, K);
+    tile_mma<TM>(lds + stage * kStageFloats, acc);
+    if (more) stage_store<PRO, TM>(st, lds + (stage ^ 1) * kStageFloats, srow, ptab, K, (kt + 1) * kBK + gkq);
     __syncthreads();
     stage ^= 1;
   }
   // ---- epilogue: the eval-mode InPlace-ABN formula on the accumulator (+ residual) + activation ----
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
-  const bool full = m0 + kTM <= M;
+  const int wi = (wid >> 1) * (TM / 2), wj = (wid & 1) * 64;
+  const bool full = m0 + TM <= M;
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) {
     const int col = n0 + wj + bj * 32 + (lane & 31);
@@ -248,13 +235,61 @@ __global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
     const float ga = weight != nullptr ? fabsf(weight[col]) + eps : 1.f;     // bn.cu:153
     const float be = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < WM; ++bi) {
       const int64_t row0 = m0 + wi + bi * 32;
       if (full)
         store_block<ACT, HAS_RES, true, NT>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
       else
         store_block<ACT, HAS_RES, false, NT>(acc[bi][bj], R, Y, row0, col, M, N, mu, is, ga, be, slope);
     }
+  }
+}
+
+template <int ACT, bool HAS_RES, bool PRO, bool NT>
+__global__ __launch_bounds__(kThreads, kMinWG) void conv1x1_abn_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ R, float *__restrict__ Y,
+    const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ weight,
+    const float *__restrict__ bias, const float *__restrict__ ppack, float eps, float slope, int64_t M, int K, int N,
+    int tiles_n, int pm, int ct, int p_full) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md; used for traffic only, any
+  // placement is correct) and every XCD has its own L2: the tiles_n workgroups that share one 128 x K activation panel are
+  // therefore given to ONE XCD, back to back in its dispatch order -- the panel is fetched into one L2 instead of eight.
+  // Counters before (profiles/r03d_gemm_lab_pmc.json, K = 256, N = 1024): 421 MB fetched for 174 MB of algorithmic reads
+  // (8 x the 35 MB of activations); time-neutral in isolation (the Infinity Cache absorbs the fills), less traffic beside the
+  // D stream.  Row panel p lives on XCD p % 8; the grid is padded to a multiple of 8 panels, the padding exits here.
+  //
+  // Round 4 (VERDICT r03 item 6i): for WIDE outputs that order thrashes the weights instead.  At K = 512, N = 2048 the 16 column
+  // tiles of a panel stream all of W (4 MB = one XCD's whole L2) past every panel: counters showed 850 MB fetched for 350 MB of
+  // algorithmic reads.  So an XCD walks SUPER-TILES: groups of `pm` row panels (<= 2 MB of activations) x chunks of `ct` column
+  // tiles (<= 1 MB of weights): for group: for chunk: for panel in group: for column tile in chunk.  A weight chunk is reused
+  // by pm panels back to back, a panel group stays L2-resident across the chunks; W traffic falls from ~one sweep per panel to one
+  // per group.  ct == tiles_n (narrow outputs, e.g. K = 256 / N = 1024: 23 of the 33 launches of a teacher forward) degenerates
+  // to the panel-major order above.
+  //
+  // Round 6: HALF-HEIGHT tiles for the launch's last, partial round.  The layer-3 problem is 2120 tiles of 128 x 128 on 768 slots
+  // (3 workgroups per CU): 2.76 rounds -- and the lab shows what the ragged last round costs: the same core reaches 0.72 of the
+  // peak on a tile count that divides the chip and 0.63-0.69 on this one (profiles/r06t_gemm_lab_quantisation.jsonl).  The row
+  // panels p < p_full are 128 rows high, the panels behind them (the rows a whole number of rounds does not cover) 64: twice the
+  // workgroups of half the duration fill the last round's slots (p_full is a multiple of 8: whole XCD rows).
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int per_group = pm * tiles_n;
+  const int group = j / per_group, r = j - group * per_group;
+  const int per_chunk = pm * ct;
+  const int chunk = r / per_chunk, r2 = r - chunk * per_chunk;
+  const int pl = r2 / ct;
+  const int tn = chunk * ct + (r2 - pl * ct);
+  const int64_t tm = ((int64_t)group * pm + pl) * 8 + xcd;
+  if (tn >= tiles_n) return;
+  const int n0 = tn * kTN;
+  if (tm < p_full) {
+    const int64_t m0 = tm * kTM;
+    if (m0 >= M) return;
+    conv1x1_tile<kTM, ACT, HAS_RES, PRO, NT>(X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, m0, n0, lds);
+  } else {
+    const int64_t m0 = (int64_t)p_full * kTM + (tm - p_full) * (kTM / 2);
+    if (m0 >= M) return;
+    conv1x1_tile<kTM / 2, ACT, HAS_RES, PRO, NT>(X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, m0, n0, lds);
   }
 }
 
@@ -294,11 +329,33 @@ static int launch(const float *X, const float *Wt, const float *R, float *Y, con
   if (ct >= tiles_n) { ct = tiles_n; pm = 1; }              // narrow output: plain panel-major order
   else if (!NT) return launch<ACT, HAS_RES, PRO, true>(X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, st);   // wide: NT epilogue
   while (tiles_n % ct) --ct;                                // chunks of equal width (tiles_n is a power of two in this network)
-  const int64_t panels_per_xcd = cdiv(cdiv(tiles_m, 8), pm) * pm;   // row panels padded to whole groups on each of the 8 XCDs
+  // half-height panels for the last, partial round; slots = 3 workgroups per compute unit
+  int64_t p_full = tiles_m, panels = tiles_m;
+  {
+    static PerDeviceFlag cu_known;
+    static int cus[64] = {};
+    bool *known = cu_known.get();
+    int dev = 0;
+    if (known != nullptr && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (!*known) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus[dev] = n;
+        *known = true;
+      }
+      const int64_t slots = (int64_t)kMinWG * cus[dev];
+      const int64_t tiles = tiles_m * tiles_n;
+      if (slots > 0 && tiles > slots && tiles % slots != 0) {
+        p_full = (tiles / slots) * slots / tiles_n / 8 * 8;            // whole rounds, whole XCD rows of panels
+        const int64_t rest_rows = M - p_full * kTM;
+        panels = p_full + cdiv(rest_rows, kTM / 2);
+      }
+    }
+  }
+  const int64_t panels_per_xcd = cdiv(cdiv(panels, 8), pm) * pm;   // row panels padded to whole groups on each of the 8 XCDs
   if (panels_per_xcd * 8 * tiles_n > 2147483647) return 0;
   const int64_t grid = panels_per_xcd * 8 * tiles_n;
   conv1x1_abn_kernel<ACT, HAS_RES, PRO, NT><<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(
-      X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n, pm, ct);
+      X, Wt, R, Y, mean, var, weight, bias, ppack, eps, slope, M, K, N, tiles_n, pm, ct, (int)p_full);
   return ok();
 }
 

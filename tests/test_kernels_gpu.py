@@ -1061,7 +1061,10 @@ def _pa_torch(fs, ft, k):
     return ((sim(pt) - sim(ps)) ** 2).sum() / (pt.shape[-1] * pt.shape[-2]) ** 2 / pt.shape[0]
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 1024, 256), (129, 2048, 512), (128, 128, 128)])
+# (33800 / 33791, 64, 512): more tiles than one round of the chip's slots -- the rows behind the last whole round run as HALF-HEIGHT
+# tiles (round 6), with a ragged last half panel
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 1024, 256), (129, 2048, 512), (128, 128, 128),
+                                   (33800, 64, 512), (33791, 32, 384)])
 @pytest.mark.parametrize("act,with_res", [(3, True), (3, False), (0, False), (1, True)])
 def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
     """1x1 convolution + eval-mode ABN (+ residual) + activation as one fp32-MFMA GEMM vs the C oracle (double dot
@@ -1079,7 +1082,7 @@ def test_conv1x1_abn_gemm(hip, ref, M, K, N, act, with_res):
     assert hip.skd_conv1x1_abn_nhwc(M, K + 8, N, P(gpu(x)), P(gpu(w)), None, P(o_g), P(gpu(mean)), P(gpu(var)), None, None, 1e-5, act, 0.01, None) == 0
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 96, 256), (129, 512, 2048)])
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4225, 256, 1024), (777, 96, 256), (129, 512, 2048), (33800, 48, 512)])
 @pytest.mark.parametrize("with_res,affine", [(True, True), (False, True), (True, False)])
 def test_conv1x1_abn_gemm_with_bn_relu_prologue(hip, ref, M, K, N, with_res, affine):
     """skd_conv1x1_abn_pro_nhwc: relu(bn_k(x)) applied to the GEMM's A operand on the way into LDS (the bottleneck tail

@@ -209,7 +209,7 @@ static void conv_cases() {
   const ConvShape shapes[] = {{33800, 256, 1024, true, 23},  {33800, 1024, 256, false, 22}, {33800, 512, 2048, true, 3},
                               {33800, 2048, 512, false, 2},  {33800, 128, 512, true, 4},   {33800, 512, 128, false, 3},
                               {133128, 64, 256, true, 3},    {133128, 256, 128, false, 1}, {33800, 1024, 2048, false, 1},
-                              {33800, 512, 2048, false, 3}};
+                              {33800, 512, 2048, false, 3}, {32768, 256, 1024, true, 0}, {36864, 256, 1024, true, 0}};
   const float eps = 1e-5f;
   for (const ConvShape &s : shapes) {
     std::vector<float> hx, hw, hr, hm, hv, hg, hb;
@@ -306,7 +306,10 @@ extern "C" const char *lab_tn_name(int variant);
 // experiment variants of the TN GEMM core (tools/gemm_lab_kernels.hip): plain C = X W^T, main-loop decomposition and tile shapes
 static void variant_cases() {
   const ConvShape shapes[] = {{33800, 1024, 256, false, 22}, {33800, 256, 1024, false, 23}, {33800, 1024, 2048, false, 1},
-                              {33800, 512, 2048, false, 3}};
+                              {33800, 512, 2048, false, 3},
+                              // round 6: the SAME problem with a tile count that divides the chip (256 x 8 tiles of 128 x 128 = 8 per CU,
+                              // against 2120 = 8.28 per CU at M = 33800): what does tile quantisation cost?
+                              {32768, 256, 1024, false, 0}, {36864, 256, 1024, false, 0}};
   for (const ConvShape &s : shapes) {
     std::vector<float> hx, hw;
     float *x = dev_random((size_t)s.M * (s.K + 32), 1.f, &hx), *w = dev_random((size_t)s.N * (s.K + 32), 0.05f, &hw);   // (+32: the padded-stride variants)
