@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+``--gpus N`` (N > 1) WITHOUT torchrun starts its own ranks (self_launch: the same command line re-run under torch.distributed.run
+on 127.0.0.1 and a free port; fewer than N devices -> one JSON line with "error", exit code 2); under torchrun it joins the
+launcher's group.  Either way rank 0 prints the ONE line.
+
 A step = one NetModel.optimize_parameters() (kd_model.py:167-173): frozen ResNet101-PSPNet teacher
 forward + ResNet18-PSPNet student forward/backward (InPlace-ABN at every BN) + CE/Pi/Pa/Ho losses +
 SGD + discriminator step (adv + WGAN-GP) + SGD, fp32, batch 8 per GPU, synthetic 512x512 19-class
