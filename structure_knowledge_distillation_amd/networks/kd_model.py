@@ -232,6 +232,16 @@ class NetModel():
         # tensors that leave the chip idle when serialised).  SKD_D_STREAM=0 restores the serial order.
         self._d_stream = (torch.cuda.Stream(device=device, priority=-1)
                           if (os.environ.get("SKD_D_STREAM", "1") == "1" and torch.device(device).type == "cuda") else None)
+        # SKD_D_GRAPH=1 (round 6, opt-in, N = 1): the whole D step but its SGD update -- D(T), D(S), the WGAN-GP double backward,
+        # d_loss.backward() -- captured ONCE per logit shape into a hipGraph and replayed: ~1100 host launches per step become one.
+        # At N = 1 the host is ahead of the device either way (the D stream is hidden): nothing to win there;
+        # it exists for nodes where eight ranks' launch queues and RCCL's share one host -- and it stays OFF by default until such a
+        # node has shown what it buys.  N > 1: ignored (the gradient hooks of the bucketed all-reduce would have
+        # to be captured with it).
+        self._d_graph_on = (os.environ.get("SKD_D_GRAPH", "0") == "1" and torch.device(device).type == "cuda"
+                            and parallel_old.world_size() == 1)
+        self._d_graphs = {}
+        self._d_eager_steps = 0
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
         self.gp_alpha = None     # tests pin the WGAN-GP interpolation coefficients through this
         self.log_teacher_ce = False      # True: also compute the teacher's own CE (kd_model.py:129: computed and discarded) as mc_T_loss
@@ -446,20 +456,80 @@ class NetModel():
         self._s_reducer.finish()
         self._scalars["G_loss"] = G_loss.detach()
 
-    def discriminator_backward(self):
-        self.D_solver.zero_grad()
+    def _d_loss(self, logits_S, logits_T, alpha):
+        """kd_model.py:153-163 on two DETACHED logit tensors: the critic on teacher and student logits, the adversarial loss and
+        the gradient penalty (criterion.py:92-120, 146-166)."""
         args = self.args
-        d_out_T = self.parallel_D(self.preds_T[0].detach(), parallel=True)
-        d_out_S = self.parallel_D(self.preds_S[0].detach(), parallel=True)
+        d_out_T = self.parallel_D(logits_T, parallel=True)
+        d_out_S = self.parallel_D(logits_S, parallel=True)
         d_loss = args.lambda_d * self.criterion_adv(d_out_S, d_out_T, is_target_scattered=True)
         if args.adv_loss_type == "wgan-gp":
-            gp = self.criterion_AdditionalGP(self.preds_S, self.preds_T, alpha=self.gp_alpha, is_target_scattered=True)
+            gp = self.criterion_AdditionalGP([logits_S], [logits_T], alpha=alpha, is_target_scattered=True)
             d_loss = d_loss + args.lambda_d * gp
+        return d_loss
+
+    def discriminator_backward(self):
+        if self._d_graph_on and self._discriminator_backward_graphed():
+            return
+        self.D_solver.zero_grad()
+        d_loss = self._d_loss(self.preds_S[0].detach(), self.preds_T[0].detach(), self.gp_alpha)
         self._d_reducer.arm()
         d_loss.backward()
         self._d_reducer.finish()
         self._scalars["D_loss"] = d_loss.detach()
         self.D_solver.step()
+        self._d_eager_steps += 1
+
+    def _discriminator_backward_graphed(self):
+        """SKD_D_GRAPH=1: replay (after the first two eager steps: lazy handles, kernel modules and the spectral-norm caches must exist
+        before a capture) the captured D step; False = run eagerly.  The graph owns the two logit inputs, the interpolation
+        coefficients when the caller pins them (``gp_alpha``; otherwise torch.rand is part of the capture and advances the generator
+        per replay), every activation and -- because the parameters' ``.grad`` are None when the capture starts -- the gradient
+        buffers the optimizer then reads: nobody may ``zero_grad(set_to_none=True)`` the critic between steps (checked: the graph is
+        dropped and the step runs eagerly if a gradient went missing)."""
+        if self._d_eager_steps < 2:
+            return False
+        logits_S, logits_T = self.preds_S[0].detach(), self.preds_T[0].detach()
+        key = (tuple(logits_S.shape), logits_S.device.index, self.gp_alpha is not None)
+        entry = self._d_graphs.get(key)
+        if entry is None:
+            try:
+                entry = self._capture_d_step(logits_S, logits_T)
+            except Exception as e:
+                import warnings
+                warnings.warn("D-step hipGraph capture failed (%s: %s): the D step runs eagerly" % (type(e).__name__, str(e)[:300]),
+                              RuntimeWarning)
+                self._d_graph_on = False
+                torch.cuda.synchronize(logits_S.device)
+                return False
+            self._d_graphs[key] = entry
+        static_S, static_T, static_alpha, graph, d_loss, grads = entry
+        if any(p.grad is not g for p, g in zip(self._d_params, grads)):
+            self._d_graphs.clear()                  # somebody replaced / dropped the critic's gradient tensors
+            self._d_eager_steps = 0
+            return False
+        static_S.copy_(logits_S)
+        static_T.copy_(logits_T)
+        if static_alpha is not None:
+            static_alpha.copy_(self.gp_alpha)
+        graph.replay()
+        self._scalars["D_loss"] = d_loss            # static: packed for the read-back right after (same stream), overwritten next step
+        self.D_solver.step()
+        return True
+
+    def _capture_d_step(self, logits_S, logits_T):
+        dev = logits_S.device
+        static_S, static_T = logits_S.clone(), logits_T.clone()
+        static_alpha = self.gp_alpha.clone() if self.gp_alpha is not None else None
+        self.D_solver.zero_grad(set_to_none=True)   # the capture's backward CREATES the gradient tensors (graph-owned, re-written per replay)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            d_loss = self._d_loss(static_S, static_T, static_alpha)
+            d_loss.backward()
+            d_loss = d_loss.detach()
+        grads = [p.grad for p in self._d_params]
+        return static_S, static_T, static_alpha, graph, d_loss, grads
 
     def optimize_parameters(self):
         if torch.device(self.args.device).type == "cuda":

@@ -96,3 +96,82 @@ def case_teacher_hipgraph_default_mode_replays_and_follows_weight_writes():
     assert rel(got[0], want[0]) < 2e-5
     model.optimize_parameters()                           # the whole step on top of a replayed teacher
     assert all(v == v for v in (model.G_loss, model.D_loss))
+
+
+def case_d_step_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode(monkeypatch):
+    """SKD_D_GRAPH=1 (round 6, opt-in): the D step but its SGD update -- D(T), D(S), the WGAN-GP double backward, d_loss.backward() --
+    captured once into a hipGraph (third step: two eager steps first) and replayed.  Same kernels, same order: under
+    SKD_DETERMINISTIC=1 five steps (two eager, the capture step, two replays on new batches) give the same bits as the eager D step
+    in every loss and every student / discriminator tensor, with the interpolation coefficients pinned (``gp_alpha``)."""
+    monkeypatch.setenv("SKD_DETERMINISTIC", "1")
+    monkeypatch.setenv("SKD_TEACHER_GRAPH", "0")
+    try:
+        def run(flag):
+            monkeypatch.setenv("SKD_D_GRAPH", flag)
+            torch.manual_seed(99)
+            args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
+            model = NetModel(args)
+            assert model.deterministic and model._d_graph_on == (flag == "1")
+            losses = []
+            for step in range(5):
+                images, labels = O.synthetic_batch(2, 512, 512, seed=step)
+                model.gp_alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step)).to(DEV)
+                torch.manual_seed(500 + step)
+                model.adjust_learning_rate(args.lr_d, model.D_solver, step * 1000)       # the learning rate moves: the update is NOT in the graph
+                model.set_input((images, labels, None, None))
+                model.optimize_parameters()
+                losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
+            torch.cuda.synchronize()
+            assert len(model._d_graphs) == (1 if flag == "1" else 0)
+            return losses, cpu_sd(model.student), cpu_sd(model.D_model)
+
+        eager, graph = run("0"), run("1")
+        assert eager[0] == graph[0], (eager[0], graph[0])
+        for which, what in ((1, "student"), (2, "D")):
+            diff = [k for k, v in eager[which].items() if not torch.equal(v, graph[which][k])]
+            assert not diff, "%s state differs with the D step replayed from a hipGraph: %s" % (what, diff[:8])
+    finally:
+        torch.backends.cudnn.enabled = True
+        torch.use_deterministic_algorithms(False)
+
+
+def case_d_step_hipgraph_default_mode(monkeypatch):
+    """Default mode (MIOpen convolutions, D step on its own stream, torch.rand inside the capture): the graph is captured, replays give
+    finite losses that track an eager twin to rounding, and a critic whose gradients were dropped falls back to the eager step."""
+    def make(flag):
+        monkeypatch.setenv("SKD_D_GRAPH", flag)
+        torch.manual_seed(7)
+        return NetModel(default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5))
+    a, b = make("1"), make("0")
+    assert a._d_graph_on and not b._d_graph_on and a._d_stream is not None
+    for m in (a, b):
+        for mod in m.student.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0                                # the twins must see the same student
+    for step in range(5):
+        images, labels = O.synthetic_batch(2, 512, 512, seed=20 + step)
+        alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(step)).to(DEV)
+        for m in (a, b):
+            m.gp_alpha = alpha
+            torch.manual_seed(1000 + step)
+            m.set_input((images, labels, None, None))
+            m.optimize_parameters()
+        # MIOpen is not bit-reproducible and the critic's loss is a cancellation that amplifies it step by step (DESIGN.md section 10
+        # item 6: two EAGER runs drift the same way; the bit-exact statement is the deterministic case above): 1e-3 while both twins
+        # have only run eagerly / just captured, a sanity bound afterwards
+        tol = 1e-3 if step <= 2 else 5e-2
+        assert abs(a.D_loss - b.D_loss) <= tol * (abs(b.D_loss) + 1e-2), (step, a.D_loss, b.D_loss)
+        assert abs(a.G_loss - b.G_loss) <= 1e-4 * abs(b.G_loss), (step, a.G_loss, b.G_loss)
+    assert len(a._d_graphs) == 1
+    a.gp_alpha = None                                      # torch.rand inside the capture: a second graph (keyed on it), finite losses
+    for step in range(4):
+        images, labels = O.synthetic_batch(2, 512, 512, seed=40 + step)
+        a.set_input((images, labels, None, None))
+        a.optimize_parameters()
+        assert a.D_loss == a.D_loss and abs(a.D_loss) < 1e3
+    assert len(a._d_graphs) == 2
+    a.D_solver.zero_grad(set_to_none=True)                 # somebody drops the critic's gradients: the graphs go, the step runs eagerly
+    images, labels = O.synthetic_batch(2, 512, 512, seed=60)
+    a.set_input((images, labels, None, None))
+    a.optimize_parameters()
+    assert len(a._d_graphs) == 0 and a.D_loss == a.D_loss

@@ -779,6 +779,16 @@ def test_teacher_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode():
     assert rc == 0, ("timed out" if rc is None else "failed", tail)
 
 
+def test_d_step_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode():
+    rc, tail = _run_isolated("case_d_step_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode", 300)
+    assert rc == 0, tail
+
+
+def test_d_step_hipgraph_default_mode():
+    rc, tail = _run_isolated("case_d_step_hipgraph_default_mode", 300)
+    assert rc == 0, tail
+
+
 def test_teacher_hipgraph_default_mode_replays_and_follows_weight_writes():
     rc, tail = _run_isolated("case_teacher_hipgraph_default_mode_replays_and_follows_weight_writes", 300)
     assert rc == 0, ("timed out" if rc is None else "failed", tail)
