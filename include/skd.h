@@ -551,6 +551,25 @@ int skd_abn_relu_maxpool3x3s2_backward_dx_nhwc(int B, int C, int H, int W, int O
                                                const float *bias, const float *edz, const float *eydz, float *dx,
                                                float *dweight, float *dbias, float eps, int accumulate, skd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * 14. The 19-class 1x1 classifier heads (networks/pspnet_combine.py:138-154: Conv2d(mid, num_classes, 1, bias=True)) on
+ *     channels-last feature maps (round 6).  x (B*HW, K) = the feature map as it lies in memory, w (C, K) = the (C, K, 1, 1)
+ *     convolution weight, bias (C) or NULL; out / gout (B, C, HW) = logits / their gradient in the reference's NCHW layout (what the
+ *     criteria consume).  HBM-bound skinny GEMMs: the feature map is read once per direction.
+ *       forward    out[b][c][p] = bias[c] + sum_k x[b*HW + p][k] * w[c][k]
+ *       backward   gx[m][k] = sum_c gout[b][c][p] * w[c][k]   (channels-last, may be NULL)
+ *                  gw[c][k] = sum_m gout[b][c][p] * x[m][k],  gb[c] = sum_m gout[b][c][p]   (WRITTEN, may be NULL; fixed summation
+ *                  order: bit-reproducible);  workspace: skd_head1x1_backward_workspace_floats().
+ *     skd_head1x1_supported(K, C, backward): C <= 20; forward K % 128 == 0 and K <= 1024; backward K == 128.  Other heads stay
+ *     convolutions.
+ * ---------------------------------------------------------------------------------- */
+int skd_head1x1_supported(int K, int C, int backward);
+int skd_head1x1_forward_nhwc(int B, int HW, int K, int C, const float *x, const float *w, const float *bias, float *out,
+                             skd_stream_t stream);
+int64_t skd_head1x1_backward_workspace_floats(int B, int HW, int K, int C);
+int skd_head1x1_backward_nhwc(int B, int HW, int K, int C, const float *x, const float *w, const float *gout, float *gx,
+                              float *gw, float *gb, float *workspace, skd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -794,3 +794,58 @@ int skd_seg_confusion(int B, int C, int h, int w, int H, int W, const float *log
     }
   return 1;
 }
+
+/* ---- the 19-class 1x1 classifier heads on channels-last feature maps (include/skd.h section 14; networks/pspnet_combine.py:138-154):
+ *      plain loops, double accumulation ---- */
+int skd_head1x1_supported(int K, int C, int backward) {
+  if (C <= 0 || C > 20 || K <= 0) return 0;
+  return backward ? K == 128 : (K % 128 == 0 && K <= 1024);
+}
+
+int skd_head1x1_forward_nhwc(int B, int HW, int K, int C, const float *x, const float *w, const float *bias, float *out, stream_t st) {
+  (void)st;
+  if (B <= 0 || HW <= 0 || !skd_head1x1_supported(K, C, 0) || !x || !w || !out) return 0;
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int p = 0; p < HW; ++p) {
+        const float *xr = x + ((int64_t)b * HW + p) * K;
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) a += (double)xr[k] * (double)w[(int64_t)c * K + k];
+        out[((int64_t)b * C + c) * HW + p] = (float)(a + (bias ? (double)bias[c] : 0.0));
+      }
+  return 1;
+}
+
+int64_t skd_head1x1_backward_workspace_floats(int B, int HW, int K, int C) {
+  (void)B; (void)HW; (void)K; (void)C;
+  return 1;
+}
+
+int skd_head1x1_backward_nhwc(int B, int HW, int K, int C, const float *x, const float *w, const float *gout, float *gx, float *gw,
+                              float *gb, float *workspace, stream_t st) {
+  (void)st;
+  if (B <= 0 || HW <= 0 || !skd_head1x1_supported(K, C, 1) || !w || !gout || !workspace) return 0;
+  if (gw && !x) return 0;
+  const int64_t M = (int64_t)B * HW;
+  if (gx)
+    for (int64_t m = 0; m < M; ++m) {
+      const int64_t b = m / HW, p = m - b * HW;
+      for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int c = 0; c < C; ++c) a += (double)gout[(b * C + c) * HW + p] * (double)w[(int64_t)c * K + k];
+        gx[m * K + k] = (float)a;
+      }
+    }
+  for (int c = 0; c < C; ++c) {
+    double sb = 0.0;
+    for (int64_t m = 0; m < M; ++m) sb += (double)gout[((m / HW) * C + c) * HW + (m % HW)];
+    if (gb) gb[c] = (float)sb;
+    if (gw)
+      for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int64_t m = 0; m < M; ++m) a += (double)gout[((m / HW) * C + c) * HW + (m % HW)] * (double)x[m * K + k];
+        gw[(int64_t)c * K + k] = (float)a;
+      }
+  }
+  return 1;
+}

@@ -100,6 +100,10 @@ SIGNATURES = {
     "skd_ppm_fold_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P]),
     "skd_ppm_fold_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
     "skd_maxpool3x3s2_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "skd_head1x1_supported": (_I, [_I, _I, _I]),
+    "skd_head1x1_forward_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "skd_head1x1_backward_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "skd_head1x1_backward_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "skd_maxpool3x3s2_backward_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "skd_abn_relu_maxpool3x3s2_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "skd_abn_relu_maxpool3x3s2_backward_reduce_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),

@@ -404,6 +404,64 @@ def max_pool_stem(x, pool):
     return pool(x)
 
 
+class _Head1x1(Function):
+    """The 19-class 1x1 classifier head on a channels-last feature map (csrc/head.hip): logits come out in the reference's NCHW layout
+    (what the criteria and the critic consume: no layout copy), the feature gradient goes back channels-last (what the InPlace-ABN
+    backward wants: no copy either), dW / db in a fixed summation order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_device(x, weight, bias)
+        b, k, h, w = x.shape
+        c = weight.shape[0]
+        lib, st = _lib.get(), _lib.stream_of(x)
+        wt = weight.reshape(c, k)
+        wt = wt if wt.is_contiguous() else wt.contiguous()
+        out = x.new_empty((b, c, h, w))
+        _lib.check(lib.skd_head1x1_forward_nhwc(b, h * w, k, c, x.data_ptr(), wt.data_ptr(), _lib.ptr(bias), out.data_ptr(), st),
+                   "skd_head1x1_forward_nhwc")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        b, k, h, w = x.shape
+        c = weight.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
+        lib, st = _lib.get(), _lib.stream_of(x)
+        wt = weight.reshape(c, k)
+        wt = wt if wt.is_contiguous() else wt.contiguous()
+        gx = _new_cl(x, b, k, h, w) if need_x else None
+        gw = torch.empty_like(wt) if need_w else None
+        gb = x.new_empty((c,)) if need_b else None
+        ws = x.new_empty((max(1, lib.skd_head1x1_backward_workspace_floats(b, h * w, k, c)),))
+        _lib.check(lib.skd_head1x1_backward_nhwc(b, h * w, k, c, x.data_ptr(), wt.data_ptr(), g.data_ptr(), _lib.ptr(gx), _lib.ptr(gw),
+                                                 _lib.ptr(gb), ws.data_ptr(), st), "skd_head1x1_backward_nhwc")
+        return gx, (gw.view_as(weight) if gw is not None else None), gb
+
+
+def head1x1_supported(x, conv):
+    """True when csrc/head.hip takes this classifier: an fp32 channels-last input, a plain 1x1 / stride 1 / no padding / ungrouped
+    convolution with <= 20 outputs, Cin a multiple of 128 (forward) and exactly 128 when a gradient is wanted."""
+    if not (x.dtype == torch.float32 and x.dim() == 4 and _is_cl(x) and (x.is_cuda or _lib.test_backend_active())):
+        return False
+    if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.weight.dtype == torch.float32):
+        return False
+    grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad
+                                        or (conv.bias is not None and conv.bias.requires_grad))
+    return bool(_lib.get().skd_head1x1_supported(conv.in_channels, conv.out_channels, 1 if grad else 0))
+
+
+def head1x1(x, conv):
+    """``conv(x)`` for a classifier head that head1x1_supported() accepted: (B, C, H, W) logits, NCHW-contiguous."""
+    return _Head1x1.apply(x, conv.weight, conv.bias)
+
+
 def blas_1x1_bn_supported(x, conv):
     """True when conv1x1_bn_blas takes this call: an fp32 channels-last input of a frozen network (no graph) and a plain
     stride-1 1x1 convolution without bias."""

@@ -38,6 +38,8 @@ FUSED_TAIL = True     # conv2 -> [bn2 -> relu -> conv3 -> bn3 -> + residual -> r
                       # profiles/r03c_bench_ab_teacher_tail{0,1}.json: -1.1 ... -2.0 ms per step
 BLAS_TAILS = True     # the 1x1 reduce convolutions and stride-1 down-sample branches as library GEMMs with the folded BN (+ ReLU)
                       # in the epilogue (functional.conv1x1_bn_blas); profiles/r02f: 68.2 -> 66.9 ms per step
+HEAD_KERNEL = True    # the 19-class 1x1 heads as the skinny HBM-bound kernels of csrc/head.hip (NCHW logits out, channels-last feature
+                      # gradient back) instead of 41 + 123 us convolutions per student head (round 6)
 STEM_FUSED = True     # training stem: bn3 -> relu3 -> maxpool without the normalised tensor (libs.modules.forward_relu_maxpool, round 6)
 PSP_FOLD = True       # conv3x3(cat(up(priors), feats)) = conv3x3(feats) + fold(priors x W) (csrc/ppm.hip); profiles/r02d: 77.4 -> 72.2 ms
 
@@ -83,6 +85,8 @@ class ClassifierConv(nn.Conv2d):
                 and not self.transposed and tuple(self.output_padding) == (0, 0))
 
     def forward(self, x):
+        if HEAD_KERNEL and SF.head1x1_supported(x, self):
+            return SF.head1x1(x, self)
         if (self.bias is None or not self._plain()
                 or not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
             return super().forward(x)

@@ -1309,6 +1309,74 @@ def test_maxpool3x3s2_nhwc(hip, ref, geom):
     assert hip.skd_maxpool3x3s2_nhwc(B, C, H, W, OH + 1, OW, P(gpu(x)), P(yg), None, None) == 0
 
 
+@pytest.mark.parametrize("geom", [(8, 65 * 65, 128, 19), (2, 33 * 33, 128, 19), (1, 7, 128, 3), (3, 100, 128, 20), (8, 65 * 65, 512, 19), (2, 50, 1024, 11)])
+def test_head1x1(hip, ref, geom):
+    """Round 6: the 19-class 1x1 classifier heads on channels-last feature maps (skd_head1x1_forward_nhwc / _backward_nhwc; networks/
+    pspnet_combine.py:138-154) against the plain-C oracle (double accumulation): NCHW logits out, channels-last feature gradient,
+    weight / bias gradients WRITTEN in a fixed order (two runs give the same bits); ragged row counts, C not a multiple of 4."""
+    B, HW, K, C = geom
+    M = B * HW
+    g = torch.Generator().manual_seed(M + K + C)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(C, K, generator=g) / K ** 0.5, torch.randn(C, generator=g)
+    xg, wg, bg = gpu(x), gpu(w), gpu(b)
+    o_r, o_g = torch.empty(B, C, HW), torch.full((B, C, HW), float("nan"), device=DEV)
+    assert hip.skd_head1x1_supported(K, C, 0) == 1 and ref.skd_head1x1_supported(K, C, 0) == 1
+    assert ref.skd_head1x1_forward_nhwc(B, HW, K, C, P(x), P(w), P(b), P(o_r), None)
+    assert hip.skd_head1x1_forward_nhwc(B, HW, K, C, P(xg), P(wg), P(bg), P(o_g), None)
+    close(o_g, o_r, 2e-5, "head forward")
+    o_nb = torch.empty_like(o_g)
+    assert hip.skd_head1x1_forward_nhwc(B, HW, K, C, P(xg), P(wg), None, P(o_nb), None)
+    close(o_nb, o_r - b.view(1, C, 1), 2e-5, "head forward without bias", floor=float(o_r.abs().max()))
+    assert hip.skd_head1x1_forward_nhwc(B, HW, K + 64, C, P(xg), P(wg), P(bg), P(o_g), None) == 0
+    assert hip.skd_head1x1_forward_nhwc(B, HW, K, 21, P(xg), P(wg), P(bg), P(o_g), None) == 0
+    if K != 128:
+        assert hip.skd_head1x1_supported(K, C, 1) == 0
+        return
+    go = torch.randn(B, C, HW, generator=g)
+    gog = gpu(go)
+    ws = torch.empty(max(1, hip.skd_head1x1_backward_workspace_floats(B, HW, K, C)), device=DEV)
+    gx_g, gw_g, gb_g = torch.full((M, K), float("nan"), device=DEV), torch.full((C, K), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
+    gx_r, gw_r, gb_r, ws_r = torch.empty(M, K), torch.empty(C, K), torch.empty(C), torch.empty(4)
+    assert ref.skd_head1x1_backward_nhwc(B, HW, K, C, P(x), P(w), P(go), P(gx_r), P(gw_r), P(gb_r), P(ws_r), None)
+    assert hip.skd_head1x1_backward_nhwc(B, HW, K, C, P(xg), P(wg), P(gog), P(gx_g), P(gw_g), P(gb_g), P(ws), None)
+    close(gx_g, gx_r, 2e-5, "head dx")
+    close(gw_g, gw_r, 3e-5, "head dW", floor=float(M ** 0.5))
+    close(gb_g, gb_r, 3e-5, "head db", floor=float(M ** 0.5))
+    gw2, gb2 = torch.empty_like(gw_g), torch.empty_like(gb_g)
+    assert hip.skd_head1x1_backward_nhwc(B, HW, K, C, P(xg), P(wg), P(gog), None, P(gw2), P(gb2), P(ws), None)
+    assert torch.equal(gw2, gw_g) and torch.equal(gb2, gb_g), "head dW / db are not bit-reproducible"
+    gx2 = torch.empty_like(gx_g)
+    assert hip.skd_head1x1_backward_nhwc(B, HW, K, C, None, P(wg), P(gog), P(gx2), None, None, P(ws), None)      # a frozen head: dx only
+    assert torch.equal(gx2, gx_g)
+    assert hip.skd_head1x1_backward_nhwc(B, HW, K, C, None, P(wg), P(gog), None, P(gw2), None, P(ws), None) == 0   # dW needs x
+
+
+def test_classifier_head_kernel_equals_conv2d_full_size(monkeypatch):
+    """pspnet_combine.ClassifierConv with HEAD_KERNEL (csrc/head.hip) against the same module through MIOpen, at the student's size:
+    logits NCHW-contiguous, feature gradient channels-last, everything to rounding; the teacher's 512-channel head forward-only."""
+    torch.manual_seed(2)
+    head = PC_MOD.ClassifierConv(128, 19, 1, 1, 0, bias=True).to(DEV)
+    x = torch.randn(8, 128, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(8, 19, 65, 65, device=DEV)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(PC_MOD, "HEAD_KERNEL", flag)
+        head.zero_grad()
+        xa = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+        y = head(xa)
+        y.backward(g)
+        res[flag] = (y.detach(), xa.grad, head.weight.grad.clone(), head.bias.grad.clone())
+    assert res[True][0].is_contiguous() and res[True][1].is_contiguous(memory_format=torch.channels_last)
+    for a, b, name in zip(res[True], res[False], ("logits", "dx", "dW", "db")):
+        close(a, b, 3e-5, "classifier head " + name, floor=float(b.abs().max()))
+    monkeypatch.setattr(PC_MOD, "HEAD_KERNEL", True)
+    t = PC_MOD.ClassifierConv(512, 19, 1, 1, 0, bias=True).to(DEV)
+    xt = torch.randn(8, 512, 65, 65, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        close(t(xt), torch.nn.functional.conv2d(xt, t.weight, t.bias), 3e-5, "teacher head")
+        assert t(xt).is_contiguous()
+
+
 @pytest.mark.parametrize("geom", [(8, 128, 256, 256), (2, 128, 128, 96), (1, 4, 9, 12), (2, 8, 65, 33), (3, 16, 1, 2), (2, 64, 17, 64)])
 @pytest.mark.parametrize("affine", [True, False])
 def test_abn_relu_maxpool_stem(hip, ref, geom, affine):

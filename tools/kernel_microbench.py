@@ -219,6 +219,19 @@ def build_cases(lib, torch, dev, st):
             add("maxunpool_scatter_nhwc", [Bp, Cp, 65, 65, kh], lambda Bp=Bp, Cp=Cp, kh=kh, dpo=dpo, pi=pi, dxx=dxx, oh=oh:
                 lib.skd_maxunpool_scatter_nhwc(Bp, Cp, 65, 65, kh, kh, p(dpo), oh * oh, p(pi), p(dxx), st), 4 * Bp * Cp * 65 * 65 + 8 * Bp * Cp * oh * oh,
                 keep=(dpo, dxx))
+    # round 6: the 19-class 1x1 heads (csrc/head.hip): forward reads the map once, writes the logits; backward reads map + logit
+    # gradient, writes the map's gradient
+    for Bh, Kh in ((8, 128), (8, 512)):
+        hx, hwt, hb = torch.randn(Bh * 65 * 65, Kh, device=dev), torch.randn(19, Kh, device=dev) * 0.05, torch.randn(19, device=dev)
+        ho, hg = torch.empty(Bh, 19, 65 * 65, device=dev), torch.randn(Bh, 19, 65 * 65, device=dev)
+        add("head1x1_forward", [Bh, 65 * 65, Kh, 19], lambda Bh=Bh, Kh=Kh, hx=hx, hwt=hwt, hb=hb, ho=ho:
+            lib.skd_head1x1_forward_nhwc(Bh, 65 * 65, Kh, 19, p(hx), p(hwt), p(hb), p(ho), st), 4 * Bh * 65 * 65 * (Kh + 19), keep=(hx, hwt, hb, ho, hg))
+        if Kh == 128:
+            hgx, hgw, hgb = torch.empty_like(hx), torch.empty_like(hwt), torch.empty_like(hb)
+            hws = torch.empty(max(1, lib.skd_head1x1_backward_workspace_floats(Bh, 65 * 65, Kh, 19)), device=dev)
+            add("head1x1_backward", [Bh, 65 * 65, Kh, 19], lambda Bh=Bh, Kh=Kh, hx=hx, hwt=hwt, hg=hg, hgx=hgx, hgw=hgw, hgb=hgb, hws=hws:
+                lib.skd_head1x1_backward_nhwc(Bh, 65 * 65, Kh, 19, p(hx), p(hwt), p(hg), p(hgx), p(hgw), p(hgb), p(hws), st),
+                4 * Bh * 65 * 65 * (2 * Kh + 19), keep=(hgx, hgw, hgb, hws))
     # evaluation tail (csrc/evaluate.hip): 8 B label + 1 B prediction per pixel, the 129 x 257 logits from cache
     el = torch.randn(1, 19, 129, 257, device=dev)
     elab = torch.randint(0, 19, (1, 1024, 2048), device=dev)
