@@ -324,7 +324,7 @@ def warm_up_with_fallback(build, warmup, world, dev, warm_timeout_s=30.0, run_ti
     import torch.distributed as dist
     from structure_knowledge_distillation_amd import _lib
     from structure_knowledge_distillation_amd.utils import parallel as P
-    if world <= 1:
+    if not P.replicated():
         model, step = build()
         for i in range(warmup):
             step(i)
@@ -430,6 +430,9 @@ def main():
     rank, world, local = P.init_distributed()
     if world != a.gpus:
         a.gpus = world                                       # torchrun's world is authoritative
+    # the N > 1 FORM of the step: more than one rank, or SKD_DIST_SOLO=1's one-rank communicator (hardware rehearsal of the RCCL
+    # plumbing on a 1-GPU box: its line is marked "rehearsal" and measures nothing about scaling)
+    multi = P.replicated()
     if a.device == "cpu":
         # launcher rehearsal (tests/test_distributed_cpu.py): the test's sitecustomize has installed a C-ABI double; without one
         # there is nothing to run -- this package has no CPU path
@@ -468,7 +471,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -527,14 +530,14 @@ def main():
         d_stream, model._d_stream = model._d_stream, None
         if rank == 0:
             _lib.enable_kernel_timing([n for n in timed if n not in (roofline_entry, gemm_entry)])
-            if world > 1:
+            if multi:
                 P.comm_timer.enable()
                 forms0 = _lib.sync_form_counts()
         for i in range(3):
             step(a.warmup + a.steps + i)
         if rank == 0:
             recs.update(_lib.disable_kernel_timing())
-            if world > 1:
+            if multi:
                 spans = P.comm_timer.disable()
                 sa, wa = spans.get("syncabn", (0.0, 0)), spans.get("allreduce_wait", (0.0, 0))
                 sf = spans.get("syncabn_fused", (0.0, 0))
@@ -553,12 +556,12 @@ def main():
                         "note": "per step, from 3 extra untimed steps with the D step serial: time rank 0's compute stream was "
                                 "blocked in the SyncABN exchanges (incl. waiting for the slowest rank) and in GradientAllReducer.finish() waits"}
         model._d_stream = d_stream
-    if world > 1:
+    if multi:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t)
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     ms = 1e3 * el / a.steps
@@ -677,6 +680,9 @@ def main():
         line["comm"] = comm
     if a.device == "cpu":
         line["rehearsal"] = "launcher rehearsal on the C-ABI double (tests only): NOT a measurement"
+    elif multi and world == 1:
+        line["rehearsal"] = ("SKD_DIST_SOLO=1: the N > 1 form of the step (hooks, buckets, synchronised ABN over torch.distributed, eager "
+                             "teacher) on a communicator of ONE rank -- plumbing evidence, NOT a scaling measurement")
     if world == 1 and not a.no_pairwise_sweep:
         line["pairwise_gram_mfma"] = pairwise_sweep(dev)
     if not a.no_cpu_baseline and world == 1:
@@ -708,7 +714,7 @@ def main():
             model.teacher.skip_dsn = keep
             model._teacher_graphs.clear()
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -65,6 +65,20 @@ def _group_size(group):
     return dist.get_world_size(group)
 
 
+def _replicated(group):
+    """The synchronised form applies: a group of more than one rank (or of one rank under utils.parallel.solo_rehearsal)."""
+    if group is None:
+        return False
+    from ..utils import parallel
+    return parallel.replicated(group)
+
+
+def _default_group():
+    """The default process group when the layer has to synchronise over it, else None."""
+    from ..utils import parallel
+    return dist.group.WORLD if parallel.replicated() else None
+
+
 def combine_replica_stats(gathered):
     """gathered: (G, 2, C) per-rank [mean, var] -> combined (mean, var).
 
@@ -286,7 +300,7 @@ class _InPlaceABN(autograd.Function):
         ctx.eps = float(eps)
         ctx.act = _act_code(activation)
         ctx.slope = float(slope)
-        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        ctx.group = group if _replicated(group) else None
         if x.dim() < 2:
             raise ValueError("InPlaceABN expects (N, C, ...) input")
         _check_contiguous(weight, bias, running_mean, running_var)
@@ -405,7 +419,7 @@ class _ABNRelu(autograd.Function):
             raise TypeError("InPlaceABN kernels are fp32 only (got %s)" % x.dtype)
         _check_contiguous(weight, bias, running_mean, running_var)
         ctx.eps = float(eps)
-        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        ctx.group = group if _replicated(group) else None
         geo = _Geom(x)
         c = geo.c
         lib, st = _lib.get(), _lib.stream_of(x)
@@ -529,8 +543,8 @@ def abn_relu_train(x, weight, bias, running_mean, running_var, residual=None, mo
     torch.distributed is initialised) like InPlaceABNSync; False = this replica only (InPlaceABN)."""
     if not sync:
         group = None
-    elif group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        group = dist.group.WORLD
+    elif group is None:
+        group = _default_group()
     if _nhwc_unsupported(x):
         return _via_nchw(lambda xc, r=None: _ABNRelu.apply(xc, weight, bias, running_mean, running_var, r, momentum, eps, group),
                          x, residual=residual)
@@ -553,7 +567,7 @@ class _ABNReluMaxPool(autograd.Function):
             raise TypeError("abn_relu_maxpool_train: channels-last fp32 tensors only")
         _check_contiguous(weight, bias, running_mean, running_var)
         ctx.eps = float(eps)
-        ctx.group = group if (group is not None and _group_size(group) > 1) else None
+        ctx.group = group if _replicated(group) else None
         geo = _Geom(x)
         c = geo.c
         b, _, h, w = x.shape
@@ -614,8 +628,8 @@ def abn_relu_maxpool_train(x, weight, bias, running_mean, running_var, oh, ow, m
     caller's pool has it), with the running-statistics update: the training stem in two fused passes per direction."""
     if not sync:
         group = None
-    elif group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        group = dist.group.WORLD
+    elif group is None:
+        group = _default_group()
     return _ABNReluMaxPool.apply(x, weight, bias, running_mean, running_var, int(oh), int(ow), momentum, eps, group)
 
 
@@ -698,8 +712,8 @@ def inplace_abn_sync(x, weight, bias, running_mean, running_var, extra=None, tra
         group = extra.get("group")
     elif extra is not None:
         group = extra
-    if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        group = dist.group.WORLD
+    if group is None:
+        group = _default_group()
     if _nhwc_unsupported(x):
         return _via_nchw(lambda xc: _InPlaceABN.apply(xc, weight, bias, running_mean, running_var, training, momentum, eps,
                                                       activation, slope, group), x, inplace=True)

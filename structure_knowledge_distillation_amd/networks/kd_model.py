@@ -222,7 +222,7 @@ class NetModel():
         # 1.2 %, and the failure mode is two orders of magnitude: the default for N > 1 stays the eager teacher.
         graph_env = os.environ.get("SKD_TEACHER_GRAPH", "1")
         self._teacher_graph_on = (graph_env in ("1", "force") and torch.device(device).type == "cuda"
-                                  and (parallel_old.world_size() == 1 or graph_env == "force")
+                                  and (not parallel_old.replicated() or graph_env == "force")
                                   and not self.deterministic_no_graph())
         self._teacher_graphs = {}
         self._teacher_tensors = list(teacher.parameters()) + list(teacher.buffers())
@@ -239,7 +239,7 @@ class NetModel():
         # node has shown what it buys.  N > 1: ignored (the gradient hooks of the bucketed all-reduce would have
         # to be captured with it).
         self._d_graph_on = (os.environ.get("SKD_D_GRAPH", "0") == "1" and torch.device(device).type == "cuda"
-                            and parallel_old.world_size() == 1)
+                            and not parallel_old.replicated())
         self._d_graphs = {}
         self._d_eager_steps = 0
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
@@ -600,7 +600,7 @@ class NetModel():
         if parallel_old.rank() == 0:
             torch.save(self.student.state_dict(),
                        osp.join(self.args.snapshot_dir, "CS_scenes_" + str(step) + "_" + str(mean_IU) + ".pth"))
-        if parallel_old.world_size() > 1:
+        if parallel_old.replicated():
             torch.distributed.barrier()
 
 

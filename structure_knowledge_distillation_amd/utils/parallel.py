@@ -23,13 +23,14 @@ import torch.distributed as dist
 import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
-           "init_distributed", "world_size", "rank", "broadcast_module", "per_rank_batch", "set_replica_batch",
+           "init_distributed", "world_size", "rank", "replicated", "solo_rehearsal", "broadcast_module", "per_rank_batch", "set_replica_batch",
            "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity", "reserve_for_collectives", "reserved_fused_cap", "sync_fused_over_rccl", "comm_form"]
 
 
 def init_distributed(backend=None):
     """Join the process group described by torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for WORLD_SIZE <= 1."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank); a no-op for WORLD_SIZE <= 1 (unless SKD_DIST_SOLO=1:
+    ``solo_rehearsal``)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,7 +39,7 @@ def init_distributed(backend=None):
         torch.cuda.set_device(local % ndev)   # more ranks than GPUs: ranks share devices
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
         share_device(-(-local_world // ndev))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or solo_rehearsal()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -101,7 +102,7 @@ def set_sync_fused(on):
 
 def comm_form(group=None):
     """How the cross-replica InPlace-ABN statistics travel right now -- what bench.py prints as ``comm.form``."""
-    if world_size(group) <= 1:
+    if not replicated(group):
         return "single rank"
     if not SyncMailbox.active():
         return "torch.distributed all_gather / all_reduce per exchange (SKD_SYNC_IPC=0 or the mailbox self-test failed)"
@@ -170,6 +171,23 @@ def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def solo_rehearsal():
+    """SKD_DIST_SOLO=1 (hardware rehearsal, never a training configuration): a process group of ONE rank runs the N > 1 FORM of the
+    step -- replica broadcast, gradient hooks + bucketed asynchronous all-reduce, synchronised InPlace-ABN over torch.distributed
+    collectives, eager teacher, sharded evaluation -- so that a 1-GPU box exercises that control flow on backend "nccl" (RCCL
+    communicator, ProcessGroupNCCL's streams and events, device-side verdict tensors).  A communicator of one rank moves no data
+    between devices: the numbers of such a run say nothing about scaling (bench.py marks its line "rehearsal")."""
+    return os.environ.get("SKD_DIST_SOLO", "0") == "1"
+
+
+def replicated(group=None):
+    """True when the step must take its multi-replica form: more than one rank in the group, or an initialised group of one rank
+    under ``solo_rehearsal``."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or solo_rehearsal()
+
+
 def rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
@@ -196,7 +214,7 @@ def set_replica_batch(local_batch, device, group=None):
     statistics: the LOSS stays the reference's plain mean over replicas of the per-replica losses (Reduce / len(outputs),
     utils/parallel.py:155), so GradientAllReducer averages with 1 / G whatever the shard sizes -- for ragged shards that
     is the reference's own weighting of the samples, not a sample-uniform one.  Valid until ``clear_replica_batch``."""
-    if world_size(group) <= 1:
+    if not replicated(group):
         _REPLICA["weights"] = None
         return None
     mine = torch.tensor([float(local_batch)], device=device)
@@ -287,7 +305,9 @@ class SyncMailbox:
         w = world_size(group)
         on_gpu = torch.device(device).type == "cuda"
         # (CPU tensors only with the tests' C-ABI double installed: its mailboxes are POSIX shared memory, oracle/sync_ref.c)
-        if w <= 1 or w > 16 or os.environ.get("SKD_SYNC_IPC", "1") != "1" or not (on_gpu or _lib.test_backend_active()):
+        # (a group of ONE rank under solo_rehearsal gets a mailbox too: it has no peer to open, and its exchanges run the same kernels)
+        if (not replicated(group) or w > 16 or os.environ.get("SKD_SYNC_IPC", "1") != "1"
+                or not (on_gpu or _lib.test_backend_active())):
             return None
         lib = _lib.get()
         rk = dist.get_rank(group)
@@ -341,7 +361,7 @@ class SyncMailbox:
 
 def broadcast_module(module, src=0, group=None):
     """Make every replica bit-identical to rank ``src`` once, at construction."""
-    if world_size(group) <= 1:
+    if not replicated(group):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -402,7 +422,7 @@ comm_timer = CommTimer()
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "pending", "work", "offsets")
+    __slots__ = ("params", "flat", "pending", "work", "offsets", "views", "avg")
 
 
 class GradientAllReducer:
@@ -420,6 +440,7 @@ class GradientAllReducer:
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size(group)
+        self.active = replicated(group)        # world > 1 (or the one-rank rehearsal: same hooks, same buckets, same waits)
         self.armed = False
         self.buckets = []
         self._bucket_of = {}
@@ -433,7 +454,7 @@ class GradientAllReducer:
         if cur:
             self._close(cur)
         self._handles = []
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -443,9 +464,18 @@ class GradientAllReducer:
         n = sum(p.numel() for p in plist)
         b.flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         b.offsets = []
+        b.views = []
         o = 0
         for p in plist:
             b.offsets.append(o)
+            # The segment is laid out in the PARAMETER's memory order (a channels-last weight stays channels-last): the gradient
+            # autograd hands over has those strides, so the pack is ONE multi-tensor copy per bucket (torch._foreach_copy_'s fast
+            # route needs equal strides), the averaged segment can BE p.grad afterwards (no unpack), and the fused SGD update sees
+            # a gradient laid out like its parameter.  Every replica builds the same model, hence the same element order.
+            if p.dim() > 1 and _dense_like(p):
+                b.views.append(b.flat[o:o + p.numel()].as_strided(p.shape, p.stride()))
+            else:
+                b.views.append(b.flat[o:o + p.numel()].view(p.shape))
             o += p.numel()
         b.pending = len(plist)
         b.work = None
@@ -471,21 +501,24 @@ class GradientAllReducer:
     def _launch(self, b):
         with torch.no_grad():
             dsts, srcs = [], []
-            for p, o in zip(b.params, b.offsets):
-                seg = b.flat[o:o + p.numel()]
+            for p, v in zip(b.params, b.views):
                 if p.grad is None:
-                    seg.zero_()
-                else:
-                    dsts.append(seg.view(p.shape))      # logical (N, C, H, W) order whatever the grad's strides
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():      # (a gradient that already IS its segment: zero_grad(set_to_none=False))
+                    dsts.append(v)
                     srcs.append(p.grad)
             if dsts:
-                torch._foreach_copy_(dsts, srcs)         # one multi-tensor launch per bucket, not one per parameter
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                torch._foreach_copy_(dsts, srcs)         # one multi-tensor launch per bucket where the strides agree
+        # RCCL averages in the collective (ncclAvg); gloo has no AVG: sum, then one scaling pass per bucket in finish()
+        b.avg = _backend_has_avg(self.group) and b.flat.is_cuda
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if b.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for the in-flight buckets, launch any bucket whose parameters did not all receive a
-        gradient (same set on every rank), write the averages back into ``p.grad``."""
-        if self.world <= 1 or not self.armed:
+        gradient (same set on every rank), and make the averages the parameters' ``.grad``: each ``p.grad`` becomes the
+        parameter's segment of the bucket (a view with the parameter's own strides -- no copy back; the next
+        ``zero_grad()`` drops it, the next backward produces a fresh gradient that is packed again)."""
+        if not self.active or not self.armed:
             self.armed = False
             return
         for b in self.buckets:
@@ -497,19 +530,33 @@ class GradientAllReducer:
                 tok = comm_timer.begin("allreduce_wait", b.flat)
                 b.work.wait()
                 comm_timer.end(tok)
-                b.flat.mul_(inv)
-                dsts, srcs = [], []
-                for p, o in zip(b.params, b.offsets):
-                    seg = b.flat[o:o + p.numel()].view(p.shape)
-                    if p.grad is None:
-                        p.grad = seg.clone()
-                    else:
-                        dsts.append(p.grad)
-                        srcs.append(seg)
-                if dsts:
-                    torch._foreach_copy_(dsts, srcs)
+                if not b.avg and self.world > 1:
+                    b.flat.mul_(inv)
+                for p, v in zip(b.params, b.views):
+                    p.grad = v
                 b.work = None
         self.armed = False
+
+
+def _dense_like(p):
+    """True when ``p`` is non-overlapping and dense (some permutation of a contiguous tensor): its strides can be copied onto a flat
+    segment of numel() elements."""
+    if p.is_contiguous():
+        return True
+    sizes_strides = sorted(((st, sz) for sz, st in zip(p.shape, p.stride()) if sz > 1))
+    expect = 1
+    for st, sz in sizes_strides:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def _backend_has_avg(group=None):
+    try:
+        return dist.get_backend(group) == "nccl"
+    except Exception:
+        return False
 
 
 class DataParallelModel(nn.Module):

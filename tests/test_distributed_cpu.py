@@ -674,3 +674,65 @@ def test_bench_gpus_8_on_a_box_without_gpus_fails_with_a_device_count_message():
     assert p.returncode == 2
     assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 8
     assert "GPU(s) visible" in lines[0]["error"] and "torchrun" not in lines[0]["error"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# SKD_DIST_SOLO=1 (utils.parallel.solo_rehearsal): a process group of ONE rank takes the N > 1 form of the step -- what a 1-GPU box
+# runs over RCCL to show the plumbing (tools/gpu_session.sh solo).  Here: gloo + the C double.
+def _solo(rank, world):
+    from structure_knowledge_distillation_amd import libs
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    assert world == 1 and P.world_size() == 1 and P.replicated() and P.comm_form() != "single rank"
+    out = _reducer(rank, world)
+    params = [torch.nn.Parameter(torch.randn(4))]
+    red = P.GradientAllReducer(params)
+    assert red.active and len(red._handles) == 1            # the hooks are registered: the bucketed asynchronous form runs
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 6, 5, 3, generator=g) * 2 + 1
+    gz = torch.randn(4, 6, 5, 3, generator=g)
+    res = {}
+    for name, cls in (("sync", libs.InPlaceABNSync), ("plain", libs.InPlaceABN)):
+        mod = cls(6, activation="leaky_relu").train()
+        xs = x.clone().requires_grad_(True)
+        P.comm_timer.enable()
+        z = mod(xs * 1.0)
+        (z * gz).sum().backward()
+        spans = P.comm_timer.disable()
+        res[name] = (z.detach(), xs.grad, mod.weight.grad, mod.bias.grad, mod.running_mean.clone(), mod.running_var.clone(),
+                     spans.get("syncabn", (0.0, 0))[1])
+    out["abn"] = res
+    return out
+
+
+def test_solo_rehearsal_group_of_one_takes_the_replicated_form(monkeypatch):
+    monkeypatch.setenv("SKD_DIST_SOLO", "1")
+    out = _run("_solo", world=1)[0]
+    for i, g in enumerate(out["avg"]):                      # the one-rank average is the rank's own gradient
+        assert torch.allclose(g, torch.full_like(g, 0.0 if i == 2 else float(i + 1)))
+    sync, plain = out["abn"]["sync"], out["abn"]["plain"]
+    assert sync[6] == 2 and plain[6] == 0                   # the synchronised layer DID exchange (forward + backward), the plain one not
+    for a, b in zip(sync[:6], plain[:6]):                   # and a group of one changes nothing
+        assert rel(a, b) < 1e-6
+
+
+def test_without_the_switch_a_group_of_one_is_a_single_rank(monkeypatch):
+    monkeypatch.delenv("SKD_DIST_SOLO", raising=False)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert not P.replicated() and P.comm_form() == "single rank"
+        assert not P.GradientAllReducer([torch.nn.Parameter(torch.zeros(3))]).active
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_bench_solo_rehearsal_prints_a_line_marked_as_rehearsal():
+    p, lines = _launch_bench(["--gpus", "1", "--device", "cpu", "--size", "256", "--batch", "1", "--losses", "pi,pa",
+                              "--steps", "2", "--warmup", "1"], env_extra={"SKD_DIST_SOLO": "1", "SKD_DIST_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["comm"]["ranks"] == 1 and line["comm"]["backend"] == "gloo" and "rehearsal" in line
+    assert line["comm"]["form"] != "single rank" and line["comm"]["fallback_reason"] is None

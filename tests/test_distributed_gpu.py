@@ -1031,3 +1031,60 @@ def _check_multi_gpu_step(outs, world):
             for k, ref in fx["shard_losses"][r].items():
                 got = outs[r]["losses"][0][k]
                 assert abs(got - ref) <= 1e-4 * abs(ref), (r, k, got, ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# RCCL on ONE GPU: a communicator of one rank under SKD_DIST_SOLO=1 (utils.parallel.solo_rehearsal) runs the N > 1 FORM of the step
+# -- replica broadcast, gradient hooks + bucketed asynchronous all-reduce, synchronised InPlace-ABN over torch.distributed
+# collectives, eager teacher -- on backend "nccl".  No data crosses a link, but ncclCommInitRank, ProcessGroupNCCL's stream / event
+# plumbing and every device-side verdict tensor of that control flow do run on hardware; the result must be the single-rank step's.
+def _worker_solo(rank, world, port, outdir, solo):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SKD_DIST_BACKEND"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIOPEN_LOG_LEVEL="3", SKD_DIST_SOLO="1" if solo else "0")
+    torch.set_num_threads(4)
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    P.init_distributed()
+    if solo:
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1 and P.replicated()
+    else:
+        assert not dist.is_initialized() and not P.replicated()
+    try:
+        out = _multi_gpu_step(0, 1)
+        out["form"] = P.comm_form()
+        torch.save(out, os.path.join(outdir, "solo%d.pt" % int(solo)))
+    finally:
+        if solo:
+            dist.destroy_process_group()
+
+
+def test_solo_rccl_group_of_one_netmodel_steps_equal_the_single_rank_steps():
+    with tempfile.TemporaryDirectory() as d:
+        for solo in (True, False):
+            mp.spawn(_worker_solo, args=(1, _free_port(), d, solo), nprocs=1, join=True)
+        a = torch.load(os.path.join(d, "solo1.pt"))
+        b = torch.load(os.path.join(d, "solo0.pt"))
+    assert a["form"].startswith("ipc mailboxes, three launches") and b["form"] == "single rank"     # the default form over RCCL
+    assert not any(a["status"]) and not any(b["status"])
+    for step in range(2):
+        # (the second step runs on weights updated from default-mode gradients -- MIOpen's atomic split-K sums -- which two runs of
+        # the SAME form do not reproduce bit for bit either: the tiny pair-wise term moves by ~1e-4 of itself there)
+        tol = 1e-4 if step == 0 else 2e-3
+        for k in ("mc_G_loss", "pi_G_loss", "pa_G_loss", "G_loss"):
+            assert abs(a["losses"][step][k] - b["losses"][step][k]) <= tol * abs(b["losses"][step][k]), (step, k, a["losses"], b["losses"])
+        assert abs(a["losses"][step]["D_loss"] - b["losses"][step]["D_loss"]) <= 1e-3 * max(1.0, abs(b["losses"][step]["D_loss"]))
+    diffs = sorted(((rel(a["after"][k], b["after"][k]), k) for k in a["after"]
+                    if a["after"][k].dtype.is_floating_point and a["after"][k].numel() > 1), reverse=True)
+    print("solo RCCL vs single rank, student state after two steps: worst relative differences %s"
+          % [("%.2e" % d, k) for d, k in diffs[:4]])
+    # NOT a rounding-level comparison, and it cannot be one: the step's gradients are conditioned at the 1e-3 level in fp32 (the
+    # gradient tests' `base`: the fp32 CPU oracle itself sits 3.6e-3 from the fp64 one on the stem's tensors), and the synchronised
+    # ABN passes sum in another order than the single-rank ones -- tests/diagnostics/diag_solo_vs_plain.py: every form of the
+    # exchange lands 3.6e-3 ... 5.3e-3 from the single-rank gradients in step 0 while two single-rank runs agree to 3e-6.  The
+    # accuracy of the N > 1 form is established against the fp64 oracle by the two- and eight-rank tests above; this test is about
+    # the RCCL plumbing producing THE SAME STEP.  The BN shifts start at zero in front of another training-mode BN (exact gradient
+    # ~ 0): what they accumulate is that noise itself.
+    for d, k in diffs:
+        noise = a["after"][k].dim() == 1 and not k.split(".")[-1].startswith("running")
+        assert d < (0.25 if noise else 1e-2), (k, d)

@@ -2,7 +2,7 @@
 # One GPU-box session (gpurun): every section writes under gpurun_out/<tag>/ and is bounded by its own timeout.
 #   tools/gpu_session.sh <tag> <section> [<section> ...]
 # sections: tests_all | tests_r5a | tests_r5b | tests_dist | world8 | smoke | bench | bench_quick | bench_prof | timeline | micro | micro_prof |
-#           pmc | pmc2 | conv | lab | lab_pmc | det | dstep | fused_ab | dist | dist_ab | scale8   (A/B sections of switches that
+#           pmc | pmc2 | conv | lab | lab_pmc | det | dstep | fused_ab | dist | dist_ab | scale8 | solo   (A/B sections of switches that
 #           no longer exist were removed in round 5; their verdicts are under profiles/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -145,15 +145,16 @@ PYEOF
       python tools/summarise_pmc.py $O/pmc_summary.json $O/pmc1.log $O/pmc1 $O/pmc2 $O/pmc3 $O/pmc4 >> $O/session.log 2>&1
       stamp "pmc2 summarised" ;;
     timeline)
+      # (TL_ENV="SKD_DIST_SOLO=1" TL_NAME=_solo: the same trace of the N > 1 form on a one-rank communicator)
       # ONE kernel trace of the default step (teacher = hipGraph replay, D step on its stream; no HIP-event bracketing) -> per-stream
       # busy / idle, main-stream gaps, exposed D tail (tools/timeline.py); the slimmed per-dispatch trace travels back for re-analysis
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof_timeline -o bench -- \
+      (cd /tmp && env $TL_ENV timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof_timeline -o bench -- \
         python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing > $O/prof_timeline.log 2>&1)
       stamp "timeline trace rc=$?"
       T=$(find $O/prof_timeline -name "*kernel_trace.csv" | head -1)
-      python tools/timeline.py $T $O/timeline.md >> $O/session.log 2>&1
+      python tools/timeline.py $T $O/timeline${TL_NAME}.md >> $O/session.log 2>&1
       stamp "timeline rc=$?"
-      python - "$T" "$O/timeline_trace_slim.csv" <<'PYEOF'
+      python - "$T" "$O/timeline${TL_NAME}_trace_slim.csv" <<'PYEOF'
 import csv, sys
 rd = csv.DictReader(open(sys.argv[1], newline=""))
 cols = [c for c in ("Queue_Id", "Stream_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size_X", "Workgroup_Size_X", "Grid_Size", "Workgroup_Size") if c in rd.fieldnames]
@@ -212,6 +213,56 @@ for l in sys.stdin:
     d = json.loads(l); print('   %.1f img/s %.2f ms/step comm=%s' % (d['value'], d['ms_per_step'], json.dumps(d.get('comm'))[:600]))" | tee -a $O/session.log
         done
       fi ;;
+    solo)
+      # RCCL on a 1-GPU box: the probe (communicator + every collective the step uses), then the N > 1 FORM of the step on a
+      # communicator of ONE rank (SKD_DIST_SOLO=1: hooks, buckets, synchronised ABN over torch.distributed, eager teacher) under
+      # torchrun AND self-launched, with a kernel trace that shows which RCCL kernels ran
+      (timeout 200 python tools/rccl_probe.py) > $O/rccl_probe.json 2> $O/rccl_probe.err
+      stamp "rccl_probe rc=$?"; cat $O/rccl_probe.json | tee -a $O/session.log
+      (SKD_DIST_SOLO=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+        bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep) > $O/bench_solo_rccl.json 2> $O/bench_solo_rccl.err
+      stamp "bench solo (torchrun, RCCL, one rank) rc=$?"; cut -c1-900 $O/bench_solo_rccl.json | tee -a $O/session.log
+      python - $O/bench_solo_rccl.json <<'EOF' | tee -a $O/session.log
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print("   comm:", json.dumps(d.get("comm")))
+    print("   rehearsal:", d.get("rehearsal"))
+except Exception as e:
+    print("   no line:", e)
+EOF
+      (timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > $O/bench_solo_ref_n1.json 2> $O/bench_solo_ref_n1.err
+      stamp "bench N = 1 (plain, same box) rc=$?"; cut -c1-300 $O/bench_solo_ref_n1.json | tee -a $O/session.log
+      (SKD_DIST_SOLO=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > $O/bench_solo_direct.json 2> $O/bench_solo_direct.err
+      stamp "bench solo (started directly, no torchrun) rc=$?"; cut -c1-300 $O/bench_solo_direct.json | tee -a $O/session.log
+      (cd /tmp && SKD_DIST_SOLO=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_solo -o solo -- \
+        python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing > $O/prof_solo.log 2>&1)
+      stamp "solo kernel trace rc=$?"
+      for f in $(find $O/prof_solo -name "*kernel_stats.csv"); do grep -i "nccl\|rccl" $f | cut -c1-200 | tee -a $O/session.log; cp $f $O/solo_kernel_stats.csv; done
+      rm -rf $O/prof_solo
+      timeout 600 python -m pytest tests/test_distributed_gpu.py -m gpu -q --tb=short -s -k "solo" > $O/pytest_solo.log 2>&1
+      stamp "tests solo rc=$?"; tail -5 $O/pytest_solo.log | tee -a $O/session.log ;;
+    solo_ab)
+      # what the N > 1 FORM of the step costs on ONE GPU with nothing on the wire (SKD_DIST_SOLO=1, RCCL communicator of one rank):
+      # the software overhead data parallelism adds to every rank before any link is involved.  Interleaved, two rounds.
+      for rep in 1 2; do
+        i=0
+        for v in "SKD_DIST_SOLO=0" "SKD_DIST_SOLO=1" "SKD_DIST_SOLO=1 SKD_ABN_SYNC_FUSED=1" "SKD_DIST_SOLO=1 SKD_SYNC_IPC=0" \
+                 "SKD_DIST_SOLO=1 SKD_TEACHER_GRAPH=force" "SKD_DIST_SOLO=1 SKD_ABN_SYNC_FUSED=1 SKD_TEACHER_GRAPH=force" $SOLO_AB_EXTRA; do
+          i=$((i+1))
+          f=$O/solo_ab_${i}_$rep.json
+          (env $v timeout 300 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > $f 2>> $O/solo_ab.err
+          python - "$f" "$v" <<'EOF' | tee -a $O/session.log
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print("   [%s] %.3f ms/step  %.2f img/s  form: %s" % (sys.argv[2], d["ms_per_step"], d["value"], (d.get("comm") or {}).get("form", "single rank")[:70]))
+except Exception as e:
+    print("   [%s] no line: %s" % (sys.argv[2], e))
+EOF
+        done
+      done
+      stamp "solo_ab done" ;;
     selflaunch)
       # round 6: `python bench.py --gpus 2` WITHOUT torchrun (the driver's command form): bench.self_launch starts the ranks itself.
       # On a 1-GPU box the two ranks share the device over gloo (SKD_DIST_BACKEND=gloo); without that switch the same command must
