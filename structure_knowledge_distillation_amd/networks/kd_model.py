@@ -232,14 +232,14 @@ class NetModel():
         # tensors that leave the chip idle when serialised).  SKD_D_STREAM=0 restores the serial order.
         self._d_stream = (torch.cuda.Stream(device=device, priority=-1)
                           if (os.environ.get("SKD_D_STREAM", "1") == "1" and torch.device(device).type == "cuda") else None)
-        # SKD_D_GRAPH=1 (round 6, opt-in, N = 1): the whole D step but its SGD update -- D(T), D(S), the WGAN-GP double backward,
+        # SKD_D_GRAPH=1 (round 6, opt-in): the whole D step but its SGD update -- D(T), D(S), the WGAN-GP double backward,
         # d_loss.backward() -- captured ONCE per logit shape into a hipGraph and replayed: ~1100 host launches per step become one.
-        # At N = 1 the host is ahead of the device either way (the D stream is hidden): nothing to win there;
-        # it exists for nodes where eight ranks' launch queues and RCCL's share one host -- and it stays OFF by default until such a
-        # node has shown what it buys.  N > 1: ignored (the gradient hooks of the bucketed all-reduce would have
-        # to be captured with it).
-        self._d_graph_on = (os.environ.get("SKD_D_GRAPH", "0") == "1" and torch.device(device).type == "cuda"
-                            and not parallel_old.replicated())
+        # At N = 1 the host is ahead of the device either way (the D stream is hidden): nothing to win there.
+        # N > 1: the capture holds NO collective -- the reducer's hooks are not armed inside it; the critic's gradients (12.8 MB) are
+        # packed and all-reduced in one go after the replay, on the D stream, before the update (the eager form overlaps them with
+        # D's backward; both sit beside the student's backbone backward).  Not with ranks SHARING a device (the two-process tests:
+        # graph launches and a co-tenant's in-kernel waits do not co-schedule, profiles/r04h_two_ranks_one_gpu_bisect.txt).
+        self._d_graph_on = os.environ.get("SKD_D_GRAPH", "0") == "1" and torch.device(device).type == "cuda"
         self._d_graphs = {}
         self._d_eager_steps = 0
         self._scalars = {"mc_G_loss": 0.0, "pi_G_loss": 0.0, "pa_G_loss": 0.0, "G_loss": 0.0, "D_loss": 0.0, "mc_T_loss": 0.0}
@@ -469,7 +469,7 @@ class NetModel():
         return d_loss
 
     def discriminator_backward(self):
-        if self._d_graph_on and self._discriminator_backward_graphed():
+        if self._d_graph_on and parallel_old.ranks_on_this_device() <= 1 and self._discriminator_backward_graphed():
             return
         self.D_solver.zero_grad()
         d_loss = self._d_loss(self.preds_S[0].detach(), self.preds_T[0].detach(), self.gp_alpha)
@@ -514,7 +514,15 @@ class NetModel():
             static_alpha.copy_(self.gp_alpha)
         graph.replay()
         self._scalars["D_loss"] = d_loss            # static: packed for the read-back right after (same stream), overwritten next step
+        if self._d_reducer.active:
+            # N > 1: average the graph's gradient buffers over the replicas (one pack + all-reduce per bucket, nothing overlapped: the
+            # D stream is off the critical path); finish() leaves p.grad pointing at the averaged bucket segments for the update
+            self._d_reducer.arm()
+            self._d_reducer.finish()
         self.D_solver.step()
+        if self._d_reducer.active:
+            for p, g in zip(self._d_params, grads):
+                p.grad = g                          # the graph's own buffers again (their identity is checked before every replay)
         return True
 
     def _capture_d_step(self, logits_S, logits_T):

@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 __all__ = ["DataParallelModel", "my_DataParallelCriterion", "DataParallelCriterion", "GradientAllReducer",
-           "init_distributed", "world_size", "rank", "replicated", "solo_rehearsal", "broadcast_module", "per_rank_batch", "set_replica_batch",
+           "init_distributed", "world_size", "rank", "replicated", "solo_rehearsal", "ranks_on_this_device", "broadcast_module", "per_rank_batch", "set_replica_batch",
            "clear_replica_batch", "replica_weights", "SyncMailbox", "device_identity", "reserve_for_collectives", "reserved_fused_cap", "sync_fused_over_rccl", "comm_form"]
 
 
@@ -112,10 +112,20 @@ def comm_form(group=None):
     return "ipc mailboxes, three launches per pass: statistics / one-workgroup exchange kernel / normalise (csrc/sync.hip)"
 
 
+_SHARED = {"ranks": 1}
+
+
+def ranks_on_this_device():
+    """How many ranks of this job run on this process's GPU (1 in production; > 1 only in the two-process tests and
+    ``bench.py --gpus N`` on a box with fewer devices): what ``share_device`` was last told."""
+    return _SHARED["ranks"]
+
+
 def share_device(ranks_per_device):
     """Ranks that share ONE device (tests, bench.py --gpus N on a 1-GPU box) must share its compute units: the one-launch
     InPlace-ABN passes hold a grid barrier (and, synchronised, wait for the PEER's launch inside it), so every rank's grid
     is capped at its share -- include/skd.h section 13.  One rank per device (production): no cap beyond the device's own."""
+    _SHARED["ranks"] = max(_SHARED["ranks"], int(ranks_per_device))
     if ranks_per_device <= 1 or not torch.cuda.is_available():
         return None
     from .. import _lib
@@ -204,6 +214,7 @@ def per_rank_batch(global_batch, group=None):
 
 
 _REPLICA = {"weights": None, "key": None}
+_REPLICA_BUF = {}
 
 
 def set_replica_batch(local_batch, device, group=None):
@@ -217,8 +228,15 @@ def set_replica_batch(local_batch, device, group=None):
     if not replicated(group):
         _REPLICA["weights"] = None
         return None
-    mine = torch.tensor([float(local_batch)], device=device)
-    counts = torch.empty(world_size(group), device=device)
+    # No host-to-device copy (a pageable one synchronises the stream: measured on the one-rank rehearsal as ~0.7 ms of main-stream
+    # gaps at every step start, profiles/r08f_timeline_solo.md): a persistent one-float buffer filled by a launch
+    w = world_size(group)
+    key = (str(torch.device(device)), w)
+    mine = _REPLICA_BUF.get(key)
+    if mine is None:
+        mine = _REPLICA_BUF[key] = torch.empty(1, device=device)
+    mine.fill_(float(local_batch))
+    counts = torch.empty(w, device=device)
     dist.all_gather_into_tensor(counts, mine, group=group)
     _REPLICA["weights"] = counts / counts.sum()
     return _REPLICA["weights"]

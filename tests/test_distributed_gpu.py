@@ -1088,3 +1088,54 @@ def test_solo_rccl_group_of_one_netmodel_steps_equal_the_single_rank_steps():
     for d, k in diffs:
         noise = a["after"][k].dim() == 1 and not k.split(".")[-1].startswith("running")
         assert d < (0.25 if noise else 1e-2), (k, d)
+
+
+def _worker_solo_d_graph(rank, world, port, outdir, flag):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SKD_DIST_BACKEND"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIOPEN_LOG_LEVEL="3", SKD_DIST_SOLO="1", SKD_DETERMINISTIC="1",
+                      SKD_TEACHER_GRAPH="0", SKD_D_GRAPH=flag)
+    torch.set_num_threads(4)
+    from structure_knowledge_distillation_amd.utils import parallel as P
+    from structure_knowledge_distillation_amd.networks.kd_model import NetModel, default_args
+    from oracle import step_torch as O
+    P.init_distributed()
+    assert dist.get_backend() == "nccl" and P.replicated()
+    try:
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(99)
+        args = default_args(batch_size=2, device=dev, ho=True, weight_decay=5e-4, lambda_pa=0.5)
+        model = NetModel(args)
+        assert model.deterministic and model._d_graph_on == (flag == "1") and model._d_reducer.active
+        losses = []
+        for step in range(5):
+            images, labels = O.synthetic_batch(2, 512, 512, seed=step)
+            model.gp_alpha = torch.rand(2, 1, 1, 1, generator=torch.Generator().manual_seed(70 + step)).to(dev)
+            torch.manual_seed(500 + step)
+            model.adjust_learning_rate(args.lr_d, model.D_solver, step * 1000)
+            model.set_input((images, labels, None, None))
+            model.optimize_parameters()
+            losses.append([model.G_loss, model.mc_G_loss, model.pi_G_loss, model.pa_G_loss, model.D_loss])
+        torch.cuda.synchronize()
+        assert len(model._d_graphs) == (1 if flag == "1" else 0)
+        torch.save({"losses": losses, "student": _snap(model.student), "D": _snap(model.D_model)}, os.path.join(outdir, "dg%s.pt" % flag))
+    finally:
+        dist.destroy_process_group()
+        torch.backends.cudnn.enabled = True
+        torch.use_deterministic_algorithms(False)
+
+
+def test_solo_rccl_d_step_hipgraph_with_the_all_reduce_behind_it_equals_eager_bit_for_bit():
+    """SKD_D_GRAPH=1 in the N > 1 form (one-rank RCCL communicator): the capture holds no collective, the critic's gradients are
+    averaged after the replay -- deterministic mode, two eager + capture + two replay steps: the same bits as the eager D step with its
+    hook-driven all-reduce, in every loss and every student / discriminator tensor."""
+    with tempfile.TemporaryDirectory() as d:
+        for flag in ("0", "1"):
+            mp.spawn(_worker_solo_d_graph, args=(1, _free_port(), d, flag), nprocs=1, join=True)
+        eager = torch.load(os.path.join(d, "dg0.pt"))
+        graph = torch.load(os.path.join(d, "dg1.pt"))
+    assert eager["losses"] == graph["losses"], (eager["losses"], graph["losses"])
+    for what in ("student", "D"):
+        diff = [k for k, v in eager[what].items() if not torch.equal(v, graph[what][k])]
+        assert not diff, "%s state differs with the D step replayed from a hipGraph in the N > 1 form: %s" % (what, diff[:8])
