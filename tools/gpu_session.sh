@@ -183,6 +183,11 @@ PYEOF
       NG=$(python -c "import torch; print(torch.cuda.device_count())")
       stamp "scale8: $NG GPUs visible"
       if [ "$NG" -ge 2 ]; then
+        # first of all: does RCCL come up on this node, and does every collective kind the step issues return the right answer
+        n=$NG; [ "$n" -gt 8 ] && n=8
+        (timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29599 \
+          tools/rccl_probe.py) > $O/rccl_probe_n$n.json 2> $O/rccl_probe_n$n.err
+        stamp "scale8 rccl_probe N=$n rc=$?"; grep '^{' $O/rccl_probe_n$n.json | tee -a $O/session.log
         timeout 900 python -m pytest tests/test_distributed_gpu.py -m gpu -q --tb=short -s -k multi_gpu > $O/pytest_multi_gpu.log 2>&1
         stamp "scale8 multi_gpu tests rc=$?"; grep -E "passed|failed|error|skipped" $O/pytest_multi_gpu.log | tail -3 | tee -a $O/session.log
       fi
@@ -203,7 +208,7 @@ for l in sys.stdin:
       done
       if [ "$NG" -ge 2 ]; then
         n=$NG; [ "$n" -gt 8 ] && n=8
-        for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=1 SKD_ABN_RCCL_RESERVE_CUS=0" "SKD_SYNC_IPC=0" "SKD_TEACHER_GRAPH=force"; do
+        for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=1 SKD_ABN_RCCL_RESERVE_CUS=0" "SKD_SYNC_IPC=0" "SKD_TEACHER_GRAPH=force" "SKD_D_GRAPH=1"; do
           port=$((port+1)); f="$O/scale_ab_n${n}_$(echo $v | tr ' =' '__').json"
           (env $v timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
             bench.py --gpus $n --steps 10 --warmup 3) > "$f" 2>> $O/scale_ab.err
