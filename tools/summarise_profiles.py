@@ -22,7 +22,7 @@ def category(n):
     if "skd::" in n:
         for key, name in (("conv1x1", "skd fused bottleneck-tail GEMM (conv1x1 + ABN)"), ("sync_", "skd SyncABN mailbox exchange"), ("abn", "skd InPlace-ABN"), ("maxpool3x3s2", "skd stem max-pool"), ("ppm_fold", "skd PSP bottleneck fold"), ("gram", "skd pair-wise"), ("pairwise", "skd pair-wise"), ("maxpool", "skd pair-wise"),
                           ("maxunpool", "skd pair-wise"), ("l2_norm", "skd pair-wise"), ("ce_", "skd CE+upsample (DSN)"),
-                          ("ppm", "skd pyramid pooling"), ("pixelwise", "skd pixel-wise"), ("sn_", "skd spectral norm")):
+                          ("ppm", "skd pyramid pooling"), ("pixelwise", "skd pixel-wise"), ("sn_", "skd spectral norm"), ("head_", "skd classifier heads")):
             if key in n:
                 return name
         return "skd other"
