@@ -493,7 +493,10 @@ def main():
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
     roofline_entry = "skd_abn_apply_nhwc"
     gemm_entry = "skd_conv1x1_abn_pro_nhwc"
-    if not a.no_kernel_timing and rank == 0:
+    # (with the teacher on its own stream -- SKD_TEACHER_STREAM=1 -- its kernels share the chip with the student's forward in the timed
+    # steps: like the graph replay, they are timed in the extra serial-teacher steps below instead)
+    teacher_beside = getattr(model, "_teacher_stream", None) is not None
+    if not a.no_kernel_timing and rank == 0 and not teacher_beside:
         _lib.enable_kernel_timing([roofline_entry, gemm_entry])
     fence()
     t0 = time.perf_counter()
@@ -501,15 +504,17 @@ def main():
         losses = step(a.warmup + i)
     fence()
     el = time.perf_counter() - t0
-    recs = _lib.disable_kernel_timing() if (not a.no_kernel_timing and rank == 0) else {}
+    recs = _lib.disable_kernel_timing() if (not a.no_kernel_timing and rank == 0 and not teacher_beside) else {}
     roofline_steps = None
-    if not a.no_kernel_timing and getattr(model, "_teacher_graph_on", False):
-        # The roofline kernel lives in the frozen teacher, and in the timed steps the teacher is ONE hipGraph replay
-        # (SKD_TEACHER_GRAPH, default): its kernels have no host-side launch to put HIP events around.  So the same kernels are
-        # timed in extra steps right after the timed region with the teacher issued eagerly -- same process, shapes, weights and
-        # stream, D step on its own stream as in the timed region; rocprofv3's per-kernel averages of the same command (profiles/)
-        # cover both kinds of step and must agree.  `value` / `ms_per_step` come from the timed region only.
-        model._teacher_graph_on = False
+    if not a.no_kernel_timing and (getattr(model, "_teacher_graph_on", False) or teacher_beside):
+        # The roofline kernel lives in the frozen teacher, and in the timed steps the teacher is ONE hipGraph replay (SKD_TEACHER_GRAPH,
+        # default: no host-side launch to put HIP events around) or runs on its own stream beside the student's forward
+        # (SKD_TEACHER_STREAM=1: its kernels share the chip).  So the same kernels are timed in extra steps
+        # right after the timed region with the teacher issued eagerly on the main stream -- same process, shapes, weights, D step
+        # on its own stream as in the timed region; rocprofv3's per-kernel averages of the same command (profiles/) cover both
+        # kinds of step.  `value` / `ms_per_step` come from the timed region only.
+        graph_was_on, teacher_stream = model._teacher_graph_on, model._teacher_stream
+        model._teacher_graph_on, model._teacher_stream = False, None      # eager teacher on the main stream
         step(a.warmup + a.steps)                         # one untimed eager step (the eager path was last run during capture)
         if rank == 0:
             _lib.enable_kernel_timing([roofline_entry, gemm_entry])
@@ -520,7 +525,7 @@ def main():
         fence()
         if rank == 0:
             recs = _lib.disable_kernel_timing()
-        model._teacher_graph_on = True
+        model._teacher_graph_on, model._teacher_stream = graph_was_on, teacher_stream
     comm = None
     if not a.no_kernel_timing:
         # kernel rates are a statement about the kernel, so these three steps run the D step serially (in the timed steps
@@ -528,6 +533,7 @@ def main():
         # steps (the collectives need all of them); rank 0 brackets its hand-written kernels, and -- N > 1 -- the spans its
         # compute stream spends blocked on collectives (P.comm_timer: SyncABN exchanges, gradient all-reduce waits).
         d_stream, model._d_stream = model._d_stream, None
+        t_stream, model._teacher_stream = model._teacher_stream, None
         if rank == 0:
             _lib.enable_kernel_timing([n for n in timed if n not in (roofline_entry, gemm_entry)])
             if multi:
@@ -555,7 +561,7 @@ def main():
                                               if P.SyncMailbox.active() else "torch.distributed all_gather / all_reduce"),
                         "note": "per step, from 3 extra untimed steps with the D step serial: time rank 0's compute stream was "
                                 "blocked in the SyncABN exchanges (incl. waiting for the slowest rank) and in GradientAllReducer.finish() waits"}
-        model._d_stream = d_stream
+        model._d_stream, model._teacher_stream = d_stream, t_stream
     if multi:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -594,9 +600,10 @@ def main():
                             "bound": "mfma", "achieved": gm["achieved_TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(gm["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "detail": gm}
         line["roofline"]["measured_in"] = ("the %d timed steps" % a.steps if roofline_steps is None else
-                                           "%d extra steps right after the timed region with the teacher issued eagerly (in the timed steps the "
-                                           "teacher forward is one hipGraph replay: no host-side launch to bracket with HIP events); same kernels, "
-                                           "shapes and stream" % roofline_steps)
+                                           "%d extra steps right after the timed region with the teacher issued eagerly on the main stream (in the "
+                                           "timed steps the teacher forward is one hipGraph replay -- no host-side launch to bracket with HIP events "
+                                           "-- or, SKD_TEACHER_STREAM=1, shares the chip with the student's forward); same kernels, shapes, weights"
+                                           % roofline_steps)
         pmc = gemm_pmc_traffic()
         if pmc is not None:
             line["roofline"]["traffic"] = pmc["MB"]

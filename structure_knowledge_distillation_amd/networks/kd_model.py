@@ -221,7 +221,21 @@ class NetModel():
         # get co-scheduled.  One rank per GPU should not meet that, but no multi-GPU box was available to show it, the gain is
         # 1.2 %, and the failure mode is two orders of magnitude: the default for N > 1 stays the eager teacher.
         graph_env = os.environ.get("SKD_TEACHER_GRAPH", "1")
+        # SKD_TEACHER_STREAM=1 (opt-in, round 6): the frozen teacher's forward is issued EAGERLY on a second HIP stream beside the
+        # student's forward (kd_model.py:121-123 runs them back to back) and joined before the criteria.  Two independent kernel
+        # sequences fill each other's launch tails and partial last rounds -- on a COOL chip: same-box A/B of 20-step runs 61.85
+        # (teacher = one hipGraph replay on the main stream) -> 61.20 ms per step; after the chip has run the step for a minute
+        # (500-step runs: 63.8 ms either way) the gain is gone: the step is power-limited there and co-running kernels buy
+        # nothing (profiles/r09h_teacher_stream_ab.txt).  A default that only helps a short benchmark is not one: the default
+        # stays the graph.  NOT combined with the graph: a graph replayed beside another stream's kernels does not co-schedule on
+        # this runtime (89 ms per step; the same pathology as two ranks sharing a device and as graph branches, ROUND6_NOTES.md).
+        # Ignored in the deterministic mode: its three-stream configuration of im2col + rocBLAS kernels intermittently never
+        # finished inside the vendor stack in round 4 (the reason the rounds 2-4 switch was removed).
+        self._teacher_stream = (torch.cuda.Stream(device=device)
+                                if (os.environ.get("SKD_TEACHER_STREAM", "0") == "1" and graph_env != "force"
+                                    and torch.device(device).type == "cuda" and not self.deterministic) else None)
         self._teacher_graph_on = (graph_env in ("1", "force") and torch.device(device).type == "cuda"
+                                  and self._teacher_stream is None
                                   and (not parallel_old.replicated() or graph_env == "force")
                                   and not self.deterministic_no_graph())
         self._teacher_graphs = {}
@@ -421,11 +435,24 @@ class NetModel():
         return [t.contiguous() for t in preds[:2]] + list(preds[2:])
 
     def forward(self):
-        # kd_model.py:121-123.  (Rounds 2-4 could also issue the teacher on a stream of its own -- +0.7 % -- ; with the teacher a
-        # single hipGraph replay the host-side gain is gone, and under SKD_DETERMINISTIC=1 that three-stream configuration
-        # intermittently never finished its D backward inside the vendor stack: removed in round 5)
-        self.preds_T = self._teacher_forward()
+        # kd_model.py:121-123: teacher forward, student forward -- independent of each other, so (SKD_TEACHER_STREAM, __init__) the
+        # teacher runs on its own stream beside the student's forward and is joined before the criteria read its outputs.
+        side = self._teacher_stream
+        if side is None or not self.images.is_cuda:
+            self.preds_T = self._teacher_forward()
+            self.preds_S = self._student_forward()
+            return
+        main = torch.cuda.current_stream(self.images.device)
+        side.wait_stream(main)                 # the images (and, across steps, every reader of the previous teacher outputs: the
+        with torch.cuda.stream(side):          # step ends with main.wait_stream(D stream))
+            self.preds_T = self._teacher_forward()
         self.preds_S = self._student_forward()
+        main.wait_stream(side)
+        for t in self.preds_T:                 # allocated on the side stream, read on the main and the D stream from here on
+            if t is not None:
+                t.record_stream(main)
+                if self._d_stream is not None:
+                    t.record_stream(self._d_stream)
 
     def student_backward(self):
         args = self.args

@@ -70,13 +70,14 @@ def case_teacher_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode(monkeyp
         torch.use_deterministic_algorithms(False)
 
 
-def case_teacher_hipgraph_default_mode_replays_and_follows_weight_writes():
+def case_teacher_hipgraph_default_mode_replays_and_follows_weight_writes(monkeypatch):
     """Default mode (MIOpen convolutions): the graph is on, replays track the eager forward on fresh inputs, and writing the
     teacher's tensors (load_state_dict after construction) drops the captured graph instead of replaying stale folded weights."""
+    monkeypatch.delenv("SKD_TEACHER_STREAM", raising=False)
     torch.manual_seed(7)
     args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
     model = NetModel(args)
-    assert model._teacher_graph_on
+    assert model._teacher_graph_on and model._teacher_stream is None
     for step in range(3):
         images, labels = O.synthetic_batch(2, 512, 512, seed=10 + step)
         model.set_input((images, labels, None, None))

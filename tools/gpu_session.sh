@@ -255,7 +255,8 @@ EOF
         for v in "SKD_DIST_SOLO=0" "SKD_DIST_SOLO=1" "SKD_DIST_SOLO=1 SKD_ABN_SYNC_FUSED=1" "SKD_DIST_SOLO=1 SKD_SYNC_IPC=0" \
                  "SKD_DIST_SOLO=1 SKD_TEACHER_GRAPH=force" "SKD_DIST_SOLO=1 SKD_ABN_SYNC_FUSED=1 SKD_TEACHER_GRAPH=force" \
                  "SKD_DIST_SOLO=1 SKD_D_GRAPH=1" "SKD_DIST_SOLO=1 SKD_D_GRAPH=1 SKD_TEACHER_GRAPH=force" "SKD_DIST_SOLO=1 SKD_D_STREAM=0" \
-                 "SKD_DIST_SOLO=0 SKD_D_STREAM=0"; do
+                 "SKD_DIST_SOLO=0 SKD_D_STREAM=0" "SKD_DIST_SOLO=1 SKD_TEACHER_STREAM=1" "SKD_DIST_SOLO=1 SKD_TEACHER_STREAM=1 SKD_ABN_SYNC_FUSED=1" \
+                 "SKD_DIST_SOLO=0 SKD_TEACHER_STREAM=0"; do
           i=$((i+1))
           f=$O/solo_ab_${i}_$rep.json
           (env $v timeout 300 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-pairwise-sweep --no-kernel-timing) > $f 2>> $O/solo_ab.err
