@@ -493,7 +493,7 @@ def main():
     # kernels is collected in three extra, untimed steps afterwards (single-rank runs only: every rank must step).
     roofline_entry = "skd_abn_apply_nhwc"
     gemm_entry = "skd_conv1x1_abn_pro_nhwc"
-    # (with the teacher on its own stream -- SKD_TEACHER_STREAM=1 -- its kernels share the chip with the student's forward in the timed
+    # (with the teacher on its own stream -- the default at N = 1 -- its kernels share the chip with the student's forward in the timed
     # steps: like the graph replay, they are timed in the extra serial-teacher steps below instead)
     teacher_beside = getattr(model, "_teacher_stream", None) is not None
     if not a.no_kernel_timing and rank == 0 and not teacher_beside:
@@ -507,9 +507,9 @@ def main():
     recs = _lib.disable_kernel_timing() if (not a.no_kernel_timing and rank == 0 and not teacher_beside) else {}
     roofline_steps = None
     if not a.no_kernel_timing and (getattr(model, "_teacher_graph_on", False) or teacher_beside):
-        # The roofline kernel lives in the frozen teacher, and in the timed steps the teacher is ONE hipGraph replay (SKD_TEACHER_GRAPH,
-        # default: no host-side launch to put HIP events around) or runs on its own stream beside the student's forward
-        # (SKD_TEACHER_STREAM=1: its kernels share the chip).  So the same kernels are timed in extra steps
+        # The roofline kernel lives in the frozen teacher, and in the timed steps the teacher runs on its own stream beside the
+        # student's forward (SKD_TEACHER_STREAM, default at N = 1: its kernels share the chip) or is ONE hipGraph replay
+        # (SKD_TEACHER_STREAM=0: no host-side launch to put HIP events around).  So the same kernels are timed in extra steps
         # right after the timed region with the teacher issued eagerly on the main stream -- same process, shapes, weights, D step
         # on its own stream as in the timed region; rocprofv3's per-kernel averages of the same command (profiles/) cover both
         # kinds of step.  `value` / `ms_per_step` come from the timed region only.
@@ -601,9 +601,9 @@ def main():
                             "frac": round(gm["achieved_TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "detail": gm}
         line["roofline"]["measured_in"] = ("the %d timed steps" % a.steps if roofline_steps is None else
                                            "%d extra steps right after the timed region with the teacher issued eagerly on the main stream (in the "
-                                           "timed steps the teacher forward is one hipGraph replay -- no host-side launch to bracket with HIP events "
-                                           "-- or, SKD_TEACHER_STREAM=1, shares the chip with the student's forward); same kernels, shapes, weights"
-                                           % roofline_steps)
+                                           "timed steps the teacher forward shares the chip with the student's forward on a stream of its own -- or, "
+                                           "SKD_TEACHER_STREAM=0, is one hipGraph replay without host-side launches to bracket with HIP events); same "
+                                           "kernels, shapes, weights" % roofline_steps)
         pmc = gemm_pmc_traffic()
         if pmc is not None:
             line["roofline"]["traffic"] = pmc["MB"]

@@ -221,18 +221,22 @@ class NetModel():
         # get co-scheduled.  One rank per GPU should not meet that, but no multi-GPU box was available to show it, the gain is
         # 1.2 %, and the failure mode is two orders of magnitude: the default for N > 1 stays the eager teacher.
         graph_env = os.environ.get("SKD_TEACHER_GRAPH", "1")
-        # SKD_TEACHER_STREAM=1 (opt-in, round 6): the frozen teacher's forward is issued EAGERLY on a second HIP stream beside the
-        # student's forward (kd_model.py:121-123 runs them back to back) and joined before the criteria.  Two independent kernel
-        # sequences fill each other's launch tails and partial last rounds -- on a COOL chip: same-box A/B of 20-step runs 61.85
-        # (teacher = one hipGraph replay on the main stream) -> 61.20 ms per step; after the chip has run the step for a minute
-        # (500-step runs: 63.8 ms either way) the gain is gone: the step is power-limited there and co-running kernels buy
-        # nothing (profiles/r09h_teacher_stream_ab.txt).  A default that only helps a short benchmark is not one: the default
-        # stays the graph.  NOT combined with the graph: a graph replayed beside another stream's kernels does not co-schedule on
-        # this runtime (89 ms per step; the same pathology as two ranks sharing a device and as graph branches, ROUND6_NOTES.md).
-        # Ignored in the deterministic mode: its three-stream configuration of im2col + rocBLAS kernels intermittently never
-        # finished inside the vendor stack in round 4 (the reason the rounds 2-4 switch was removed).
+        # SKD_TEACHER_STREAM (round 6; default ON at N = 1): the frozen teacher's forward is issued EAGERLY on a second HIP stream
+        # beside the student's forward (kd_model.py:121-123 runs them back to back) and joined before the criteria.  Two independent
+        # kernel sequences fill each other's launch tails and partial last rounds.  One box, interleaved
+        # (profiles/r09k_teacher_stream_one_box_cool_long_warm.txt): 61.77 (teacher = one hipGraph replay on the main stream) ->
+        # 61.01 ms per step in 20-step runs on the fresh box, 61.87 -> 61.10 over 500 steps, 61.85 -> 61.01 in 20-step runs right
+        # after those; on a slower box of the pool (63.6-63.9 ms in every run) it was neutral (profiles/r09h_teacher_stream_ab.txt).
+        # NOT combined with the graph: a graph replayed beside another stream's kernels does not co-schedule on this runtime (89 ms
+        # per step; the same pathology as two ranks sharing a device and as graph branches, ROUND6_NOTES.md) -- SKD_TEACHER_GRAPH=
+        # force selects the graph and switches the stream off; SKD_TEACHER_STREAM=0 gives the round-4/5 default (graph, one stream).
+        # Never in the deterministic mode: its three-stream configuration of im2col + rocBLAS kernels with atomics off
+        # intermittently never finished inside the vendor stack in round 4 -- the reason the rounds 2-4
+        # switch of this name was removed; the default mode never hung then and has not in this round's 4000 steps and two full
+        # test-suite runs.  N > 1: opt-in only (SKD_TEACHER_STREAM=1), like every other form no multi-GPU box has run.
+        stream_env = os.environ.get("SKD_TEACHER_STREAM", "0" if parallel_old.replicated() else "1")
         self._teacher_stream = (torch.cuda.Stream(device=device)
-                                if (os.environ.get("SKD_TEACHER_STREAM", "0") == "1" and graph_env != "force"
+                                if (stream_env == "1" and graph_env != "force"
                                     and torch.device(device).type == "cuda" and not self.deterministic) else None)
         self._teacher_graph_on = (graph_env in ("1", "force") and torch.device(device).type == "cuda"
                                   and self._teacher_stream is None

@@ -71,9 +71,10 @@ def case_teacher_hipgraph_equals_eager_bit_for_bit_in_deterministic_mode(monkeyp
 
 
 def case_teacher_hipgraph_default_mode_replays_and_follows_weight_writes(monkeypatch):
-    """Default mode (MIOpen convolutions): the graph is on, replays track the eager forward on fresh inputs, and writing the
-    teacher's tensors (load_state_dict after construction) drops the captured graph instead of replaying stale folded weights."""
-    monkeypatch.delenv("SKD_TEACHER_STREAM", raising=False)
+    """Default mode (MIOpen convolutions), SKD_TEACHER_STREAM=0 (the N = 1 default since the end of round 6 is the eager teacher on
+    its own stream): the graph is on, replays track the eager forward on fresh inputs, and writing the teacher's tensors
+    (load_state_dict after construction) drops the captured graph instead of replaying stale folded weights."""
+    monkeypatch.setenv("SKD_TEACHER_STREAM", "0")
     torch.manual_seed(7)
     args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
     model = NetModel(args)

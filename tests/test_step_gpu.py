@@ -645,8 +645,8 @@ def test_channels_last_abn_any_channel_count(C):
 
 
 def test_optimize_parameters_teacher_stream_equals_serial(monkeypatch):
-    """The frozen teacher's forward on its own HIP stream beside the student's forward (SKD_TEACHER_STREAM=1, opt-in, round 6)
-    against the teacher issued first on the main stream: same operations per data dependency, so -- with the yard-stick of
+    """The frozen teacher's forward on its own HIP stream beside the student's forward (SKD_TEACHER_STREAM, the N = 1 default since the end of
+    round 6) against the teacher issued first on the main stream (as one hipGraph replay: SKD_TEACHER_STREAM=0): same operations per data dependency, so -- with the yard-stick of
     two runs of the serial order -- the same losses and the same parameters after the first step; a student forward that read a
     half-written teacher output, or criteria released before the teacher had finished, would show in step 0."""
     _stream_equals_serial(monkeypatch, "SKD_TEACHER_STREAM", "_teacher_stream", loss_floor=1e-5)
