@@ -33,7 +33,11 @@ for sec in "$@"; do
     bench_prof)
       (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- \
         python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-pairwise-sweep > $O/prof_bench.log 2>&1)
-      stamp "bench_prof rc=$?" ;;
+      stamp "bench_prof rc=$?"
+      # the roofline kernel per hardware queue: its launches beside the student's forward (teacher stream, timed steps) against its
+      # launches on the main stream (the steps bench.py brackets with HIP events)
+      T=$(find $O/prof_bench -name "*kernel_trace.csv" | head -1)
+      [ -n "$T" ] && python tools/kernel_by_queue.py $T conv1x1_abn_kernel $O/tail_gemm_by_queue.md | tee -a $O/session.log ;;
     micro)
       timeout 300 python tools/kernel_microbench.py time 20 > $O/micro.jsonl 2> $O/micro.err
       stamp "micro rc=$?"; grep -v manifest $O/micro.jsonl | cut -c1-230 | tee -a $O/session.log ;;
