@@ -451,12 +451,39 @@ class NetModel():
         with torch.cuda.stream(side):          # step ends with main.wait_stream(D stream))
             self.preds_T = self._teacher_forward()
         self.preds_S = self._student_forward()
+        # The join is LATE: the first read of ``self.preds_T`` (a property) makes the main stream wait for the teacher.  What does not
+        # read the teacher -- the student's CE and the critic's forward on the student's logits (student_backward) -- is issued
+        # before that and runs while the teacher's last layers still do: -0.4 ms per step (profiles/r09q_late_join_ab.txt).
+        self._teacher_pending = (main, side)
+
+    def _join_teacher(self):
+        pend = self._teacher_pending
+        if pend is None:
+            return
+        self._teacher_pending = None
+        main, side = pend
         main.wait_stream(side)
-        for t in self.preds_T:                 # allocated on the side stream, read on the main and the D stream from here on
+        cur = torch.cuda.current_stream(main.device)
+        if cur != main:                        # first read under another stream (the D step when neither Pi nor Pa is on)
+            cur.wait_stream(side)
+        for t in self._preds_T:                # allocated on the side stream, read on the main and the D stream from here on
             if t is not None:
                 t.record_stream(main)
                 if self._d_stream is not None:
                     t.record_stream(self._d_stream)
+
+    _teacher_pending = None
+    _preds_T = None
+
+    @property
+    def preds_T(self):
+        """The teacher's outputs of this step.  With the teacher on its own stream (SKD_TEACHER_STREAM) the first read joins it."""
+        self._join_teacher()
+        return self._preds_T
+
+    @preds_T.setter
+    def preds_T(self, value):
+        self._preds_T = value
 
     def student_backward(self):
         args = self.args
@@ -465,6 +492,18 @@ class NetModel():
         if self.log_teacher_ce and self.preds_T[1] is not None:     # kd_model.py:129 computes the teacher's CE and throws it away; off unless asked for
             self._scalars["mc_T_loss"] = self.criterion(self.preds_T, self.labels, is_target_scattered=False).detach()
         G_loss = temp
+        adv_term = None
+        if args.ho == True and self._teacher_pending is not None:  # noqa: E712
+            # the critic's forward on the student's logits does not read the teacher: issue it while the teacher is still running
+            # (the terms are still SUMMED in the reference's order below)
+            for p in self._d_params:
+                p.requires_grad_(False)
+            try:
+                d_out_S = self.parallel_D(self.preds_S[0], parallel=args.parallel)
+            finally:
+                for p in self._d_params:
+                    p.requires_grad_(True)
+            adv_term = args.lambda_d * self.criterion_adv_for_G(d_out_S, d_out_S, is_target_scattered=True)
         if args.pi == True:  # noqa: E712  (flags may arrive as 0/1)
             temp = args.lambda_pi * self.criterion_pixel_wise(self.preds_S, self.preds_T, is_target_scattered=True)
             self._scalars["pi_G_loss"] = temp.detach()
@@ -473,7 +512,9 @@ class NetModel():
             temp1 = self.criterion_pair_wise_for_interfeat(self.preds_S, self.preds_T, is_target_scattered=True)
             self._scalars["pa_G_loss"] = temp1.detach()
             G_loss = G_loss + args.lambda_pa * temp1
-        if args.ho == True:  # noqa: E712
+        if args.ho == True and adv_term is not None:  # noqa: E712
+            G_loss = G_loss + adv_term
+        elif args.ho == True:  # noqa: E712
             for p in self._d_params:
                 p.requires_grad_(False)
             try:
