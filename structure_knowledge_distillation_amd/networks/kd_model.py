@@ -485,25 +485,30 @@ class NetModel():
     def preds_T(self, value):
         self._preds_T = value
 
-    def student_backward(self):
+    def _adv_for_G(self, logits=None):
+        """The critic on the student's logits with its own parameters frozen (kd_model.py:141-143): lambda_d x the adversarial term."""
+        args = self.args
+        for p in self._d_params:
+            p.requires_grad_(False)
+        try:
+            d_out_S = self.parallel_D(self.preds_S[0] if logits is None else logits, parallel=args.parallel)
+        finally:
+            for p in self._d_params:
+                p.requires_grad_(True)
+        return args.lambda_d * self.criterion_adv_for_G(d_out_S, d_out_S, is_target_scattered=True)
+
+    def student_backward(self, on_logits_ready=None):
+        """kd_model.py:125-150.  ``on_logits_ready`` (the two-stream step): called once the student loss has finished back-propagating
+        through D and the teacher's outputs are joined -- the point from which the D step may run; only the split form below calls
+        it (the serial form's caller hooks the logits' gradient instead)."""
+        if self._teacher_pending is not None and os.environ.get("SKD_SPLIT_BACKWARD", "1") == "1":
+            return self._student_backward_split(on_logits_ready)
         args = self.args
         temp = self.criterion(self.preds_S, self.labels, is_target_scattered=False)
         self._scalars["mc_G_loss"] = temp.detach()
         if self.log_teacher_ce and self.preds_T[1] is not None:     # kd_model.py:129 computes the teacher's CE and throws it away; off unless asked for
             self._scalars["mc_T_loss"] = self.criterion(self.preds_T, self.labels, is_target_scattered=False).detach()
         G_loss = temp
-        adv_term = None
-        if args.ho == True and self._teacher_pending is not None:  # noqa: E712
-            # the critic's forward on the student's logits does not read the teacher: issue it while the teacher is still running
-            # (the terms are still SUMMED in the reference's order below)
-            for p in self._d_params:
-                p.requires_grad_(False)
-            try:
-                d_out_S = self.parallel_D(self.preds_S[0], parallel=args.parallel)
-            finally:
-                for p in self._d_params:
-                    p.requires_grad_(True)
-            adv_term = args.lambda_d * self.criterion_adv_for_G(d_out_S, d_out_S, is_target_scattered=True)
         if args.pi == True:  # noqa: E712  (flags may arrive as 0/1)
             temp = args.lambda_pi * self.criterion_pixel_wise(self.preds_S, self.preds_T, is_target_scattered=True)
             self._scalars["pi_G_loss"] = temp.detach()
@@ -512,21 +517,66 @@ class NetModel():
             temp1 = self.criterion_pair_wise_for_interfeat(self.preds_S, self.preds_T, is_target_scattered=True)
             self._scalars["pa_G_loss"] = temp1.detach()
             G_loss = G_loss + args.lambda_pa * temp1
-        if args.ho == True and adv_term is not None:  # noqa: E712
-            G_loss = G_loss + adv_term
-        elif args.ho == True:  # noqa: E712
-            for p in self._d_params:
-                p.requires_grad_(False)
-            try:
-                d_out_S = self.parallel_D(self.preds_S[0], parallel=args.parallel)
-            finally:
-                for p in self._d_params:
-                    p.requires_grad_(True)
-            G_loss = G_loss + args.lambda_d * self.criterion_adv_for_G(d_out_S, d_out_S, is_target_scattered=True)
+        if args.ho == True:  # noqa: E712
+            G_loss = G_loss + self._adv_for_G()
         self._s_reducer.arm()
         G_loss.backward()
         self._s_reducer.finish()
         self._scalars["G_loss"] = G_loss.detach()
+
+    def _student_backward_split(self, on_logits_ready=None):
+        """The same loss and (by linearity of the backward pass) the same gradients with the teacher still running on its own stream:
+        the terms that do not read the teacher -- the student's CE and the adversarial term -- are evaluated AND differentiated down
+        to the student's outputs first (criteria kernels and the critic's forward + data-gradient backward: launch-bound work that
+        runs under the teacher's MFMA-bound last layers); the first read of ``self.preds_T`` then joins the teacher, Pi and Pa are
+        evaluated and differentiated down to the student's outputs, and ONE backward pass through the backbone starts from the summed
+        output gradients.  G_loss is summed from the same term values in the reference's order (kd_model.py:125-146)."""
+        args = self.args
+        # what the criteria read of the student: the logits (CE, Pi, the critic), the DSN logits (CE), the PSP feature (Pa).  The criteria
+        # see them as LEAVES (detached copies of the same storage): the logits are computed FROM the feature, and a partial backward
+        # pass must stop at the student's outputs instead of running on through the heads
+        feat = getattr(getattr(self.criterion_pair_wise_for_interfeat, "module", None), "feat_ind", -5) % len(self.preds_S)
+        idx = [i for i in sorted({0, 1, feat}) if torch.is_tensor(self.preds_S[i]) and self.preds_S[i].requires_grad]
+        S = list(self.preds_S)
+        for i in idx:
+            S[i] = self.preds_S[i].detach().requires_grad_(True)
+        outs = [S[i] for i in idx]
+        ce = self.criterion(S, self.labels, is_target_scattered=False)
+        self._scalars["mc_G_loss"] = ce.detach()
+        early = ce
+        adv = None
+        if args.ho == True:  # noqa: E712
+            adv = self._adv_for_G(S[0])
+            early = ce + adv
+        grads = list(torch.autograd.grad(early, outs, allow_unused=True))
+        if self.log_teacher_ce and self.preds_T[1] is not None:
+            self._scalars["mc_T_loss"] = self.criterion(self.preds_T, self.labels, is_target_scattered=False).detach()
+        G_loss = ce.detach()
+        late = None
+        if args.pi == True:  # noqa: E712
+            temp = args.lambda_pi * self.criterion_pixel_wise(S, self.preds_T, is_target_scattered=True)     # (first read of preds_T: joins)
+            self._scalars["pi_G_loss"] = temp.detach()
+            G_loss = G_loss + temp.detach()
+            late = temp
+        if args.pa == True:  # noqa: E712
+            temp1 = self.criterion_pair_wise_for_interfeat(S, self.preds_T, is_target_scattered=True)
+            self._scalars["pa_G_loss"] = temp1.detach()
+            G_loss = G_loss + args.lambda_pa * temp1.detach()
+            late = args.lambda_pa * temp1 if late is None else late + args.lambda_pa * temp1
+        if adv is not None:
+            G_loss = G_loss + adv.detach()
+        self._join_teacher()                      # (no Pi and no Pa: nobody has read the teacher yet)
+        if on_logits_ready is not None:
+            on_logits_ready()
+        if late is not None:
+            for k, g in enumerate(torch.autograd.grad(late, outs, allow_unused=True)):
+                if g is not None:
+                    grads[k] = g if grads[k] is None else grads[k] + g
+        roots = [(self.preds_S[i], g) for i, g in zip(idx, grads) if g is not None]
+        self._s_reducer.arm()
+        torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
+        self._s_reducer.finish()
+        self._scalars["G_loss"] = G_loss
 
     def _d_loss(self, logits_S, logits_T, alpha):
         """kd_model.py:153-163 on two DETACHED logit tensors: the critic on teacher and student logits, the adversarial loss and
@@ -645,11 +695,17 @@ class NetModel():
             ready.record(torch.cuda.current_stream(grad.device))
             fired.append(True)
 
-        handle = self.preds_S[0].register_hook(_logits_grad_ready)
-        try:
-            self.student_backward()
-        finally:
-            handle.remove()
+        if self._teacher_pending is not None and os.environ.get("SKD_SPLIT_BACKWARD", "1") == "1":
+            def _ready():                       # (the split backward knows the point itself: after the critic's backward for G and the join)
+                ready.record(torch.cuda.current_stream(dev))
+                fired.append(True)
+            self.student_backward(_ready)
+        else:
+            handle = self.preds_S[0].register_hook(_logits_grad_ready)
+            try:
+                self.student_backward()
+            finally:
+                handle.remove()
         self.G_solver.step()
         if fired:
             side.wait_event(ready)

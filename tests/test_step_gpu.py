@@ -652,6 +652,15 @@ def test_optimize_parameters_teacher_stream_equals_serial(monkeypatch):
     _stream_equals_serial(monkeypatch, "SKD_TEACHER_STREAM", "_teacher_stream", loss_floor=1e-5)
 
 
+def test_split_student_backward_equals_the_single_backward_pass(monkeypatch):
+    """With the teacher on its own stream the student's loss is differentiated in two stages down to the student's outputs (CE and the
+    adversarial term under the still-running teacher, Pi and Pa after the join) and ONE backward pass through the backbone starts from
+    the summed output gradients (NetModel._student_backward_split).  By linearity that is the single G_loss.backward() of
+    kd_model.py:147 (SKD_SPLIT_BACKWARD=0): same losses, same parameters after the first step, to the yard-stick of two runs of the
+    single-pass form."""
+    _stream_equals_serial(monkeypatch, "SKD_SPLIT_BACKWARD", None, loss_floor=1e-5)
+
+
 def test_optimize_parameters_d_stream_equals_serial(monkeypatch):
     """NetModel.optimize_parameters() with the D step on its own HIP stream (default) against the strictly serial order of
     kd_model.py:167-173, from the same seed.  A D step released too early (before the student loss has back-propagated
@@ -671,7 +680,8 @@ def _stream_equals_serial(monkeypatch, env, attr, loss_floor):
         torch.manual_seed(99)
         args = default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5)
         model = NetModel(args)
-        assert (getattr(model, attr) is not None) == (flag == "1")
+        if attr is not None:
+            assert (getattr(model, attr) is not None) == (flag == "1")
         with torch.no_grad():
             model.D_model.attn1.gamma.fill_(0.25)
             model.D_model.attn2.gamma.fill_(-0.5)
