@@ -212,7 +212,7 @@ for l in sys.stdin:
       done
       if [ "$NG" -ge 2 ]; then
         n=$NG; [ "$n" -gt 8 ] && n=8
-        for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=1 SKD_ABN_RCCL_RESERVE_CUS=0" "SKD_SYNC_IPC=0" "SKD_TEACHER_GRAPH=force" "SKD_D_GRAPH=1"; do
+        for v in "SKD_ABN_SYNC_FUSED=1" "SKD_ABN_SYNC_FUSED=1 SKD_ABN_RCCL_RESERVE_CUS=0" "SKD_SYNC_IPC=0" "SKD_TEACHER_GRAPH=force" "SKD_D_GRAPH=1" "SKD_TEACHER_STREAM=1"; do
           port=$((port+1)); f="$O/scale_ab_n${n}_$(echo $v | tr ' =' '__').json"
           (env $v timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
             bench.py --gpus $n --steps 10 --warmup 3) > "$f" 2>> $O/scale_ab.err
