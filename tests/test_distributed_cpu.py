@@ -736,3 +736,56 @@ def test_bench_solo_rehearsal_prints_a_line_marked_as_rehearsal():
     line = lines[0]
     assert line["n_gpus"] == 1 and line["comm"]["ranks"] == 1 and line["comm"]["backend"] == "gloo" and "rehearsal" in line
     assert line["comm"]["form"] != "single rank" and line["comm"]["fallback_reason"] is None
+
+
+# ---------------------------------------------------------------------------------------------------
+# GradientAllReducer, round 6: a bucket segment has its parameter's strides and BECOMES p.grad after finish() (no unpack copy).
+def _reducer_views(rank, world):
+    from structure_knowledge_distillation_amd.utils.parallel import GradientAllReducer
+    torch.manual_seed(3)
+    w_cl = torch.nn.Parameter(torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last))    # a channels-last weight
+    w_1x1 = torch.nn.Parameter(torch.randn(5, 4, 1, 1).contiguous(memory_format=torch.channels_last))   # ambiguous strides (size-1 dims)
+    b = torch.nn.Parameter(torch.randn(6))
+    params = [w_cl, w_1x1, b]
+    red = GradientAllReducer(params, bucket_bytes=1 << 20)
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(10 + rank))
+    out = {}
+    for step, set_to_none in enumerate((True, False)):
+        if step == 0:
+            for p in params:
+                p.grad = None
+        else:
+            for p in params:
+                p.grad.zero_()                                  # zero_grad(set_to_none=False): the gradient already IS its bucket segment
+        red.arm()
+        y = torch.nn.functional.conv2d(x, w_cl, b, padding=1)
+        z = torch.nn.functional.conv2d(x, w_1x1)
+        ((rank + 1.0) * (y.square().sum() + z.square().sum())).backward()
+        red.finish()
+        out[step] = {"grads": [p.grad.clone() for p in params], "strides": [tuple(p.grad.stride()) for p in params],
+                     "is_view": [p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.buckets[0].params, red.buckets[0].views)]}
+    out["param_strides"] = [tuple(p.stride()) for p in params]
+    # the same gradients computed locally, for the expected average
+    local = []
+    for r in range(world):
+        ps = [p.detach().clone().requires_grad_(True) for p in params]
+        xr = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(10 + r))
+        yr = torch.nn.functional.conv2d(xr, ps[0], ps[2], padding=1)
+        zr = torch.nn.functional.conv2d(xr, ps[1])
+        ((r + 1.0) * (yr.square().sum() + zr.square().sum())).backward()
+        local.append([p.grad for p in ps])
+    out["want"] = [sum(g[i] for g in local) / world for i in range(3)]
+    return out
+
+
+def test_gradient_allreducer_segments_have_the_parameters_strides_and_become_the_gradients():
+    outs = _run("_reducer_views", 2)
+    for o in outs:
+        for step in (0, 1):
+            assert all(o[step]["is_view"]), "p.grad must BE its bucket segment after finish()"
+            for got, want in zip(o[step]["grads"], o["want"]):
+                assert rel(got, want) < 1e-5
+        assert o[0]["strides"][0] == o["param_strides"][0] and o[0]["strides"][0] != torch.empty(6, 4, 3, 3).stride()   # channels-last kept
+        assert o[0]["strides"][2] == (1,)
+    for a, b in zip(outs[0][1]["grads"], outs[1][1]["grads"]):
+        assert torch.equal(a, b)                                 # replicas hold identical averages
