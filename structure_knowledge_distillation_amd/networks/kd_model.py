@@ -112,6 +112,13 @@ def load_D_model(args, model, with_module=False):
     return True
 
 
+# With the teacher on its own stream: its deep-supervision branch (a 2.4 ms convolution whose output only the teacher's own CE would
+# read -- computed like the reference's forward does, kd_model.py:121, consumed by nothing) is issued LAST, behind the event the step's
+# criteria wait for, and works off beside the criteria and the start of the backbone backward: -0.46 ms per step, three of three
+# interleaved pairs (profiles/r09y_teacher_dsn_last_ab.txt).  False: in the reference's order (between layer3 and layer4).
+TEACHER_DSN_LAST = True
+
+
 class NetModel():
     def name(self):
         return "kd_seg"
@@ -448,37 +455,77 @@ class NetModel():
             return
         main = torch.cuda.current_stream(self.images.device)
         side.wait_stream(main)                 # the images (and, across steps, every reader of the previous teacher outputs: the
-        with torch.cuda.stream(side):          # step ends with main.wait_stream(D stream))
-            self.preds_T = self._teacher_forward()
+        outputs_ready = []                     # step ends with main.wait_stream(D stream) and main.wait_stream(teacher stream))
+
+        def _mark(logits, feature):
+            # (the criteria read the logits and the PSP feature: both exist here; NetModel hands the logits on as they are when
+            # they are already contiguous NCHW -- the head kernel's output -- so nothing of theirs is issued behind this point)
+            if logits.is_contiguous():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(logits.device))
+                outputs_ready.append(ev)
+
+        self.teacher.dsn_last = _mark if TEACHER_DSN_LAST else None
+        try:
+            with torch.cuda.stream(side):
+                self.preds_T = self._teacher_forward()
+        finally:
+            self.teacher.dsn_last = None
         self.preds_S = self._student_forward()
         # The join is LATE: the first read of ``self.preds_T`` (a property) makes the main stream wait for the teacher.  What does not
         # read the teacher -- the student's CE and the critic's forward on the student's logits (student_backward) -- is issued
         # before that and runs while the teacher's last layers still do: -0.4 ms per step (profiles/r09q_late_join_ab.txt).
-        self._teacher_pending = (main, side)
+        self._teacher_pending = (main, side, outputs_ready[0] if outputs_ready else None)
 
-    def _join_teacher(self):
+    def _join_teacher(self, whole=True):
+        """Make the main stream (and the current one, if different) wait for the teacher.  ``whole=False`` (the step's own criteria,
+        which read the logits and the PSP feature only): wait for the event recorded before the deep-supervision branch, which the
+        teacher stream works off behind it -- 2.5 ms of convolution that nothing on the critical path reads; ``_finish_teacher`` (end of
+        the step) or any read of the ``preds_T`` property waits for the rest."""
         pend = self._teacher_pending
-        if pend is None:
-            return
-        self._teacher_pending = None
-        main, side = pend
-        main.wait_stream(side)
-        cur = torch.cuda.current_stream(main.device)
-        if cur != main:                        # first read under another stream (the D step when neither Pi nor Pa is on)
-            cur.wait_stream(side)
-        for t in self._preds_T:                # allocated on the side stream, read on the main and the D stream from here on
-            if t is not None:
-                t.record_stream(main)
-                if self._d_stream is not None:
-                    t.record_stream(self._d_stream)
+        if pend is not None:
+            self._teacher_pending = None
+            main, side, ev = pend
+            cur = torch.cuda.current_stream(main.device)
+            for st in ([main] if cur == main else [main, cur]):     # (first read under another stream: the D step when neither Pi nor Pa is on)
+                if ev is not None:
+                    st.wait_event(ev)
+                else:
+                    st.wait_stream(side)
+            for t in self._preds_T:            # allocated on the side stream, read on the main and the D stream from here on
+                if t is not None:
+                    t.record_stream(main)
+                    if self._d_stream is not None:
+                        t.record_stream(self._d_stream)
+            self._teacher_tail = (main, side) if ev is not None else None
+        if whole:
+            self._finish_teacher()
+
+    def _finish_teacher(self):
+        tail = self._teacher_tail
+        if tail is not None:
+            self._teacher_tail = None
+            main, side = tail
+            main.wait_stream(side)
+            cur = torch.cuda.current_stream(main.device)
+            if cur != main:
+                cur.wait_stream(side)
+
+    _teacher_tail = None
+
+    def _teacher_main_outputs(self):
+        """The teacher's outputs for the step's own criteria and the D step (logits, PSP feature): joined up to the event in front of
+        the deep-supervision branch."""
+        self._join_teacher(whole=False)
+        return self._preds_T
 
     _teacher_pending = None
     _preds_T = None
 
     @property
     def preds_T(self):
-        """The teacher's outputs of this step.  With the teacher on its own stream (SKD_TEACHER_STREAM) the first read joins it."""
-        self._join_teacher()
+        """The teacher's outputs of this step.  With the teacher on its own stream (SKD_TEACHER_STREAM) a read joins ALL of it."""
+        self._join_teacher(whole=True)
         return self._preds_T
 
     @preds_T.setter
@@ -554,18 +601,18 @@ class NetModel():
         G_loss = ce.detach()
         late = None
         if args.pi == True:  # noqa: E712
-            temp = args.lambda_pi * self.criterion_pixel_wise(S, self.preds_T, is_target_scattered=True)     # (first read of preds_T: joins)
+            temp = args.lambda_pi * self.criterion_pixel_wise(S, self._teacher_main_outputs(), is_target_scattered=True)   # (joins)
             self._scalars["pi_G_loss"] = temp.detach()
             G_loss = G_loss + temp.detach()
             late = temp
         if args.pa == True:  # noqa: E712
-            temp1 = self.criterion_pair_wise_for_interfeat(S, self.preds_T, is_target_scattered=True)
+            temp1 = self.criterion_pair_wise_for_interfeat(S, self._teacher_main_outputs(), is_target_scattered=True)
             self._scalars["pa_G_loss"] = temp1.detach()
             G_loss = G_loss + args.lambda_pa * temp1.detach()
             late = args.lambda_pa * temp1 if late is None else late + args.lambda_pa * temp1
         if adv is not None:
             G_loss = G_loss + adv.detach()
-        self._join_teacher()                      # (no Pi and no Pa: nobody has read the teacher yet)
+        self._join_teacher(whole=False)           # (no Pi and no Pa: nobody has read the teacher yet)
         if on_logits_ready is not None:
             on_logits_ready()
         if late is not None:
@@ -594,7 +641,7 @@ class NetModel():
         if self._d_graph_on and parallel_old.ranks_on_this_device() <= 1 and self._discriminator_backward_graphed():
             return
         self.D_solver.zero_grad()
-        d_loss = self._d_loss(self.preds_S[0].detach(), self.preds_T[0].detach(), self.gp_alpha)
+        d_loss = self._d_loss(self.preds_S[0].detach(), self._teacher_main_outputs()[0].detach(), self.gp_alpha)
         self._d_reducer.arm()
         d_loss.backward()
         self._d_reducer.finish()
@@ -611,7 +658,7 @@ class NetModel():
         dropped and the step runs eagerly if a gradient went missing)."""
         if self._d_eager_steps < 2:
             return False
-        logits_S, logits_T = self.preds_S[0].detach(), self.preds_T[0].detach()
+        logits_S, logits_T = self.preds_S[0].detach(), self._teacher_main_outputs()[0].detach()
         key = (tuple(logits_S.shape), logits_S.device.index, self.gp_alpha is not None)
         entry = self._d_graphs.get(key)
         if entry is None:
@@ -681,6 +728,7 @@ class NetModel():
                 self.discriminator_backward()
             if torch.device(self.args.device).type == "cuda":
                 self._publish_scalars()
+            self._finish_teacher()
             return
         # Same operations, same order per data dependency: the D step may start as soon as the student's logits have
         # received their gradient -- by then the student loss has finished back-propagating through D, so D's
@@ -715,6 +763,7 @@ class NetModel():
             self.discriminator_backward()
         self._publish_scalars(side)         # the G step's scalars were produced on the main stream before `ready` was recorded
         main.wait_stream(side)
+        self._finish_teacher()              # the teacher's deep-supervision branch (long finished: issued behind the join event)
 
     def evalute_model(self, model, loader, gpu_id, input_size, num_classes, whole):
         """networks/evaluate.py via kd_model.py:178-181.  One process per GPU: the replicas are identical, so the validation

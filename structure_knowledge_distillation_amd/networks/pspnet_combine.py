@@ -314,6 +314,16 @@ class ResNet(nn.Module):
         # rows, 67.5 vs 67.2 ms per step -- and that variant is gone.)
         if getattr(self, "skip_dsn", False) and not torch.is_grad_enabled():
             x_dsn = None
+        elif getattr(self, "dsn_last", None) is not None and not torch.is_grad_enabled():
+            # frozen network on a stream of its own (NetModel, SKD_TEACHER_STREAM): the deep-supervision branch is independent of
+            # layer4 / pyramid / head and nothing the criteria read -- it is issued LAST, behind a call-back that marks the outputs
+            # the criteria do read as complete (same operations, same results)
+            x4 = self.layer4(x3)
+            x_feat_after_psp = self.pspmodule(x4)
+            x = self.head(x_feat_after_psp)
+            self.dsn_last(x, x_feat_after_psp)
+            x_dsn = self.dsn(x3)
+            return [x, x_dsn, x_feat_after_psp, x4, x3, x2, x1]
         else:
             x_dsn = self.dsn(x3)
         x4 = self.layer4(x3)
