@@ -644,6 +644,33 @@ def test_channels_last_abn_any_channel_count(C):
         assert rel(a, b) < 1e-5
 
 
+def test_teacher_stream_outputs_incl_the_deferred_dsn_branch_match_the_serial_forward(monkeypatch):
+    """NetModel.forward() with the teacher on its own stream issues the teacher's deep-supervision branch LAST, behind the event the
+    step's criteria wait for (kd_model.TEACHER_DSN_LAST).  A read of ``model.preds_T`` joins ALL of it: every output -- the DSN logits
+    included, which no criterion reads -- equals the serial eager forward's (MIOpen's run-to-run rounding), and after a whole step the
+    tail is joined (nothing of the teacher stream is left pending)."""
+    monkeypatch.setenv("SKD_TEACHER_STREAM", "1")
+    torch.manual_seed(5)
+    model = NetModel(default_args(batch_size=2, device=DEV, ho=True, weight_decay=5e-4, lambda_pa=0.5))
+    assert model._teacher_stream is not None and not model._teacher_graph_on
+    for step in range(2):
+        images, labels = O.synthetic_batch(2, 512, 512, seed=30 + step)
+        model.set_input((images, labels, None, None))
+        model.forward()
+        assert model._teacher_pending is not None and model._teacher_pending[2] is not None     # the event in front of the DSN branch
+        main = model._teacher_main_outputs()
+        assert model._teacher_pending is None and model._teacher_tail is not None               # joined up to the event only
+        got = model.preds_T                                                                     # the property: the rest
+        assert model._teacher_tail is None and got is main
+        want = model._teacher_forward_eager(model.images)
+        assert got[1] is not None
+        for a, b in zip(got[:3], want[:3]):
+            assert a.shape == b.shape and rel(a, b) < 2e-5
+        model.optimize_parameters()
+        assert model._teacher_pending is None and model._teacher_tail is None
+        assert all(v == v for v in (model.G_loss, model.D_loss))
+
+
 def test_optimize_parameters_teacher_stream_equals_serial(monkeypatch):
     """The frozen teacher's forward on its own HIP stream beside the student's forward (SKD_TEACHER_STREAM, the N = 1 default since the end of
     round 6) against the teacher issued first on the main stream (as one hipGraph replay: SKD_TEACHER_STREAM=0): same operations per data dependency, so -- with the yard-stick of
