@@ -529,7 +529,14 @@ class GradientAllReducer:
                 torch._foreach_copy_(dsts, srcs)         # one multi-tensor launch per bucket where the strides agree
         # RCCL averages in the collective (ncclAvg); gloo has no AVG: sum, then one scaling pass per bucket in finish()
         b.avg = _backend_has_avg(self.group) and b.flat.is_cuda
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if b.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.avg:
+            try:
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                return
+            except (RuntimeError, ValueError, NotImplementedError):      # a build whose RCCL has no ncclAvg: refused at the call, synchronously
+                _AVG["broken"] = True
+                b.avg = False
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for the in-flight buckets, launch any bucket whose parameters did not all receive a
@@ -570,7 +577,12 @@ def _dense_like(p):
     return True
 
 
+_AVG = {"broken": False}
+
+
 def _backend_has_avg(group=None):
+    if _AVG["broken"]:
+        return False
     try:
         return dist.get_backend(group) == "nccl"
     except Exception:

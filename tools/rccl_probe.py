@@ -45,6 +45,12 @@ def main():
     work.wait()
     want = ws * (ws + 1) / 2
     ok_sum = bool((flat == want).all())
+    av = torch.full((1024,), float(rk + 1), device=dev)                          # the gradient reducer averages in the collective
+    try:
+        dist.all_reduce(av, op=dist.ReduceOp.AVG)
+        ok_avg = bool((av - (ws + 1) / 2.0).abs().max() < 1e-6)
+    except Exception as e:                                                       # (the reducer falls back to SUM + scaling)
+        ok_avg = "refused: %s" % type(e).__name__
     mx = torch.tensor([float(rk)], device=dev)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     mn = torch.tensor([float(rk)], device=dev)
@@ -84,7 +90,7 @@ def main():
     torch.cuda.synchronize()
     us = 1e6 * (time.perf_counter() - t0) / reps
     out.update({"all_reduce_sum": ok_sum, "all_reduce_min_max": ok_minmax, "all_gather_into_tensor": ok_gather, "broadcast": ok_bcast,
-                "all_reduce_int64_and_f64": ok_int, "all_gather_object": ok_obj, "all_reduce_16MiB_us": round(us, 1),
+                "all_reduce_int64_and_f64": ok_int, "all_reduce_avg": ok_avg, "all_gather_object": ok_obj, "all_reduce_16MiB_us": round(us, 1),
                 "all_reduce_16MiB_busbw_GBs": round(2 * (ws - 1) / ws * bucket.numel() * 4 / us / 1e3, 2) if ws > 1 else None})
     good = ok_sum and ok_minmax and ok_gather and ok_bcast and ok_obj and ok_int
     out["ok"] = good
